@@ -1,0 +1,148 @@
+/*
+ * lion_hip.h -- C ABI of liblion_hip.so: the MI355X (gfx950) implementation of the
+ * LION / PVCNN hot path.
+ *
+ * Every entry point replaces one function of the reference's pybind/ATen operator modules
+ * (cited per function as file:line under /root/reference).  Conventions:
+ *   - plain device pointers + sizes, no torch types; all tensors C-contiguous, fp32 / int32;
+ *   - no allocation, no synchronisation, no global state inside: safe under hipGraph capture;
+ *     scratch memory is passed in (`ws`, size from the matching lion_*_workspace_bytes());
+ *   - every launch goes to the caller's `stream` (the reference mixes the legacy default stream
+ *     and the current stream; here it is always the caller's stream);
+ *   - outputs are fully overwritten (callers may pass torch.empty buffers) unless a parameter
+ *     is documented "pre-zeroed";
+ *   - return 0 on success, a positive hipError_t if a launch failed, or a negative LION_E* code
+ *     for a rejected argument.  Nothing ever calls exit() (the reference does: cuda_utils.cuh:28-37).
+ */
+#ifndef LION_HIP_H_
+#define LION_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *lionStream_t; /* hipStream_t */
+
+#define LION_OK 0
+#define LION_EINVAL (-1)      /* bad shape / null pointer */
+#define LION_EUNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define LION_EWORKSPACE (-3)  /* workspace too small */
+
+/* Library / device info. */
+int lion_abi_version(void);
+
+/* ---- K1+K2: avg_voxelize_forward, voxelization/vox.cpp:17-43 (vox.cu:18-72) -------------
+ * feat f32[B,C,N], coords i32[B,3,N] -> out f32[B,C,r^3], ind i32[B,N], cnt i32[B,r^3].
+ * Deterministic: each voxel sums its points in ascending point index (bit-exact vs oracle). */
+size_t lion_avg_voxelize_workspace_bytes(int B, int C, int N, int r);
+int lion_avg_voxelize_forward(const float *feat, const int32_t *coords, int B, int C, int N,
+                              int r, float *out, int32_t *ind, int32_t *cnt, void *ws,
+                              size_t ws_bytes, lionStream_t stream);
+
+/* ---- P1+K1+K2 fused: Voxelization.forward, models/pvcnn2_ada.py:173-188 -----------------
+ * coords f32[B,3,N] (raw point coords) -> norm_coords f32[B,3,N] (voxel units, clamped) and
+ * everything lion_avg_voxelize_forward returns.  feat may be NULL (C ignored): only
+ * norm_coords / ind / cnt are produced (pvcnn2_ada.py:185-186).
+ * The coordinate mean uses the fixed summation tree documented in oracle/lion_oracle.c. */
+int lion_voxelize_points_forward(const float *feat, const float *coords, int B, int C, int N,
+                                 int r, int normalize, float eps, float *out,
+                                 float *norm_coords, int32_t *ind, int32_t *cnt, void *ws,
+                                 size_t ws_bytes, lionStream_t stream);
+
+/* ---- K3: avg_voxelize_backward, vox.cpp:54-79 (vox.cu:86-110) --------------------------
+ * gy f32[B,C,r3], ind i32[B,N], cnt i32[B,r3] -> gx f32[B,C,N]. */
+int lion_avg_voxelize_backward(const float *gy, const int32_t *ind, const int32_t *cnt, int B,
+                               int C, int N, int r3, float *gx, lionStream_t stream);
+
+/* ---- K4: trilinear_devoxelize_forward, interpolate/trilinear_devox.cpp:18-55 -------------
+ * coords f32[B,3,N] (voxel units in [0,r-1]), feat f32[B,C,r^3] -> out f32[B,C,N];
+ * training != 0 also writes inds i32[B,8,N], wgts f32[B,8,N] (else they may be NULL). */
+int lion_trilinear_devoxelize_forward(const float *coords, const float *feat, int B, int C,
+                                      int N, int r, int training, float *out, int32_t *inds,
+                                      float *wgts, lionStream_t stream);
+
+/* ---- K5: trilinear_devoxelize_backward, trilinear_devox.cpp:67-95 -------------------------
+ * gy f32[B,C,N], inds i32[B,8,N], wgts f32[B,8,N] -> gx f32[B,C,r3] (fully written). */
+int lion_trilinear_devoxelize_backward(const float *gy, const int32_t *inds, const float *wgts,
+                                       int B, int C, int N, int r3, float *gx,
+                                       lionStream_t stream);
+
+/* ---- K6: ball_query, ball_query/ball_query.cpp:7-33 (ball_query.cu:19-50) ----------------
+ * centers f32[B,3,M], points f32[B,3,N] -> idx i32[B,M,U]: the first U points (ascending
+ * index) with d^2 < radius^2, padded with the first hit; all zero when there is none. */
+int lion_ball_query(const float *centers, const float *points, int B, int M, int N,
+                    float radius, int U, int32_t *idx, lionStream_t stream);
+
+/* ---- K7/K8: grouping, grouping/grouping.cu:18-36 / :58-77 --------------------------------
+ * feat f32[B,C,N], idx i32[B,M,U] -> out f32[B,C,M,U];  gy f32[B,C,M,U] -> gx f32[B,C,N]. */
+int lion_grouping_forward(const float *feat, const int32_t *idx, int B, int C, int N, int M,
+                          int U, float *out, lionStream_t stream);
+int lion_grouping_backward(const float *gy, const int32_t *idx, int B, int C, int N, int M,
+                           int U, float *gx, lionStream_t stream);
+
+/* ---- K9: furthest_point_sampling, sampling/sampling.cpp:43-58 (sampling.cu:86-167) -------
+ * coords f32[B,3,N] -> idx i32[B,M]; idx[.,0] = 0; ties resolved exactly as the reference's
+ * 512-thread reduction does (lowest (k mod 512, k)). */
+int lion_furthest_point_sampling(const float *coords, int B, int N, int M, int32_t *idx,
+                                 lionStream_t stream);
+
+/* ---- K10: gather_features, sampling/sampling.cu:17-31 / :52-66 --------------------------- */
+int lion_gather_features_forward(const float *feat, const int32_t *idx, int B, int C, int N,
+                                 int M, float *out, lionStream_t stream);
+int lion_gather_features_backward(const float *gy, const int32_t *idx, int B, int C, int N,
+                                  int M, float *gx, lionStream_t stream);
+
+/* ---- K11+K12: three_nearest_neighbors_interpolate, interpolate/neighbor_interpolate.cu ----
+ * points f32[B,3,N], centers f32[B,3,M], cfeat f32[B,C,M] ->
+ * out f32[B,C,N], idx i32[B,3,N], wgt f32[B,3,N]   (:20-75 then :90-116);
+ * backward gy f32[B,C,N] -> gx f32[B,C,M]           (:145-170). */
+int lion_three_nn_interpolate_forward(const float *points, const float *centers,
+                                      const float *cfeat, int B, int C, int N, int M,
+                                      float *out, int32_t *idx, float *wgt,
+                                      lionStream_t stream);
+int lion_three_nn_interpolate_backward(const float *gy, const int32_t *idx, const float *wgt,
+                                       int B, int C, int N, int M, float *gx,
+                                       lionStream_t stream);
+
+/* ---- E1: chamfer_3D.forward / .backward, chamfer3D/chamfer_cuda.cpp:17-33 ----------------
+ * xyz1 f32[B,N,3], xyz2 f32[B,M,3] (point-major) -> dist1 f32[B,N], idx1 i32[B,N],
+ * dist2 f32[B,M], idx2 i32[B,M]; lowest index wins ties (chamfer3D.cu:36,126).
+ * backward: gxyz1 f32[B,N,3], gxyz2 f32[B,M,3] fully written (chamfer3D.cu:155-185). */
+int lion_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M,
+                         float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
+                         lionStream_t stream);
+int lion_chamfer_backward(const float *xyz1, const float *xyz2, const float *gdist1,
+                          const float *gdist2, const int32_t *idx1, const int32_t *idx2, int B,
+                          int N, int M, float *gxyz1, float *gxyz2, lionStream_t stream);
+
+/* ---- E2: emd_ext.approxmatch_forward / matchcost_forward / matchcost_backward ------------
+ * PyTorchEMD/cuda/emd.cpp:7-27 (emd_kernel.cu:24-156, :199-241, :285-353).
+ * xyz1 f32[B,N,3], xyz2 f32[B,M,3] -> match f32[B,M,N]; cost f32[B]. */
+size_t lion_emd_workspace_bytes(int B, int N, int M);
+int lion_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int N, int M,
+                         float *match, void *ws, size_t ws_bytes, lionStream_t stream);
+int lion_emd_matchcost(const float *xyz1, const float *xyz2, const float *match, int B, int N,
+                       int M, float *cost, void *ws, size_t ws_bytes, lionStream_t stream);
+int lion_emd_matchcost_backward(const float *grad_cost, const float *xyz1, const float *xyz2,
+                                const float *match, int B, int N, int M, float *grad1,
+                                float *grad2, lionStream_t stream);
+
+/* ---- D1: one denoiser update, utils/diffusion_pvd.py -------------------------------------
+ * DDIM (:451-467): out = x*s + (c*eps + sigma*z).            z may be NULL when sigma == 0.
+ * DDPM (:283-296 + get_q_posterior_mean :475-486):
+ *   t>0 : out = k_outer*(x - k_a*eps/k_b) + scale*z*temp
+ *   t==0: out = k_outer*(x - k_a*eps)
+ * out may alias x. */
+int lion_ddim_update(const float *x, const float *eps, const float *z, size_t numel, float s,
+                     float c, float sigma, float *out, lionStream_t stream);
+int lion_ddpm_update(const float *x, const float *eps, const float *z, size_t numel,
+                     int t_is_zero, float k_outer, float k_a, float k_b, float scale,
+                     float temp, float *out, lionStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LION_HIP_H_ */

@@ -1,0 +1,99 @@
+"""ctypes binding of ``lion_amd/csrc/liblion_hip.so`` (C ABI declared in ``include/lion_hip.h``).
+
+There is NO fallback: if the shared library is missing or a call returns non-zero, a
+``RuntimeError`` is raised (reference convention: precondition -> exception,
+third_party/pvcnn/functional/src/utils.hpp:7-18; the reference's ``exit(-1)`` on launch
+failure, cuda_utils.cuh:28-37, is deliberately not reproduced).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "liblion_hip.so")
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/lion_hip.h one to one
+SIGNATURES = {
+    "lion_abi_version": (_i, []),
+    "lion_avg_voxelize_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "lion_avg_voxelize_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lion_voxelize_points_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp,
+                                          _vp, _sz, _vp]),
+    "lion_avg_voxelize_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_trilinear_devoxelize_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lion_trilinear_devoxelize_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "lion_grouping_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lion_grouping_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lion_furthest_point_sampling": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "lion_gather_features_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_gather_features_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_three_nn_interpolate_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lion_three_nn_interpolate_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_chamfer_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lion_chamfer_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "lion_emd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "lion_emd_approxmatch": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lion_emd_matchcost": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lion_emd_matchcost_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "lion_ddim_update": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp]),
+    "lion_ddpm_update": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp, _vp]),
+}
+
+_ERR = {-1: "LION_EINVAL (bad shape / null pointer)",
+        -2: "LION_EUNSUPPORTED (shape outside what the kernels implement)",
+        -3: "LION_EWORKSPACE (workspace too small)"}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load liblion_hip.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"lion_amd: HIP extension not built: {SO_PATH} is missing. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or lion_amd/csrc/build.sh. "
+            f"There is no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise RuntimeError(f"lion_amd: {SO_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = _ERR.get(code, f"hipError {code}" if code > 0 else f"error {code}")
+        raise RuntimeError(f"lion_amd: {what} failed: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    """Same preconditions the reference enforces with TORCH_CHECK (src/utils.hpp:7-18)."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("lion_amd: expected a CUDA(HIP) tensor; there is no CPU path")
+        if not t.is_contiguous():
+            raise RuntimeError("lion_amd: expected a contiguous tensor")

@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Builds liblion_hip.so for gfx950 (cross-compiles without a GPU).  -ffp-contract=off: the parity
+# contract is "one IEEE rounding per written operation", same as the oracle.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
+OBJS=()
+for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion "$@"; do
+  [ -f "$f.hip" ] || continue
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
+    $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
+  fi
+  OBJS+=("$f.o")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o liblion_hip.so "${OBJS[@]}"
+echo "built $(pwd)/liblion_hip.so"

@@ -1,0 +1,320 @@
+// emd.hip -- E2 approximate earth mover's distance (auction-style soft matching).
+//
+// Reference: third_party/PyTorchEMD/cuda/emd_kernel.cu:24-156 (approxmatch: ONE 512-thread block
+// per cloud pair walks 10 temperature levels x 3 O(N*M) passes), :199-241 (matchcost),
+// :285-353 (gradients), cuda/emd.cpp:7-27.
+//
+// MI355X design: the three passes of a level are separate launches with grid = (row tiles, batch)
+// so a batch of pairs fills the chip instead of 32 blocks; per row the loop over the other cloud
+// is in ascending index order exactly like the reference's, so each remainL/ratioL/remainR/ratioR
+// value is the same sequential float sum.  The other cloud is staged in LDS as float4 {x,y,z,w}
+// tiles (w = remainR / ratioL / ratioR) and read as broadcasts.  exp() is the hardware v_exp_f32
+// path (__expf), the same class of approximation as the reference's CUDA __expf.
+#include "common.h"
+
+namespace {
+
+constexpr int EMD_TILE = 1024;
+
+// level * ((x2-x1)^2 + (y2-y1)^2 + (z2-z1)^2), reference operand order
+__device__ __forceinline__ float lvl_d(float level, float x2, float y2, float z2, float x1,
+                                       float y1, float z1) {
+  return mul_rn(level, sqdist3(x2, y2, z2, x1, y1, z1));
+}
+
+__global__ void emd_init_kernel(int n, int m, float multiL, float multiR, float *__restrict__ remainL,
+                                float *__restrict__ remainR) {
+  const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) remainL[(size_t)b * n + i] = multiL;
+  if (i < m) remainR[(size_t)b * m + i] = multiR;
+}
+
+// pass 1 (emd_kernel.cu:50-81): ratioL[k] = remainL[k] / (1e-9 + sum_l exp(level*d) * remainR[l])
+__global__ __launch_bounds__(256) void emd_pass1_kernel(const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2, int n, int m,
+                                                        float level,
+                                                        const float *__restrict__ remainL,
+                                                        const float *__restrict__ remainR,
+                                                        float *__restrict__ ratioL) {
+  __shared__ float4 tile[EMD_TILE];
+  const int tid = threadIdx.x, b = blockIdx.y, k = blockIdx.x * 256 + tid;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  float x1 = 0, y1 = 0, z1 = 0;
+  if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
+  float suml = 1e-9f;
+  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, m - l0);
+    __syncthreads();
+    for (int l = tid; l < ln; l += 256)
+      tile[l] = make_float4(p2[(size_t)(l0 + l) * 3], p2[(size_t)(l0 + l) * 3 + 1],
+                            p2[(size_t)(l0 + l) * 3 + 2], remainR[(size_t)b * m + l0 + l]);
+    __syncthreads();
+#pragma unroll 4
+    for (int l = 0; l < ln; ++l) {
+      const float4 v = tile[l];
+      const float w = mul_rn(__expf(lvl_d(level, v.x, v.y, v.z, x1, y1, z1)), v.w);
+      suml = add_rn(suml, w);
+    }
+  }
+  if (k < n) ratioL[(size_t)b * n + k] = div_rn(remainL[(size_t)b * n + k], suml);
+}
+
+// pass 2 (emd_kernel.cu:83-117)
+__global__ __launch_bounds__(256) void emd_pass2_kernel(const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2, int n, int m,
+                                                        float level,
+                                                        const float *__restrict__ ratioL,
+                                                        float *__restrict__ remainR,
+                                                        float *__restrict__ ratioR) {
+  __shared__ float4 tile[EMD_TILE];
+  const int tid = threadIdx.x, b = blockIdx.y, l = blockIdx.x * 256 + tid;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  float x2 = 0, y2 = 0, z2 = 0;
+  if (l < m) { x2 = p2[l * 3]; y2 = p2[l * 3 + 1]; z2 = p2[l * 3 + 2]; }
+  float sumr = 0;
+  for (int k0 = 0; k0 < n; k0 += EMD_TILE) {
+    const int kn = min(EMD_TILE, n - k0);
+    __syncthreads();
+    for (int k = tid; k < kn; k += 256)
+      tile[k] = make_float4(p1[(size_t)(k0 + k) * 3], p1[(size_t)(k0 + k) * 3 + 1],
+                            p1[(size_t)(k0 + k) * 3 + 2], ratioL[(size_t)b * n + k0 + k]);
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < kn; ++k) {
+      const float4 v = tile[k];
+      const float w = mul_rn(__expf(lvl_d(level, x2, y2, z2, v.x, v.y, v.z)), v.w);
+      sumr = add_rn(sumr, w);
+    }
+  }
+  if (l < m) {
+    const float rr = remainR[(size_t)b * m + l];
+    sumr = mul_rn(sumr, rr);
+    const float consumption = fminf(div_rn(rr, add_rn(sumr, 1e-9f)), 1.0f);
+    ratioR[(size_t)b * m + l] = mul_rn(consumption, rr);
+    remainR[(size_t)b * m + l] = fmaxf(0.0f, sub_rn(rr, sumr));
+  }
+}
+
+// pass 3 (emd_kernel.cu:119-153): match[l][k] += w ; remainL[k] = max(0, remainL[k] - sum_l w)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void emd_pass3_kernel(const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2, int n, int m,
+                                                        float level,
+                                                        const float *__restrict__ ratioL,
+                                                        const float *__restrict__ ratioR,
+                                                        float *__restrict__ remainL,
+                                                        float *__restrict__ match) {
+  __shared__ float4 tile[EMD_TILE];
+  const int tid = threadIdx.x, b = blockIdx.y, k = blockIdx.x * 256 + tid;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  float x1 = 0, y1 = 0, z1 = 0, rl = 0;
+  if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; rl = ratioL[(size_t)b * n + k]; }
+  float suml = 0;
+  float *mt = match + (size_t)b * n * m;
+  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, m - l0);
+    __syncthreads();
+    for (int l = tid; l < ln; l += 256)
+      tile[l] = make_float4(p2[(size_t)(l0 + l) * 3], p2[(size_t)(l0 + l) * 3 + 1],
+                            p2[(size_t)(l0 + l) * 3 + 2], ratioR[(size_t)b * m + l0 + l]);
+    __syncthreads();
+    if (k < n) {
+#pragma unroll 4
+      for (int l = 0; l < ln; ++l) {
+        const float4 v = tile[l];
+        const float w = mul_rn(mul_rn(__expf(lvl_d(level, v.x, v.y, v.z, x1, y1, z1)), rl), v.w);
+        float *dst = mt + (size_t)(l0 + l) * n + k;
+        if (FIRST) *dst = w;               // first level: match starts at zero (0 + w == w)
+        else *dst = add_rn(*dst, w);
+        suml = add_rn(suml, w);
+      }
+    }
+  }
+  if (k < n) remainL[(size_t)b * n + k] = fmaxf(0.0f, sub_rn(remainL[(size_t)b * n + k], suml));
+}
+
+// matchcost (emd_kernel.cu:199-241): per-k partial sums over l, reduced per block into
+// partial[b][block]; a second tiny kernel sums the partials in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void emd_cost_partial_kernel(const float *__restrict__ xyz1,
+                                                               const float *__restrict__ xyz2,
+                                                               const float *__restrict__ match, int n,
+                                                               int m, float *__restrict__ partial) {
+  __shared__ float4 tile[EMD_TILE];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+  const int k = blockIdx.x * 256 + tid;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  const float *mt = match + (size_t)b * n * m;
+  float x1 = 0, y1 = 0, z1 = 0;
+  if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
+  float sub = 0;
+  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, m - l0);
+    __syncthreads();
+    for (int l = tid; l < ln; l += 256)
+      tile[l] = make_float4(p2[(size_t)(l0 + l) * 3], p2[(size_t)(l0 + l) * 3 + 1],
+                            p2[(size_t)(l0 + l) * 3 + 2], 0.f);
+    __syncthreads();
+    if (k < n)
+#pragma unroll 4
+      for (int l = 0; l < ln; ++l) {
+        const float4 v = tile[l];
+        sub = add_rn(sub, mul_rn(sqdist3(v.x, v.y, v.z, x1, y1, z1), mt[(size_t)(l0 + l) * n + k]));
+      }
+  }
+  for (int s = 32; s >= 1; s >>= 1) sub = add_rn(sub, __shfl_xor(sub, s, 64));
+  if (lane == 0) red[wave] = sub;
+  __syncthreads();
+  if (tid == 0)
+    partial[(size_t)b * gridDim.x + blockIdx.x] = add_rn(add_rn(red[0], red[1]), add_rn(red[2], red[3]));
+}
+
+__global__ void emd_cost_final_kernel(const float *__restrict__ partial, int nblk, int B,
+                                      float *__restrict__ cost) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0;
+  for (int i = 0; i < nblk; ++i) s = add_rn(s, partial[(size_t)b * nblk + i]);
+  cost[b] = s;
+}
+
+// grad wrt xyz1 (emd_kernel.cu:332-353): thread per point l of cloud 1, k ascending
+__global__ __launch_bounds__(256) void emd_grad1_kernel(const float *__restrict__ grad_cost,
+                                                        const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2,
+                                                        const float *__restrict__ match, int n, int m,
+                                                        float *__restrict__ grad1) {
+  __shared__ float4 tile[EMD_TILE];
+  const int tid = threadIdx.x, b = blockIdx.y, l = blockIdx.x * 256 + tid;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  const float *mt = match + (size_t)b * n * m;
+  float x1 = 0, y1 = 0, z1 = 0;
+  if (l < n) { x1 = p1[l * 3]; y1 = p1[l * 3 + 1]; z1 = p1[l * 3 + 2]; }
+  float dx = 0, dy = 0, dz = 0;
+  for (int k0 = 0; k0 < m; k0 += EMD_TILE) {
+    const int kn = min(EMD_TILE, m - k0);
+    __syncthreads();
+    for (int k = tid; k < kn; k += 256)
+      tile[k] = make_float4(p2[(size_t)(k0 + k) * 3], p2[(size_t)(k0 + k) * 3 + 1],
+                            p2[(size_t)(k0 + k) * 3 + 2], 0.f);
+    __syncthreads();
+    if (l < n)
+#pragma unroll 4
+      for (int k = 0; k < kn; ++k) {
+        const float4 v = tile[k];
+        const float d = mul_rn(mt[(size_t)(k0 + k) * n + l], 2.0f);
+        dx = add_rn(dx, mul_rn(sub_rn(x1, v.x), d));
+        dy = add_rn(dy, mul_rn(sub_rn(y1, v.y), d));
+        dz = add_rn(dz, mul_rn(sub_rn(z1, v.z), d));
+      }
+  }
+  if (l < n) {
+    const float g = grad_cost[b];
+    grad1[((size_t)b * n + l) * 3 + 0] = mul_rn(dx, g);
+    grad1[((size_t)b * n + l) * 3 + 1] = mul_rn(dy, g);
+    grad1[((size_t)b * n + l) * 3 + 2] = mul_rn(dz, g);
+  }
+}
+
+// grad wrt xyz2 (emd_kernel.cu:285-325): one wave per point k of cloud 2, lanes stride over j
+__global__ __launch_bounds__(256) void emd_grad2_kernel(const float *__restrict__ grad_cost,
+                                                        const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2,
+                                                        const float *__restrict__ match, int n, int m,
+                                                        float *__restrict__ grad2) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y;
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= m) return;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  const float *row = match + (size_t)b * n * m + (size_t)k * n;
+  const float x2 = p2[k * 3], y2 = p2[k * 3 + 1], z2 = p2[k * 3 + 2];
+  float sx = 0, sy = 0, sz = 0;
+  for (int j = lane; j < n; j += 64) {
+    const float d = mul_rn(row[j], 2.0f);
+    sx = add_rn(sx, mul_rn(sub_rn(x2, p1[j * 3]), d));
+    sy = add_rn(sy, mul_rn(sub_rn(y2, p1[j * 3 + 1]), d));
+    sz = add_rn(sz, mul_rn(sub_rn(z2, p1[j * 3 + 2]), d));
+  }
+  for (int s = 32; s >= 1; s >>= 1) {
+    sx = add_rn(sx, __shfl_xor(sx, s, 64));
+    sy = add_rn(sy, __shfl_xor(sy, s, 64));
+    sz = add_rn(sz, __shfl_xor(sz, s, 64));
+  }
+  if (lane == 0) {
+    const float g = grad_cost[b];
+    grad2[((size_t)b * m + k) * 3 + 0] = mul_rn(sx, g);
+    grad2[((size_t)b * m + k) * 3 + 1] = mul_rn(sy, g);
+    grad2[((size_t)b * m + k) * 3 + 2] = mul_rn(sz, g);
+  }
+}
+
+static size_t emd_ws_floats(int B, int N, int M) {
+  const size_t nb = (size_t)lion_cdiv(N, 256);
+  // remainL[B,N] remainR[B,M] ratioL[B,N] ratioR[B,M] partial[B,nb]
+  return (size_t)B * (2 * (size_t)N + 2 * (size_t)M + nb) + 64;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t lion_emd_workspace_bytes(int B, int N, int M) {
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  return emd_ws_floats(B, N, M) * 4;
+}
+
+int lion_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int N, int M, float *match,
+                         void *ws, size_t ws_bytes, lionStream_t stream) {
+  if (!xyz1 || !xyz2 || !match || B <= 0 || N <= 0 || M <= 0) return LION_EINVAL;
+  if (!ws || ws_bytes < lion_emd_workspace_bytes(B, N, M)) return LION_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float *remainL = static_cast<float *>(ws);
+  float *remainR = remainL + (size_t)B * N;
+  float *ratioL = remainR + (size_t)B * M;
+  float *ratioR = ratioL + (size_t)B * N;
+  float multiL, multiR; // emd_kernel.cu:27-33 (integer division)
+  if (N >= M) { multiL = 1.f; multiR = (float)(N / M); }
+  else { multiL = (float)(M / N); multiR = 1.f; }
+  const int nmax = N > M ? N : M;
+  emd_init_kernel<<<dim3(lion_cdiv(nmax, 256), B), 256, 0, st>>>(N, M, multiL, multiR, remainL, remainR);
+  const dim3 gn(lion_cdiv(N, 256), B), gm(lion_cdiv(M, 256), B);
+  for (int j = 7; j >= -2; --j) {
+    float level = -powf(4.0f, (float)j); // :45-48
+    if (j == -2) level = 0.f;
+    emd_pass1_kernel<<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, remainL, remainR, ratioL);
+    emd_pass2_kernel<<<gm, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, remainR, ratioR);
+    if (j == 7)
+      emd_pass3_kernel<true><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, ratioR, remainL, match);
+    else
+      emd_pass3_kernel<false><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, ratioR, remainL, match);
+  }
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_emd_matchcost(const float *xyz1, const float *xyz2, const float *match, int B, int N, int M,
+                       float *cost, void *ws, size_t ws_bytes, lionStream_t stream) {
+  if (!xyz1 || !xyz2 || !match || !cost || B <= 0 || N <= 0 || M <= 0) return LION_EINVAL;
+  if (!ws || ws_bytes < lion_emd_workspace_bytes(B, N, M)) return LION_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float *partial = static_cast<float *>(ws) + (size_t)B * (2 * (size_t)N + 2 * (size_t)M);
+  const int nb = lion_cdiv(N, 256);
+  emd_cost_partial_kernel<<<dim3(nb, B), 256, 0, st>>>(xyz1, xyz2, match, N, M, partial);
+  emd_cost_final_kernel<<<lion_cdiv(B, 64), 64, 0, st>>>(partial, nb, B, cost);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_emd_matchcost_backward(const float *grad_cost, const float *xyz1, const float *xyz2,
+                                const float *match, int B, int N, int M, float *grad1, float *grad2,
+                                lionStream_t stream) {
+  if (!grad_cost || !xyz1 || !xyz2 || !match || !grad1 || !grad2 || B <= 0 || N <= 0 || M <= 0)
+    return LION_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  emd_grad1_kernel<<<dim3(lion_cdiv(N, 256), B), 256, 0, st>>>(grad_cost, xyz1, xyz2, match, N, M, grad1);
+  emd_grad2_kernel<<<dim3(lion_cdiv(M, 4), B), 256, 0, st>>>(grad_cost, xyz1, xyz2, match, N, M, grad2);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,160 @@
+// sampling.hip -- K9 furthest point sampling.
+//
+// Reference: third_party/pvcnn/functional/src/sampling/sampling.cu:86-167, sampling.cpp:43-58
+// (512 threads per cloud, two __syncthreads tree reductions per round, coordinates in 36 KiB of
+// shared memory, running distances in global memory).
+//
+// M-1 dependent rounds per cloud make this latency bound, so the design minimises the length of
+// one round: one 256-thread workgroup per cloud, the cloud's coordinates AND running min-distances
+// live in registers (PPT points per lane), the arg-max is a single 64-bit key max
+//   key = (float bits of d2) << 32 | ~((k & 511) << 20 | k)
+// (d2 >= 0 so its bit pattern is monotone) reduced with 6 xor-shuffles per wave and ONE barrier per
+// round (double-buffered 4-entry LDS exchange).  The low word reproduces the reference's tie-break
+// exactly: its strided per-thread scan + left-biased tree picks the lowest (k mod 512, k) among
+// equal distances (sampling.cu:141-159), so the indices are bit-exact, ties included.
+// Clouds with N > 256*32 use the same kernel with distances in a caller-provided global scratch?
+// No: they take the generic strided variant below (distances in LDS up to 32K points).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long fps_key(float d2, int k) {
+  const unsigned int tb = 0xffffffffu - (((unsigned)(k & 511) << 20) | (unsigned)k);
+  return ((unsigned long long)__float_as_uint(d2) << 32) | tb;
+}
+__device__ __forceinline__ int fps_key_index(unsigned long long key) {
+  return (int)((0xffffffffu - (unsigned)(key & 0xffffffffull)) & 0xfffffu);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const unsigned long long o = __shfl_xor(v, s, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ coords, int N, int M,
+                                                      int32_t *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *sx = reinterpret_cast<float *>(smem); // [3][N] copy for the "coords[old]" lookup
+  __shared__ unsigned long long wkey[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const float *co = coords + (size_t)b * 3 * N;
+  float x[PPT], y[PPT], z[PPT], td[PPT];
+#pragma unroll
+  for (int p = 0; p < PPT; ++p) {
+    const int k = tid + p * 256;
+    x[p] = y[p] = z[p] = 0.f;
+    td[p] = 1e38f; // sampling.cpp:53-54
+    if (k < N) {
+      x[p] = co[k]; y[p] = co[k + N]; z[p] = co[k + 2 * N];
+      sx[k] = x[p]; sx[N + k] = y[p]; sx[2 * N + k] = z[p];
+    }
+  }
+  int32_t *out = idx + (size_t)b * M;
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+  int old = 0;
+  for (int j = 1; j < M; ++j) {
+    const float x1 = sx[old], y1 = sx[N + old], z1 = sx[2 * N + old];
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const int k = tid + p * 256;
+      if (k < N) {
+        const float d = sqdist3(x[p], y[p], z[p], x1, y1, z1); // sampling.cu:133-134
+        const float d2 = d < td[p] ? d : td[p];
+        td[p] = d2;
+        const unsigned long long key = fps_key(d2, k);
+        best = key > best ? key : best;
+      }
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) wkey[j & 1][wave] = best;
+    __syncthreads();
+    unsigned long long k0 = wkey[j & 1][0], k1 = wkey[j & 1][1], k2 = wkey[j & 1][2],
+                       k3 = wkey[j & 1][3];
+    k0 = k1 > k0 ? k1 : k0;
+    k2 = k3 > k2 ? k3 : k2;
+    k0 = k2 > k0 ? k2 : k0;
+    old = fps_key_index(k0);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+// Generic variant: running distances in LDS (N <= 32768), coordinates re-read from global / L2.
+__global__ __launch_bounds__(1024) void fps_lds_kernel(const float *__restrict__ coords, int N,
+                                                       int M, int32_t *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *td = reinterpret_cast<float *>(smem);
+  __shared__ unsigned long long wkey[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const float *co = coords + (size_t)b * 3 * N;
+  for (int k = tid; k < N; k += 1024) td[k] = 1e38f;
+  int32_t *out = idx + (size_t)b * M;
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+  int old = 0;
+  for (int j = 1; j < M; ++j) {
+    const float x1 = co[old], y1 = co[old + N], z1 = co[old + 2 * (size_t)N];
+    unsigned long long best = 0ull;
+    for (int k = tid; k < N; k += 1024) {
+      const float d = sqdist3(co[k], co[k + N], co[k + 2 * (size_t)N], x1, y1, z1);
+      const float t = td[k];
+      const float d2 = d < t ? d : t;
+      td[k] = d2;
+      const unsigned long long key = fps_key(d2, k);
+      best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) wkey[j & 1][wave] = best;
+    __syncthreads();
+    unsigned long long m = wkey[j & 1][lane & 15];
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) {
+      const unsigned long long o = __shfl_xor(m, s, 64);
+      m = o > m ? o : m;
+    }
+    old = fps_key_index(m);
+    if (tid == 0) out[j] = old;
+  }
+}
+
+template <int PPT>
+static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx, hipStream_t st) {
+  const size_t lds = (size_t)3 * N * 4;
+  fps_reg_kernel<PPT><<<B, 256, lds, st>>>(coords, N, M, idx);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+} // namespace
+
+extern "C" int lion_furthest_point_sampling(const float *coords, int B, int N, int M, int32_t *idx,
+                                            lionStream_t stream) {
+  if (!coords || !idx || B <= 0 || N <= 0 || M < 0) return LION_EINVAL;
+  if (M == 0) return 0;
+  if (N > (1 << 20)) return LION_EUNSUPPORTED; // tie-break key holds 20 index bits
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (N <= 256) return launch_fps_reg<1>(coords, B, N, M, idx, st);
+  if (N <= 512) return launch_fps_reg<2>(coords, B, N, M, idx, st);
+  if (N <= 1024) return launch_fps_reg<4>(coords, B, N, M, idx, st);
+  if (N <= 2048) return launch_fps_reg<8>(coords, B, N, M, idx, st);
+  if (N <= 4096) return launch_fps_reg<16>(coords, B, N, M, idx, st);
+  if (N <= 32768) {
+    const size_t lds = (size_t)N * 4;
+    static size_t configured = 0;
+    if (lds > configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      configured = lds;
+    }
+    fps_lds_kernel<<<B, 1024, lds, st>>>(coords, N, M, idx);
+    LION_LAUNCH_CHECK();
+    return 0;
+  }
+  return LION_EUNSUPPORTED;
+}

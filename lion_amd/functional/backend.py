@@ -1,0 +1,223 @@
+"""Drop-in replacement for ``third_party.pvcnn.functional.backend`` (reference backend.py:8-27).
+
+The reference JIT-builds a pybind11/ATen CUDA module ``_pvcnn_backend`` and exposes it as
+``_backend``.  Here ``_backend`` is an object with exactly the same 12 callables
+(bindings.cpp:10-37, signatures in the per-op ``*.hpp`` files) implemented on top of the C ABI of
+``liblion_hip.so``.  This shim owns what the ATen side owned in the reference: dtype / device /
+contiguity checks, output allocation, current-stream lookup, error -> exception.
+
+Two extra callables (not in the reference) expose fused paths: ``voxelize_points_forward``
+(Voxelization.forward, pvcnn2_ada.py:173-188, in two launches) -- used by ``lion_amd.models``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+__all__ = ["_backend"]
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float32 tensor")  # CHECK_IS_FLOAT
+
+
+def _i32(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int32 tensor")  # CHECK_IS_INT
+
+
+class _HipBackend:
+    """The 12 operator entry points of the reference's ``_pvcnn_backend`` module."""
+
+    def __init__(self):
+        self._l = None
+
+    @property
+    def lib(self):
+        if self._l is None:
+            self._l = _lib.load()
+        return self._l
+
+    # -- sampling/sampling.cpp:8-24 ------------------------------------------------------------
+    def gather_features_forward(self, features, indices):
+        _lib.require_cuda(features, indices); _f32(features, "features"); _i32(indices, "indices")
+        b, c, n = features.shape
+        m = indices.shape[1]
+        out = torch.empty((b, c, m), device=features.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_gather_features_forward(
+            _lib.ptr(features), _lib.ptr(indices), b, c, n, m, _lib.ptr(out),
+            _lib.stream_ptr(features.device)), "gather_features_forward")
+        return out
+
+    # -- sampling/sampling.cpp:26-41 -----------------------------------------------------------
+    def gather_features_backward(self, grad_y, indices, n):
+        _lib.require_cuda(grad_y, indices); _f32(grad_y, "grad_y"); _i32(indices, "indices")
+        b, c, m = grad_y.shape
+        gx = torch.empty((b, c, n), device=grad_y.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_gather_features_backward(
+            _lib.ptr(grad_y), _lib.ptr(indices), b, c, n, m, _lib.ptr(gx),
+            _lib.stream_ptr(grad_y.device)), "gather_features_backward")
+        return gx
+
+    # -- sampling/sampling.cpp:43-58 -----------------------------------------------------------
+    def furthest_point_sampling(self, coords, num_samples):
+        _lib.require_cuda(coords); _f32(coords, "coords")
+        b, _, n = coords.shape
+        idx = torch.empty((b, num_samples), device=coords.device, dtype=torch.int32)
+        _lib.check(self.lib.lion_furthest_point_sampling(
+            _lib.ptr(coords), b, n, num_samples, _lib.ptr(idx), _lib.stream_ptr(coords.device)),
+            "furthest_point_sampling")
+        return idx
+
+    # -- ball_query/ball_query.cpp:7-33 --------------------------------------------------------
+    def ball_query(self, centers_coords, points_coords, radius, num_neighbors):
+        _lib.require_cuda(centers_coords, points_coords)
+        _f32(centers_coords, "centers_coords"); _f32(points_coords, "points_coords")
+        b, _, m = centers_coords.shape
+        n = points_coords.shape[2]
+        idx = torch.empty((b, m, num_neighbors), device=centers_coords.device, dtype=torch.int32)
+        _lib.check(self.lib.lion_ball_query(
+            _lib.ptr(centers_coords), _lib.ptr(points_coords), b, m, n, float(radius),
+            int(num_neighbors), _lib.ptr(idx), _lib.stream_ptr(idx.device)), "ball_query")
+        return idx
+
+    # -- grouping/grouping.cpp ----------------------------------------------------------------
+    def grouping_forward(self, features, indices):
+        _lib.require_cuda(features, indices); _f32(features, "features"); _i32(indices, "indices")
+        b, c, n = features.shape
+        _, m, u = indices.shape
+        out = torch.empty((b, c, m, u), device=features.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_grouping_forward(
+            _lib.ptr(features), _lib.ptr(indices), b, c, n, m, u, _lib.ptr(out),
+            _lib.stream_ptr(out.device)), "grouping_forward")
+        return out
+
+    def grouping_backward(self, grad_y, indices, n):
+        _lib.require_cuda(grad_y, indices); _f32(grad_y, "grad_y"); _i32(indices, "indices")
+        b, c, m, u = grad_y.shape
+        gx = torch.empty((b, c, n), device=grad_y.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_grouping_backward(
+            _lib.ptr(grad_y), _lib.ptr(indices), b, c, n, m, u, _lib.ptr(gx),
+            _lib.stream_ptr(gx.device)), "grouping_backward")
+        return gx
+
+    # -- interpolate/neighbor_interpolate.cpp --------------------------------------------------
+    def three_nearest_neighbors_interpolate_forward(self, points_coords, centers_coords,
+                                                    centers_features):
+        _lib.require_cuda(points_coords, centers_coords, centers_features)
+        _f32(points_coords, "points_coords"); _f32(centers_coords, "centers_coords")
+        _f32(centers_features, "centers_features")
+        b, c, m = centers_features.shape
+        n = points_coords.shape[2]
+        dev = points_coords.device
+        out = torch.empty((b, c, n), device=dev, dtype=torch.float32)
+        idx = torch.empty((b, 3, n), device=dev, dtype=torch.int32)
+        wgt = torch.empty((b, 3, n), device=dev, dtype=torch.float32)
+        _lib.check(self.lib.lion_three_nn_interpolate_forward(
+            _lib.ptr(points_coords), _lib.ptr(centers_coords), _lib.ptr(centers_features), b, c, n,
+            m, _lib.ptr(out), _lib.ptr(idx), _lib.ptr(wgt), _lib.stream_ptr(dev)),
+            "three_nearest_neighbors_interpolate_forward")
+        return out, idx, wgt
+
+    def three_nearest_neighbors_interpolate_backward(self, grad_y, indices, weights, m):
+        _lib.require_cuda(grad_y, indices, weights)
+        _f32(grad_y, "grad_y"); _i32(indices, "indices"); _f32(weights, "weights")
+        b, c, n = grad_y.shape
+        gx = torch.empty((b, c, m), device=grad_y.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_three_nn_interpolate_backward(
+            _lib.ptr(grad_y), _lib.ptr(indices), _lib.ptr(weights), b, c, n, m, _lib.ptr(gx),
+            _lib.stream_ptr(gx.device)), "three_nearest_neighbors_interpolate_backward")
+        return gx
+
+    # -- interpolate/trilinear_devox.cpp:18-55 -------------------------------------------------
+    def trilinear_devoxelize_forward(self, r, is_training, coords, features):
+        _lib.require_cuda(coords, features); _f32(coords, "coords"); _f32(features, "features")
+        b, c, r3 = features.shape
+        if r3 != r * r * r:
+            raise RuntimeError("features.size(2) must be r**3")
+        n = coords.shape[2]
+        dev = features.device
+        outs = torch.empty((b, c, n), device=dev, dtype=torch.float32)
+        if is_training:
+            inds = torch.empty((b, 8, n), device=dev, dtype=torch.int32)
+            wgts = torch.empty((b, 8, n), device=dev, dtype=torch.float32)
+        else:  # the reference returns [1]-shaped placeholders (trilinear_devox.cpp:45-54)
+            inds = torch.zeros((1,), device=dev, dtype=torch.int32)
+            wgts = torch.zeros((1,), device=dev, dtype=torch.float32)
+        _lib.check(self.lib.lion_trilinear_devoxelize_forward(
+            _lib.ptr(coords), _lib.ptr(features), b, c, n, int(r), int(bool(is_training)),
+            _lib.ptr(outs), _lib.ptr(inds) if is_training else None,
+            _lib.ptr(wgts) if is_training else None, _lib.stream_ptr(dev)),
+            "trilinear_devoxelize_forward")
+        return outs, inds, wgts
+
+    # -- interpolate/trilinear_devox.cpp:67-95 -------------------------------------------------
+    def trilinear_devoxelize_backward(self, grad_y, indices, weights, r):
+        _lib.require_cuda(grad_y, indices, weights)
+        _f32(grad_y, "grad_y"); _i32(indices, "indices"); _f32(weights, "weights")
+        b, c, n = grad_y.shape
+        r3 = r * r * r
+        gx = torch.empty((b, c, r3), device=grad_y.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_trilinear_devoxelize_backward(
+            _lib.ptr(grad_y), _lib.ptr(indices), _lib.ptr(weights), b, c, n, r3, _lib.ptr(gx),
+            _lib.stream_ptr(gx.device)), "trilinear_devoxelize_backward")
+        return gx
+
+    # -- voxelization/vox.cpp:17-43 -----------------------------------------------------------
+    def avg_voxelize_forward(self, features, coords, resolution):
+        _lib.require_cuda(features, coords); _f32(features, "features"); _i32(coords, "coords")
+        b, c, n = features.shape
+        r = int(resolution)
+        r3 = r * r * r
+        dev = features.device
+        out = torch.empty((b, c, r3), device=dev, dtype=torch.float32)
+        ind = torch.empty((b, n), device=dev, dtype=torch.int32)
+        cnt = torch.empty((b, r3), device=dev, dtype=torch.int32)
+        wsb = self.lib.lion_avg_voxelize_workspace_bytes(b, c, n, r)
+        ws = torch.empty((wsb,), device=dev, dtype=torch.uint8)
+        _lib.check(self.lib.lion_avg_voxelize_forward(
+            _lib.ptr(features), _lib.ptr(coords), b, c, n, r, _lib.ptr(out), _lib.ptr(ind),
+            _lib.ptr(cnt), _lib.ptr(ws), wsb, _lib.stream_ptr(dev)), "avg_voxelize_forward")
+        return out, ind, cnt
+
+    # -- voxelization/vox.cpp:54-79 -----------------------------------------------------------
+    def avg_voxelize_backward(self, grad_y, indices, cnt):
+        _lib.require_cuda(grad_y, indices, cnt)
+        _f32(grad_y, "grad_y"); _i32(indices, "indices"); _i32(cnt, "cnt")
+        b, c, s = grad_y.shape
+        n = indices.shape[1]
+        gx = torch.empty((b, c, n), device=grad_y.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_avg_voxelize_backward(
+            _lib.ptr(grad_y), _lib.ptr(indices), _lib.ptr(cnt), b, c, n, s, _lib.ptr(gx),
+            _lib.stream_ptr(gx.device)), "avg_voxelize_backward")
+        return gx
+
+    # -- fused: Voxelization.forward (pvcnn2_ada.py:173-188), not part of the reference module ---
+    def voxelize_points_forward(self, features, coords, resolution, normalize=True, eps=0.0):
+        """coords f32[B,3,N] raw -> (out f32[B,C,r^3] | None, norm_coords, ind, cnt)."""
+        _lib.require_cuda(features, coords); _f32(coords, "coords")
+        b, _, n = coords.shape
+        r = int(resolution)
+        r3 = r * r * r
+        dev = coords.device
+        c = 0
+        out = None
+        if features is not None:
+            _f32(features, "features")
+            c = features.shape[1]
+            out = torch.empty((b, c, r3), device=dev, dtype=torch.float32)
+        norm = torch.empty((b, 3, n), device=dev, dtype=torch.float32)
+        ind = torch.empty((b, n), device=dev, dtype=torch.int32)
+        cnt = torch.empty((b, r3), device=dev, dtype=torch.int32)
+        wsb = self.lib.lion_avg_voxelize_workspace_bytes(b, max(c, 1), n, r)
+        ws = torch.empty((wsb,), device=dev, dtype=torch.uint8)
+        _lib.check(self.lib.lion_voxelize_points_forward(
+            _lib.ptr(features), _lib.ptr(coords), b, c, n, r, int(bool(normalize)), float(eps),
+            _lib.ptr(out), _lib.ptr(norm), _lib.ptr(ind), _lib.ptr(cnt), _lib.ptr(ws), wsb,
+            _lib.stream_ptr(dev)), "voxelize_points_forward")
+        return out, norm, ind, cnt
+
+
+_backend = _HipBackend()
