@@ -23,6 +23,9 @@ __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, 
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+// NOTE: __fsqrt_rn() lowers to a bare v_sqrt_f32 (1 ulp) on gfx950; sqrtf() gets the correctly
+// rounded refinement sequence under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
+__device__ __forceinline__ float sqrt_rn(float a) { return sqrtf(a); }
 
 // (a-b)^2 + (c-d)^2 + (e-f)^2 evaluated left to right without contraction.
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by,

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
         if (i < N) {
           const float x = sub_rn(px[p], mean[0]), y = sub_rn(py[p], mean[1]),
                       z = sub_rn(pz[p], mean[2]);
-          const float nr = __fsqrt_rn(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z)));
+          const float nr = sqrt_rn(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z)));
           mx = nr > mx ? nr : mx;
         }
       }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(VT) void p1_kernel(const float *__restrict__ coords
     for (int k = tid; k < N; k += VT) {
       const float x = sub_rn(co[k], mean[0]), y = sub_rn(co[k + N], mean[1]),
                   z = sub_rn(co[k + 2 * (size_t)N], mean[2]);
-      const float nr = __fsqrt_rn(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z)));
+      const float nr = sqrt_rn(add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z)));
       mx = nr > mx ? nr : mx;
     }
     for (int s = 1; s < 64; s <<= 1) { const float o = __shfl_xor(mx, s, 64); mx = o > mx ? o : mx; }

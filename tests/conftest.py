@@ -37,5 +37,5 @@ def voxel_coords(rng, b, n, r, kind="gauss"):
     c = gaussian_cloud(rng, b, n) if kind == "gauss" else surface_cloud(rng, b, n)
     c = c - c.mean(2, keepdims=True)
     nrm = np.sqrt((c ** 2).sum(1, keepdims=True)).max(2, keepdims=True)
-    c = c / (nrm * 2.0) + 0.5
+    c = c / (np.maximum(nrm, 1e-12) * 2.0) + 0.5
     return np.clip(c * r, 0, r - 1).astype(np.float32)
