@@ -3,19 +3,26 @@
 // Reference: third_party/pvcnn/functional/src/voxelization/vox.cu:18-110, vox.cpp:17-79,
 //            models/pvcnn2_ada.py:173-188.
 //
-// MI355X design (not the reference's "one block per cloud + global float atomics + memset"):
-//   phase 1  vox_index_kernel   one 1024-thread workgroup per cloud.  The r^3 occupancy histogram
-//            lives in LDS (128 KiB at r=32, padded so the segmented scan is bank-conflict free),
-//            points are counting-sorted by (voxel, point index) and the sorted list, the dense
-//            count grid and the per-1024-voxel chunk offsets go to HBM with coalesced stores.
-//            No memset, no global atomics.  With FUSE_P1 the same kernel first normalises the raw
-//            float coordinates (mean / max-norm / round-half-even) using the fixed summation tree
-//            the oracle documents, so voxel indices are bit-exact.
-//   phase 2  vox_dense_kernel   writes the dense [C, r^3] grid exactly once with 16-byte coalesced
-//            stores straight from registers (>= 94 % of it is zeros); an occupied voxel gathers its
-//            points from the L2-resident feature rows in ascending point index, so every output
-//            float is bit-identical to the sequential oracle.  HBM traffic ~= the algorithmic
-//            4*B*(3N + C*N + C*r^3 + N + r^3) bytes.
+// MI355X design (not the reference's "one block per cloud + global float atomics + memset").
+// What was measured on the chip (tools/exp/*.hip) shaped it: a plain zero fill of the [B,C,r^3] grid
+// with one 16-byte store per lane per channel reaches 7.5-8.0 TB/s; every load that a store has to
+// wait for costs dearly once the memory pipe is saturated with stores (two dependent round trips
+// + a block barrier in front of the stores: 2.3 TB/s; one int4 load + one batch of independent
+// gathers: 5.8 TB/s).  Hence three kernels:
+//   1  vox_index_kernel  one 1024-thread workgroup per cloud.  The r^3 occupancy histogram lives in
+//      LDS (128 KiB at r=32, padded so the segmented scan is bank-conflict free); points are
+//      counting-sorted by (voxel, point index); outputs: ind, the dense count grid, a dense "slot"
+//      grid (rank of the voxel among the occupied ones, -1 if empty), the occupied-voxel list
+//      (start,count) and the sorted point list.  No memset, no global atomics.  With FUSE_P1 the
+//      kernel first normalises the raw float coordinates (mean / max-norm / round-half-even) with
+//      the fixed summation tree the oracle documents, so voxel indices are bit-exact.
+//   2  vox_mean_kernel   one lane per (occupied voxel, channel tile): sums the voxel's points in
+//      ascending point index (bit-exact vs the sequential oracle; 1-2 gathers from the L2-resident
+//      feature row on average) into a compact table vmean[B,C,U].
+//   3  vox_dense_kernel  writes the dense [C, r^3] grid exactly once: int4 slot load, (rare)
+//      independent table gathers for a 16-channel tile, then 16 back-to-back 16-byte stores per lane.
+//      >= 94 % of the lanes store zeros and never wait for anything but the slot load.
+// HBM traffic ~= the algorithmic 4*B*(3N + C*N + C*r^3 + N + r^3) bytes + the slot grid (4*B*r^3 x2).
 //   fallback (r^3 or N too large for LDS): memset + integer/float atomics, like the reference but
 //            with a (points x batch) grid.  Within 1e-6 of the oracle, not bit-exact.
 #include "common.h"
@@ -24,21 +31,21 @@ namespace {
 
 constexpr int VT = 1024;    // threads of the per-cloud index kernel
 constexpr int MAXP = 8;     // points per thread kept in registers  (N <= 8192)
-constexpr int CHUNK = 1024; // voxels per dense-write workgroup (256 threads x 4)
 constexpr int LDS_LIMIT = 160 * 1024;
 
 __device__ __forceinline__ int padv(int v) { return v + (v >> 5); }
 __host__ __device__ inline int align4i(int x) { return (x + 3) & ~3; }
 
 struct IndexLds {
-  int hist_words, tmp_words;
+  int hist_words, n_words;
   size_t bytes;
 };
-static inline IndexLds index_lds(int N, int r3) {
+static inline IndexLds index_lds(int N, long r3) {
   IndexLds l;
-  l.hist_words = align4i(r3 + (r3 >> 5) + 1);
-  l.tmp_words = align4i(N);
-  l.bytes = (size_t)(l.hist_words + l.tmp_words + 128) * 4;
+  l.hist_words = align4i((int)(r3 + (r3 >> 5) + 1));
+  l.n_words = align4i(N);
+  // hist | tmp[N] | ust[N] | 64 floats | 64 ints
+  l.bytes = ((size_t)l.hist_words + 2 * (size_t)l.n_words + 128) * 4;
   return l;
 }
 
@@ -46,13 +53,14 @@ template <bool FUSE_P1>
 __global__ __launch_bounds__(VT) void vox_index_kernel(
     const int32_t *__restrict__ coords_i, const float *__restrict__ coords_f, int N, int r,
     int normalize, float eps, float *__restrict__ norm_coords, int32_t *__restrict__ ind,
-    int32_t *__restrict__ cnt, int32_t *__restrict__ sorted, int32_t *__restrict__ chunk_start,
-    int nchunks, int hist_words, int tmp_words) {
+    int32_t *__restrict__ cnt, int32_t *__restrict__ vslot, int32_t *__restrict__ sorted,
+    int32_t *__restrict__ uinfo, int32_t *__restrict__ ucount, int hist_words, int n_words) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+  uint32_t *hist = reinterpret_cast<uint32_t *>(smem); // count, later (urank << 16) | count
   int32_t *tmp = reinterpret_cast<int32_t *>(hist + hist_words);
-  float *fscr = reinterpret_cast<float *>(tmp + tmp_words); // 64 floats
-  int *iscr = reinterpret_cast<int *>(fscr + 64);           // 64 ints
+  int32_t *ust = tmp + n_words;                         // (start << 16) | count per occupied voxel
+  float *fscr = reinterpret_cast<float *>(ust + n_words); // 64 floats
+  int *iscr = reinterpret_cast<int *>(fscr + 64);         // 64 ints
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
@@ -97,7 +105,6 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
       for (int s = 1; s < 16; s <<= 1) v = add_rn(v, __shfl_xor(v, s, 64));
       mean[a] = div_rn(v, (float)N);
     }
-    __syncthreads();
     float denom = 1.0f;
     if (normalize) {
       float mx = 0.0f;
@@ -168,126 +175,156 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
   __syncthreads();
 
   // exclusive scan of the histogram: thread t owns voxels [t*VPT, (t+1)*VPT) (conflict free
-  // thanks to the +v/32 padding), block scan of the per-thread totals, then rewrite each
-  // entry as (start << 16) | count.
+  // thanks to the +v/32 padding); one packed block scan gives both the point offset (start) and
+  // the rank among occupied voxels; each entry becomes (urank << 16) | count.
   const int VPT = (r3 + VT - 1) / VT;
   const int v0 = min(tid * VPT, r3), v1 = min(v0 + VPT, r3);
-  int local = 0;
-  for (int v = v0; v < v1; ++v) local += (int)hist[padv(v)];
-  const int incl = wave_incl_scan(local, lane);
+  int lp = 0, lo = 0;
+  for (int v = v0; v < v1; ++v) { const int c = (int)hist[padv(v)]; lp += c; lo += (c > 0); }
+  const int packed = (lp << 16) | lo; // points < 2^14, occupied <= N < 2^14
+  const int incl = wave_incl_scan(packed, lane);
   if (lane == 63) iscr[wave] = incl;
   __syncthreads();
-  int run = incl - local;
-  for (int w = 0; w < wave; ++w) run += iscr[w];
+  int excl = incl - packed;
+  for (int w = 0; w < wave; ++w) excl += iscr[w];
+  int run = excl >> 16, urun = excl & 0xffff;
   for (int v = v0; v < v1; ++v) {
     const uint32_t c = hist[padv(v)];
-    hist[padv(v)] = ((uint32_t)run << 16) | c;
-    run += (int)c;
+    if (c) {
+      hist[padv(v)] = ((uint32_t)urun << 16) | c;
+      ust[urun] = (run << 16) | (int)c;
+      ++urun;
+      run += (int)c;
+    }
   }
+  if (tid == VT - 1) ucount[b] = urun;
   __syncthreads();
 
   // bucket placement in arrival order, then the deterministic rank inside the bucket
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
     const int i = tid + p * VT;
-    if (i < N) tmp[(hist[padv(myv[p])] >> 16) + myarr[p]] = i;
+    if (i < N) tmp[(ust[hist[padv(myv[p])] >> 16] >> 16) + myarr[p]] = i;
   }
   __syncthreads();
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
     const int i = tid + p * VT;
     if (i < N) {
-      const uint32_t h = hist[padv(myv[p])];
-      const int s = (int)(h >> 16), c = (int)(h & 0xffffu);
+      const int h = ust[hist[padv(myv[p])] >> 16];
+      const int s = h >> 16, c = h & 0xffff;
       int rank = 0;
       for (int k = 0; k < c; ++k) rank += (tmp[s + k] < i) ? 1 : 0;
       sorted[(size_t)b * N + s + rank] = i;
     }
   }
-  for (int v = tid; v < r3; v += VT) cnt[(size_t)b * r3 + v] = (int32_t)(hist[padv(v)] & 0xffffu);
-  for (int q = tid; q <= nchunks; q += VT)
-    chunk_start[(size_t)b * (nchunks + 1) + q] =
-        (q * CHUNK < r3) ? (int32_t)(hist[padv(q * CHUNK)] >> 16) : N;
+  // dense outputs, 16 bytes per lane: counts and slots (r3 % 4 == 0)
+  for (int v = tid * 4; v < r3; v += VT * 4) {
+    int4 c, sl;
+    const uint32_t h0 = hist[padv(v)], h1 = hist[padv(v + 1)], h2 = hist[padv(v + 2)], h3 = hist[padv(v + 3)];
+    c.x = h0 & 0xffff; c.y = h1 & 0xffff; c.z = h2 & 0xffff; c.w = h3 & 0xffff;
+    sl.x = c.x ? (int)(h0 >> 16) : -1; sl.y = c.y ? (int)(h1 >> 16) : -1;
+    sl.z = c.z ? (int)(h2 >> 16) : -1; sl.w = c.w ? (int)(h3 >> 16) : -1;
+    *reinterpret_cast<int4 *>(cnt + (size_t)b * r3 + v) = c;
+    *reinterpret_cast<int4 *>(vslot + (size_t)b * r3 + v) = sl;
+  }
+  for (int u = tid; u < N; u += VT) uinfo[(size_t)b * N + u] = ust[u]; // entries >= U are unused
 }
 
-// Dense write of one (batch, channel tile, 1024-voxel chunk).
-template <int CT>
-__global__ __launch_bounds__(256) void vox_dense_kernel(
-    const float *__restrict__ feat, const int32_t *__restrict__ cnt,
-    const int32_t *__restrict__ sorted, const int32_t *__restrict__ chunk_start, int C, int N,
-    int r3, int nchunks, float *__restrict__ out) {
-  __shared__ int wt[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = blockIdx.x, b = blockIdx.z;
-  const int c_begin = blockIdx.y * CT, c_end = min(C, c_begin + CT);
-  const int v0 = chunk * CHUNK + tid * 4;
-  const bool inb = v0 < r3; // r3 % 4 == 0 is guaranteed by the launcher
-  const int cs0 = chunk_start[(size_t)b * (nchunks + 1) + chunk];
-  const int cs1 = chunk_start[(size_t)b * (nchunks + 1) + chunk + 1];
-  float *obase = out + ((size_t)b * C) * r3 + v0;
-
-  if (cs0 == cs1) { // whole chunk empty (wave-uniform): pure zero streaming
-    if (inb) {
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int c = c_begin; c < c_end; ++c) *reinterpret_cast<float4 *>(obase + (size_t)c * r3) = z;
-    }
-    return;
+// vmean[b][c][u] = sum_k feat[b][c][p_k] * (1/n), p_k ascending (vox.cu:59-71 with the order fixed
+// to ascending point index, as in the oracle).  One workgroup per (batch, tile of CT channels): the
+// CT feature rows are staged in LDS with coalesced 16-byte loads (random 4-byte gathers straight
+// from global memory cost one TA cycle per lane: 53 us for 3.2 M gathers; from LDS they are free),
+// then lanes walk the occupied voxels and write the table coalesced.
+__global__ __launch_bounds__(256) void vox_mean_kernel(const float *__restrict__ feat,
+                                                       const int32_t *__restrict__ sorted,
+                                                       const int32_t *__restrict__ uinfo,
+                                                       const int32_t *__restrict__ ucount, int C,
+                                                       int N, int CT, float *__restrict__ vmean) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *rows = reinterpret_cast<float *>(smem);            // [CT][N]
+  int32_t *ssrt = reinterpret_cast<int32_t *>(rows + (size_t)CT * N); // [N] sorted point list
+  int32_t *sinf = ssrt + N;                                  // [N] (start << 16) | count
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int c0 = blockIdx.x * CT, nc = min(CT, C - c0);
+  const float *src = feat + ((size_t)b * C + c0) * N;
+  const int tot = nc * N;
+  if ((N & 3) == 0) {
+    for (int i = tid * 4; i < tot; i += 1024)
+      *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
+  } else {
+    for (int i = tid; i < tot; i += 256) rows[i] = src[i];
   }
-
-  int c4[4] = {0, 0, 0, 0};
-  if (inb) {
-    const int4 t = *reinterpret_cast<const int4 *>(cnt + (size_t)b * r3 + v0);
-    c4[0] = t.x; c4[1] = t.y; c4[2] = t.z; c4[3] = t.w;
-  }
-  const int total = c4[0] + c4[1] + c4[2] + c4[3];
-  const int incl = wave_incl_scan(total, lane);
-  if (lane == 63) wt[wave] = incl;
+  // everything a lane will need comes in with this one batch of coalesced loads (a per-voxel
+  // uinfo -> sorted -> feature chain of dependent global loads was 7x slower)
+  const int U = ucount[b];
+  for (int i = tid; i < N; i += 256) ssrt[i] = sorted[(size_t)b * N + i];
+  for (int i = tid; i < U; i += 256) sinf[i] = uinfo[(size_t)b * N + i];
   __syncthreads();
-  int start = cs0 + incl - total;
-  for (int w = 0; w < wave; ++w) start += wt[w];
-
-  const int32_t *srt = sorted + (size_t)b * N;
-  float inv[4];
-  int off[4];
+  float *dst = vmean + ((size_t)b * C + c0) * N;
+  for (int u = tid; u < U; u += 256) {
+    const int info = sinf[u], st = info >> 16, n = info & 0xffff;
+    const float inv = div_rn(1.0f, (float)n); // vox.cu:66 (== float(1.0 / cnt))
+    const int32_t *srt = ssrt + st;
+    if (n <= 4) {
+      int p[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    inv[q] = c4[q] > 0 ? div_rn(1.0f, (float)c4[q]) : 0.0f; // vox.cu:66 (== float(1.0/cnt))
-    off[q] = (q == 0) ? 0 : off[q - 1] + c4[q - 1];
-  }
-  // common case: <= 4 points in these 4 voxels -> member indices in registers
-  int mi[4] = {0, 0, 0, 0};
-  if (total > 0 && total <= 4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < total) mi[k] = srt[start + k];
-  }
-
-  for (int c = c_begin; c < c_end; ++c) {
-    float val[4] = {0.f, 0.f, 0.f, 0.f};
-    if (total > 0) {
-      const float *frow = feat + ((size_t)b * C + c) * N;
-      if (total <= 4) {
-        float f[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f[k] = (k < total) ? frow[mi[k]] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k >= off[q] && k < off[q] + c4[q]) val[q] = add_rn(val[q], mul_rn(f[k], inv[q]));
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float acc = 0.f;
-          for (int k = 0; k < c4[q]; ++k)
-            acc = add_rn(acc, mul_rn(frow[srt[start + off[q] + k]], inv[q]));
-          val[q] = acc;
-        }
+      for (int k = 0; k < 4; ++k) p[k] = srt[k < n ? k : 0];
+      for (int c = 0; c < nc; ++c) {
+        const float *rw = rows + c * N;
+        float acc = mul_rn(rw[p[0]], inv); // 0 + x == x
+        const float a1 = add_rn(acc, mul_rn(rw[p[1]], inv));
+        acc = n > 1 ? a1 : acc;
+        const float a2 = add_rn(acc, mul_rn(rw[p[2]], inv));
+        acc = n > 2 ? a2 : acc;
+        const float a3 = add_rn(acc, mul_rn(rw[p[3]], inv));
+        acc = n > 3 ? a3 : acc;
+        dst[(size_t)c * N + u] = acc;
+      }
+    } else {
+      for (int c = 0; c < nc; ++c) {
+        const float *rw = rows + c * N;
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc = add_rn(acc, mul_rn(rw[srt[k]], inv));
+        dst[(size_t)c * N + u] = acc;
       }
     }
-    if (inb)
-      *reinterpret_cast<float4 *>(obase + (size_t)c * r3) = make_float4(val[0], val[1], val[2], val[3]);
   }
+}
+
+// Dense write: 128-thread workgroups, 512 voxels x CT channels each.
+template <int CT>
+__global__ __launch_bounds__(128) void vox_dense_kernel(const int32_t *__restrict__ vslot,
+                                                        const float *__restrict__ vmean, int C,
+                                                        int N, int r3, float *__restrict__ out) {
+  const int b = blockIdx.z, c0 = blockIdx.y * CT;
+  const int v0 = (blockIdx.x * 128 + threadIdx.x) * 4;
+  if (v0 >= r3) return;
+  float *ob = out + ((size_t)b * C + c0) * r3 + v0;
+  const int4 s = *reinterpret_cast<const int4 *>(vslot + (size_t)b * r3 + v0);
+  const int nc = min(CT, C - c0);
+  if ((s.x & s.y & s.z & s.w) < 0) { // all four slots are -1: empty
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < nc) *reinterpret_cast<float4 *>(ob + (size_t)c * r3) = z;
+    return;
+  }
+  const float *tb = vmean + ((size_t)b * C + c0) * N;
+  float4 v[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) { // all gathers first ...
+    v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nc) {
+      if (s.x >= 0) v[c].x = tb[(size_t)c * N + s.x];
+      if (s.y >= 0) v[c].y = tb[(size_t)c * N + s.y];
+      if (s.z >= 0) v[c].z = tb[(size_t)c * N + s.z];
+      if (s.w >= 0) v[c].w = tb[(size_t)c * N + s.w];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) // ... then nothing but stores
+    if (c < nc) *reinterpret_cast<float4 *>(ob + (size_t)c * r3) = v[c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,22 +426,25 @@ __global__ __launch_bounds__(256) void vox_grad_kernel(const float *__restrict__
 
 struct VoxPlan {
   bool fast;
-  int nchunks;
   IndexLds lds;
-  size_t off_sorted, off_chunk, off_vox, total;
+  size_t off_sorted, off_uinfo, off_ucount, off_vslot, off_vmean, off_vox, total;
 };
 
-static VoxPlan make_plan(int B, int N, int r) {
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static VoxPlan make_plan(int B, int C, int N, int r) {
   VoxPlan p;
   const long r3 = (long)r * r * r;
-  p.nchunks = (int)((r3 + CHUNK - 1) / CHUNK);
-  p.lds = index_lds(N, (int)(r3 < (1 << 24) ? r3 : 0));
-  p.fast = r3 <= 65536 * 2 && (r3 % 4 == 0) && N <= MAXP * VT && N <= 65535 && N >= 1 &&
+  p.lds = index_lds(N, r3 < (1L << 20) ? r3 : 0);
+  p.fast = r3 <= (1L << 17) && (r3 % 4 == 0) && N <= MAXP * VT && N < 16384 && N >= 1 &&
            p.lds.bytes <= (size_t)LDS_LIMIT;
   size_t o = 0;
-  p.off_sorted = o; o += ((size_t)B * N * 4 + 255) & ~(size_t)255;
-  p.off_chunk = o;  o += ((size_t)B * (p.nchunks + 1) * 4 + 255) & ~(size_t)255;
-  p.off_vox = o;    o += ((size_t)B * 3 * N * 4 + 255) & ~(size_t)255; // int coords (fallback P1)
+  p.off_sorted = o; o += up256((size_t)B * N * 4);
+  p.off_uinfo = o;  o += up256((size_t)B * N * 4);
+  p.off_ucount = o; o += up256((size_t)B * 4);
+  p.off_vslot = o;  o += up256((size_t)B * r3 * 4);
+  p.off_vmean = o;  o += up256((size_t)B * (C > 0 ? C : 1) * N * 4);
+  p.off_vox = o;    o += up256((size_t)B * 3 * N * 4); // int coords (fallback P1)
   p.total = o;
   return p;
 }
@@ -421,25 +461,26 @@ static int set_index_lds(size_t bytes) {
   return 0;
 }
 
-static int pick_ct(int B, int C, int nchunks) {
-  // enough workgroups to fill 256 CUs several times over, as few channel tiles as possible so the
-  // count grid is re-read as little as possible.
-  int ct = 64;
-  while (ct > 4 && (long)B * nchunks * ((C + ct - 1) / ct) < 2048) ct >>= 1;
-  return ct;
-}
-
-static int launch_dense(const float *feat, const int32_t *cnt, const int32_t *sorted,
-                        const int32_t *chunk_start, int B, int C, int N, int r3, int nchunks,
-                        float *out, hipStream_t st) {
-  const int ct = pick_ct(B, C, nchunks);
-  dim3 grid(nchunks, (C + ct - 1) / ct, B);
+static int launch_mean_dense(const float *feat, const int32_t *sorted, const int32_t *uinfo,
+                             const int32_t *ucount, const int32_t *vslot, float *vmean, int B, int C,
+                             int N, int r3, float *out, hipStream_t st) {
+  {
+    int ct = (int)((32 * 1024) / ((size_t)N * 4)); // rows per workgroup: <= 32 KiB of LDS (+ 2 index rows)
+    if (ct < 1) ct = 1;                           // N <= 8192 on this path -> one row is <= 32 KiB
+    if (ct > 8) ct = 8;
+    while (ct > 1 && (long)B * lion_cdiv(C, ct) < 512) ct >>= 1;
+    vox_mean_kernel<<<dim3(lion_cdiv(C, ct), B), 256, ((size_t)ct + 2) * N * 4, st>>>(
+        feat, sorted, uinfo, ucount, C, N, ct, vmean);
+    LION_LAUNCH_CHECK();
+  }
+  const int vt = lion_cdiv(r3, 512);
+  int ct = 16;
+  while (ct > 4 && (long)B * vt * lion_cdiv(C, ct) < 2048) ct >>= 1;
+  dim3 grid(vt, lion_cdiv(C, ct), B);
   switch (ct) {
-  case 64: vox_dense_kernel<64><<<grid, 256, 0, st>>>(feat, cnt, sorted, chunk_start, C, N, r3, nchunks, out); break;
-  case 32: vox_dense_kernel<32><<<grid, 256, 0, st>>>(feat, cnt, sorted, chunk_start, C, N, r3, nchunks, out); break;
-  case 16: vox_dense_kernel<16><<<grid, 256, 0, st>>>(feat, cnt, sorted, chunk_start, C, N, r3, nchunks, out); break;
-  case 8:  vox_dense_kernel<8><<<grid, 256, 0, st>>>(feat, cnt, sorted, chunk_start, C, N, r3, nchunks, out); break;
-  default: vox_dense_kernel<4><<<grid, 256, 0, st>>>(feat, cnt, sorted, chunk_start, C, N, r3, nchunks, out); break;
+  case 16: vox_dense_kernel<16><<<grid, 128, 0, st>>>(vslot, vmean, C, N, r3, out); break;
+  case 8:  vox_dense_kernel<8><<<grid, 128, 0, st>>>(vslot, vmean, C, N, r3, out); break;
+  default: vox_dense_kernel<4><<<grid, 128, 0, st>>>(vslot, vmean, C, N, r3, out); break;
   }
   LION_LAUNCH_CHECK();
   return 0;
@@ -454,28 +495,32 @@ static int voxelize_impl(const float *feat, const int32_t *coords_i, const float
   if (!coords_i && !coords_f) return LION_EINVAL;
   if (coords_f && !norm_coords) return LION_EINVAL;
   if ((long)r * r * r > (1L << 30)) return LION_EUNSUPPORTED;
-  const VoxPlan p = make_plan(B, N, r);
+  const VoxPlan p = make_plan(B, feat ? C : 0, N, r);
   if (!ws || ws_bytes < p.total) return LION_EWORKSPACE;
   const int r3 = r * r * r;
   char *w = static_cast<char *>(ws);
   int32_t *sorted = reinterpret_cast<int32_t *>(w + p.off_sorted);
-  int32_t *chunk_start = reinterpret_cast<int32_t *>(w + p.off_chunk);
+  int32_t *uinfo = reinterpret_cast<int32_t *>(w + p.off_uinfo);
+  int32_t *ucount = reinterpret_cast<int32_t *>(w + p.off_ucount);
+  int32_t *vslot = reinterpret_cast<int32_t *>(w + p.off_vslot);
+  float *vmean = reinterpret_cast<float *>(w + p.off_vmean);
   if (p.fast) {
     if (coords_f) {
       int e = set_index_lds<true>(p.lds.bytes);
       if (e) return e;
       vox_index_kernel<true><<<B, VT, p.lds.bytes, st>>>(nullptr, coords_f, N, r, normalize, eps,
-                                                         norm_coords, ind, cnt, sorted, chunk_start,
-                                                         p.nchunks, p.lds.hist_words, p.lds.tmp_words);
+                                                         norm_coords, ind, cnt, vslot, sorted, uinfo,
+                                                         ucount, p.lds.hist_words, p.lds.n_words);
     } else {
       int e = set_index_lds<false>(p.lds.bytes);
       if (e) return e;
       vox_index_kernel<false><<<B, VT, p.lds.bytes, st>>>(coords_i, nullptr, N, r, 0, 0.f, nullptr,
-                                                          ind, cnt, sorted, chunk_start, p.nchunks,
-                                                          p.lds.hist_words, p.lds.tmp_words);
+                                                          ind, cnt, vslot, sorted, uinfo, ucount,
+                                                          p.lds.hist_words, p.lds.n_words);
     }
     LION_LAUNCH_CHECK();
-    if (feat) return launch_dense(feat, cnt, sorted, chunk_start, B, C, N, r3, p.nchunks, out, st);
+    if (feat)
+      return launch_mean_dense(feat, sorted, uinfo, ucount, vslot, vmean, B, C, N, r3, out, st);
     return 0;
   }
   // fallback
@@ -510,7 +555,7 @@ int lion_abi_version(void) { return 1; }
 size_t lion_avg_voxelize_workspace_bytes(int B, int C, int N, int r) {
   (void)C;
   if (B <= 0 || N <= 0 || r <= 0) return 0;
-  return make_plan(B, N, r).total;
+  return make_plan(B, C, N, r).total;
 }
 
 int lion_avg_voxelize_forward(const float *feat, const int32_t *coords, int B, int C, int N, int r,
