@@ -1,0 +1,185 @@
+"""PVCNN2Unet + the VAE's latent-point encoder / decoder -- mirror of the reference's
+``models/latent_points_ada.py`` (PVCNN2Unet :19, PointTransPVC :175, LatentPointDecPVC :222)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .pvcnn2_ada import (LinearAttention, SharedMLP, create_mlp_components,
+                         create_pointnet2_fp_modules, create_pointnet2_sa_components)
+
+# conv_configs = (out_channels, num_blocks, voxel_resolution), sa_configs = (centers, radius, U, mlp)
+_VAE_SA_BLOCKS = [
+    ((32, 2, 32), (1024, 0.1, 32, (32, 64))),
+    ((64, 3, 16), (256, 0.2, 32, (64, 128))),
+    ((128, 3, 8), (64, 0.4, 32, (128, 256))),
+    (None, (16, 0.8, 32, (128, 128, 128))),
+]
+_FP_BLOCKS = [
+    ((128, 128), (128, 3, 8)),
+    ((128, 128), (128, 3, 8)),
+    ((128, 128), (128, 2, 16)),
+    ((128, 128, 64), (64, 2, 32)),
+]
+
+
+class PVCNN2Unet(nn.Module):
+    """4 SA stages -> global linear attention -> 4 FP stages -> point-wise classifier."""
+
+    def __init__(self, num_classes, embed_dim, use_att, dropout=0.1, extra_feature_channels=3,
+                 input_dim=3, width_multiplier=1, voxel_resolution_multiplier=1, time_emb_scales=1.0,
+                 verbose=True, condition_input=False, point_as_feat=1, cfg={}, sa_blocks={},
+                 fp_blocks={}, clip_forge_enable=0, clip_forge_dim=512):
+        super().__init__()
+        self.input_dim = input_dim
+        self.clip_forge_enable = clip_forge_enable
+        self.sa_blocks = sa_blocks
+        self.fp_blocks = fp_blocks
+        self.point_as_feat = point_as_feat
+        self.condition_input = condition_input
+        assert extra_feature_channels >= 0
+        self.time_emb_scales = time_emb_scales
+        self.embed_dim = embed_dim
+        if self.embed_dim > 0:  # priors have a time embedding, the VAE networks do not
+            self.embedf = nn.Sequential(
+                nn.Linear(embed_dim, embed_dim),
+                nn.LeakyReLU(0.1, inplace=True),
+                nn.Linear(embed_dim, embed_dim))
+        if self.clip_forge_enable:
+            self.clip_forge_mapping = nn.Linear(clip_forge_dim, embed_dim)
+            style_dim = cfg.latent_pts.style_dim
+            self.style_clip = nn.Linear(style_dim + embed_dim, style_dim)
+        self.in_channels = extra_feature_channels + 3
+
+        sa_layers, sa_in_channels, channels_sa_features, _ = create_pointnet2_sa_components(
+            input_dim=input_dim, sa_blocks=self.sa_blocks,
+            extra_feature_channels=extra_feature_channels, with_se=True, embed_dim=embed_dim,
+            use_att=use_att, dropout=dropout, width_multiplier=width_multiplier,
+            voxel_resolution_multiplier=voxel_resolution_multiplier, verbose=verbose, cfg=cfg)
+        self.sa_layers = nn.ModuleList(sa_layers)
+        self.global_att = None if not use_att else LinearAttention(channels_sa_features, 8, verbose=verbose)
+
+        sa_in_channels[0] = extra_feature_channels + input_dim - 3  # extra features only in the last FP
+        fp_layers, channels_fp_features = create_pointnet2_fp_modules(
+            fp_blocks=self.fp_blocks, in_channels=channels_sa_features,
+            sa_in_channels=sa_in_channels, with_se=True, embed_dim=embed_dim, use_att=use_att,
+            dropout=dropout, width_multiplier=width_multiplier,
+            voxel_resolution_multiplier=voxel_resolution_multiplier, verbose=verbose, cfg=cfg)
+        self.fp_layers = nn.ModuleList(fp_layers)
+
+        layers, _ = create_mlp_components(
+            in_channels=channels_fp_features, out_channels=[128, dropout, num_classes],
+            classifier=True, dim=2, width_multiplier=width_multiplier, cfg=cfg)
+        self.classifier = nn.ModuleList(layers)
+
+    def get_timestep_embedding(self, timesteps, device):
+        """sinusoidal embedding, frequencies built in float64 numpy then cast (reference :101-115)."""
+        if len(timesteps.shape) == 2 and timesteps.shape[1] == 1:
+            timesteps = timesteps[:, 0]
+        assert len(timesteps.shape) == 1, f'get shape: {timesteps.shape}'
+        timesteps = timesteps * self.time_emb_scales
+        half_dim = self.embed_dim // 2
+        scale = np.log(10000) / (half_dim - 1)
+        freq = torch.from_numpy(np.exp(np.arange(0, half_dim) * -scale)).float().to(device)
+        emb = timesteps[:, None] * freq[None, :]
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+        if self.embed_dim % 2 == 1:
+            emb = nn.functional.pad(emb, (0, 1), "constant", 0)
+        assert emb.shape == torch.Size([timesteps.shape[0], self.embed_dim])
+        return emb
+
+    def forward(self, inputs, **kwargs):
+        B = inputs.shape[0]
+        coords = inputs[:, :self.input_dim, :].contiguous()
+        features = inputs
+        temb = kwargs.get('t', None)
+        if temb is not None:
+            t = temb
+            if t.ndim == 0 and not len(t.shape) == 1:
+                t = t.view(1).expand(B)
+            temb = self.embedf(self.get_timestep_embedding(t, inputs.device))[:, :, None] \
+                .expand(-1, -1, inputs.shape[-1])
+        style = kwargs['style']
+        if self.clip_forge_enable:
+            clip_feat = kwargs['clip_feat']
+            assert clip_feat is not None, 'require clip_feat as input'
+            clip_feat = self.clip_forge_mapping(clip_feat)
+            style = self.style_clip(torch.cat([style, clip_feat], dim=1).contiguous())
+
+        coords_list, in_features_list = [], []
+        for i, sa_blocks in enumerate(self.sa_layers):
+            in_features_list.append(features)
+            coords_list.append(coords)
+            if i > 0 and temb is not None:
+                features = torch.cat([features, temb], dim=1)
+            features, coords, temb, _ = sa_blocks((features, coords, temb, style))
+
+        in_features_list[0] = inputs[:, 3:, :].contiguous()
+        if self.global_att is not None:
+            features = self.global_att(features)
+        for fp_idx, fp_blocks in enumerate(self.fp_layers):
+            cf = torch.cat([features, temb], dim=1) if temb is not None else features
+            features, coords, temb, _ = fp_blocks(
+                (coords_list[-1 - fp_idx], coords, cf, in_features_list[-1 - fp_idx], temb, style))
+
+        for layer in self.classifier:
+            features = layer(features, style) if isinstance(layer, SharedMLP) else layer(features)
+        return features
+
+
+class PointTransPVC(nn.Module):
+    """VAE local encoder: [B,N,3] -> mu / log-sigma of the latent points (reference :175-220)."""
+    sa_blocks = _VAE_SA_BLOCKS
+    fp_blocks = _FP_BLOCKS
+
+    def __init__(self, zdim, input_dim, args={}):
+        super().__init__()
+        self.zdim = zdim
+        self.layers = PVCNN2Unet(2 * zdim + input_dim * 2, embed_dim=0, use_att=1,
+                                 extra_feature_channels=0, input_dim=args.ddpm.input_dim, cfg=args,
+                                 sa_blocks=self.sa_blocks, fp_blocks=self.fp_blocks,
+                                 dropout=args.ddpm.dropout)
+        self.skip_weight = args.latent_pts.skip_weight
+        self.pts_sigma_offset = args.latent_pts.pts_sigma_offset
+        self.input_dim = input_dim
+
+    def forward(self, inputs):
+        x, style = inputs
+        B, N, D = x.shape
+        output = self.layers(x.permute(0, 2, 1).contiguous(), style=style).permute(0, 2, 1).contiguous()
+        pt_mu_1d = output[:, :, :self.input_dim].contiguous()
+        pt_sigma_1d = output[:, :, self.input_dim:2 * self.input_dim].contiguous() - self.pts_sigma_offset
+        pt_mu_1d = self.skip_weight * pt_mu_1d + x
+        if self.zdim > 0:
+            ft_mu_1d = output[:, :, 2 * self.input_dim:-self.zdim].contiguous()
+            ft_sigma_1d = output[:, :, -self.zdim:].contiguous()
+            mu_1d = torch.cat([pt_mu_1d, ft_mu_1d], dim=2).view(B, -1).contiguous()
+            sigma_1d = torch.cat([pt_sigma_1d, ft_sigma_1d], dim=2).view(B, -1).contiguous()
+        else:
+            mu_1d = pt_mu_1d.view(B, -1).contiguous()
+            sigma_1d = pt_sigma_1d.view(B, -1).contiguous()
+        return {'mu_1d': mu_1d, 'sigma_1d': sigma_1d}
+
+
+class LatentPointDecPVC(nn.Module):
+    """VAE decoder: latent points [B, N*(3+D)] + style -> [B,N,3] (reference :222-273)."""
+    sa_blocks = _VAE_SA_BLOCKS
+    fp_blocks = _FP_BLOCKS
+
+    def __init__(self, point_dim, context_dim, num_points=None, args={}, **kwargs):
+        super().__init__()
+        self.point_dim = point_dim
+        self.context_dim = context_dim + self.point_dim
+        self.num_points = args.data.tr_max_sample_points if num_points is None else num_points
+        self.layers = PVCNN2Unet(point_dim, embed_dim=0, use_att=1,
+                                 extra_feature_channels=context_dim, input_dim=args.ddpm.input_dim,
+                                 cfg=args, sa_blocks=self.sa_blocks, fp_blocks=self.fp_blocks,
+                                 dropout=args.ddpm.dropout)
+        self.skip_weight = args.latent_pts.skip_weight
+
+    def forward(self, x, beta, context, style):
+        assert context.shape[1] == self.num_points * self.context_dim
+        context = context.view(-1, self.num_points, self.context_dim)
+        x = context[:, :, :self.point_dim]
+        output = self.layers(context.permute(0, 2, 1).contiguous(), style=style) \
+            .permute(0, 2, 1).contiguous()
+        return output * self.skip_weight + x

@@ -1,0 +1,153 @@
+"""Non-adaptive PVCNN blocks (plain GroupNorm) -- mirror of the part of the reference's
+``models/pvcnn2.py`` that LION instantiates: the VAE's global style encoder
+(``shapelatent_modules.PointNetPlusEncoder``) builds its SA stack from here
+(SharedMLP :117, PVConv :170, PointNetSAModule :288, create_pointnet2_sa_components :441).
+Blocks exchange 3-tuples (features, coords, time_emb) instead of the ada variant's 4-tuples."""
+import functools
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from .pvcnn2_ada import BallQuery, LinearAttention, SE3d, Swish, Voxelization
+
+
+class SharedMLP(nn.Module):
+    def __init__(self, in_channels, out_channels, dim=1):
+        super().__init__()
+        conv = nn.Conv1d if dim == 1 else nn.Conv2d
+        if not isinstance(out_channels, (list, tuple)):
+            out_channels = [out_channels]
+        layers = []
+        for oc in out_channels:
+            layers += [conv(in_channels, oc, 1), nn.GroupNorm(8, oc), Swish()]
+            in_channels = oc
+        self.layers = nn.Sequential(*layers)
+
+    def forward(self, inputs):
+        if isinstance(inputs, (list, tuple)):
+            return (self.layers(inputs[0]), *inputs[1:])
+        return self.layers(inputs)
+
+
+class PVConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, resolution, normalize=1, eps=0,
+                 with_se=False, add_point_feat=True, attention=False, dropout=0.1, verbose=True):
+        super().__init__()
+        self.resolution = resolution
+        self.voxelization = Voxelization(resolution, normalize=normalize, eps=eps)
+        voxel_layers = [
+            nn.Conv3d(in_channels, out_channels, kernel_size, stride=1, padding=kernel_size // 2),
+            nn.GroupNorm(8, out_channels),
+            Swish(),
+            nn.Dropout(dropout),
+            nn.Conv3d(out_channels, out_channels, kernel_size, stride=1, padding=kernel_size // 2),
+            nn.GroupNorm(8, out_channels),
+        ]
+        if with_se:
+            voxel_layers.append(SE3d(out_channels))
+        self.voxel_layers = nn.Sequential(*voxel_layers)
+        self.attn = LinearAttention(out_channels, verbose=verbose) if attention else None
+        if add_point_feat:
+            self.point_features = SharedMLP(in_channels, out_channels)
+        self.add_point_feat = add_point_feat
+
+    def forward(self, inputs):
+        features, coords_input, time_emb = inputs[0], inputs[1], inputs[2]
+        coords = coords_input[:, :3] if coords_input.shape[1] > 3 else coords_input
+        assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2]
+        assert coords.shape[1] == 3, f'expect coords: B,3,Npoint, get: {coords.shape}'
+        grid, voxel_coords = self.voxelization(features, coords)
+        grid = self.voxel_layers(grid)
+        fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
+        if self.add_point_feat:
+            fused = fused + self.point_features(features)
+        if self.attn is not None:
+            fused = self.attn(fused)
+        if time_emb is None:  # reference :246-247 (debug payload; nothing consumes it)
+            time_emb = {'voxel_features_4d': grid, 'resolution': self.resolution, 'training': self.training}
+        return fused, coords_input, time_emb
+
+
+class PointNetSAModule(nn.Module):
+    def __init__(self, num_centers, radius, num_neighbors, in_channels, out_channels,
+                 include_coordinates=True):
+        super().__init__()
+        if not isinstance(radius, (list, tuple)):
+            radius = [radius]
+        if not isinstance(num_neighbors, (list, tuple)):
+            num_neighbors = [num_neighbors] * len(radius)
+        if not isinstance(out_channels, (list, tuple)):
+            out_channels = [[out_channels]] * len(radius)
+        elif not isinstance(out_channels[0], (list, tuple)):
+            out_channels = [out_channels] * len(radius)
+        assert len(radius) == len(num_neighbors) == len(out_channels)
+        groupers, mlps, total = [], [], 0
+        for rad, oc, nn_ in zip(radius, out_channels, num_neighbors):
+            groupers.append(BallQuery(radius=rad, num_neighbors=nn_, include_coordinates=include_coordinates))
+            mlps.append(SharedMLP(in_channels + (3 if include_coordinates else 0), oc, dim=2))
+            total += oc[-1]
+        self.num_centers = num_centers
+        self.out_channels = total
+        self.groupers = nn.ModuleList(groupers)
+        self.mlps = nn.ModuleList(mlps)
+
+    def forward(self, inputs):
+        features, coords, time_emb = inputs[0], inputs[1], inputs[2]
+        if coords.shape[1] > 3:
+            coords = coords[:, :3]
+        centers_coords = F.furthest_point_sample(coords, self.num_centers)
+        if time_emb is not None and type(time_emb) is not dict:
+            time_emb = time_emb[:, :, :centers_coords.shape[-1]]
+        pooled = [mlp(grouper(coords, centers_coords, features)).max(dim=-1).values
+                  for grouper, mlp in zip(self.groupers, self.mlps)]
+        return (torch.cat(pooled, dim=1) if len(pooled) > 1 else pooled[0]), centers_coords, time_emb
+
+    def extra_repr(self):
+        return f'num_centers={self.num_centers}, out_channels={self.out_channels}'
+
+
+def create_pointnet2_sa_components(sa_blocks, extra_feature_channels, input_dim=3, embed_dim=64,
+                                   use_att=False, force_att=0, dropout=0.1, with_se=False,
+                                   normalize=True, eps=0, has_temb=1, width_multiplier=1,
+                                   voxel_resolution_multiplier=1, verbose=True):
+    """reference :441-510 (same first-block-only quirk as the ada builder)."""
+    r, vr = width_multiplier, voxel_resolution_multiplier
+    in_channels = extra_feature_channels + input_dim
+    sa_layers, sa_in_channels = [], []
+    num_centers = None
+    for c, (conv_configs, sa_configs) in enumerate(sa_blocks):
+        k = 0
+        sa_in_channels.append(in_channels)
+        stage = []
+        if conv_configs is not None:
+            out_channels, num_blocks, voxel_resolution = conv_configs
+            out_channels = int(r * out_channels)
+            for p in range(num_blocks):
+                attention = ((c + 1) % 2 == 0 and use_att and p == 0) or (force_att and c > 0)
+                if voxel_resolution is None:
+                    block = SharedMLP
+                else:
+                    block = functools.partial(
+                        PVConv, kernel_size=3, resolution=int(vr * voxel_resolution),
+                        attention=attention, dropout=dropout, with_se=with_se,
+                        normalize=normalize, eps=eps, verbose=verbose)
+                if c == 0:
+                    stage.append(block(in_channels, out_channels))
+                elif k == 0:
+                    stage.append(block(in_channels + embed_dim * has_temb, out_channels))
+                in_channels = out_channels
+                k += 1
+            extra_feature_channels = in_channels
+        if sa_configs is not None:
+            num_centers, radius, num_neighbors, out_channels = sa_configs
+            out_channels = [[int(r * o) for o in oc] if isinstance(oc, (list, tuple)) else int(r * oc)
+                            for oc in out_channels]
+            assert num_centers is not None, "PointNetAModule (global pooling) is not used by LION"
+            stage.append(PointNetSAModule(
+                num_centers=num_centers, radius=radius, num_neighbors=num_neighbors,
+                in_channels=extra_feature_channels + (embed_dim * has_temb if k == 0 else 0),
+                out_channels=out_channels, include_coordinates=True))
+            in_channels = extra_feature_channels = stage[-1].out_channels
+        sa_layers.append(stage[0] if len(stage) == 1 else nn.Sequential(*stage))
+    return sa_layers, sa_in_channels, in_channels, 1 if num_centers is None else num_centers

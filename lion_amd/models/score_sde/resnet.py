@@ -1,0 +1,153 @@
+"""Global (style-latent) denoiser -- mirror of the reference's ``models/score_sde/resnet.py``
+(SE :16, ResBlockSEClip :29, ResBlockSEDrop :60, ResBlock :92, Prior :124, PriorSEDrop :221,
+PriorSEClip :226).  The input is [B, C, 1, 1]; every Conv2d is a 1x1 conv, i.e. a skinny GEMM whose
+cost is streaming the 2048x2048 weights."""
+import functools
+
+import torch
+import torch.nn as nn
+
+from ..utils import init_temb_fun, mask_inactive_variables
+
+
+class SE(nn.Module):
+    def __init__(self, channel, reduction=8):
+        super().__init__()
+        self.fc = nn.Sequential(
+            nn.Conv2d(channel, channel // reduction, 1, 1, bias=False),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(channel // reduction, channel, 1, 1, bias=False),
+            nn.Sigmoid())
+
+    def forward(self, inputs):
+        return inputs * self.fc(inputs)
+
+
+class ResBlockSEClip(nn.Module):
+    """x + SE(relu(conv2(relu(conv1(cat[x + temb, clip]))))); the second half of `t` is the CLIP feature."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.non_linearity = nn.ReLU(inplace=True)
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.conv1 = nn.Conv2d(input_dim * 2, output_dim, 1, 1)
+        self.conv2 = nn.Conv2d(output_dim, output_dim, 1, 1)
+        self.SE = SE(self.output_dim)
+
+    def forward(self, x, t):
+        clip_feat = t[:, self.input_dim:].contiguous()
+        t = t[:, :self.input_dim].contiguous()
+        h = torch.cat([x + t, clip_feat], dim=1).contiguous()
+        h = self.non_linearity(self.conv1(h))
+        h = self.non_linearity(self.conv2(h))
+        return x + self.SE(h)
+
+    def __repr__(self):
+        return "ResBlockSEClip(%d, %d)" % (self.input_dim, self.output_dim)
+
+
+class ResBlockSEDrop(nn.Module):
+    def __init__(self, input_dim, output_dim, dropout):
+        super().__init__()
+        self.non_linearity = nn.ReLU(inplace=True)
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.conv1 = nn.Conv2d(input_dim, output_dim, 1, 1)
+        self.conv2 = nn.Conv2d(output_dim, output_dim, 1, 1)
+        self.SE = SE(self.output_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.dropout_ratio = dropout
+
+    def forward(self, x, t):
+        h = self.non_linearity(self.conv1(x + t))
+        h = self.dropout(h)
+        h = self.non_linearity(self.conv2(h))
+        return x + self.SE(h)
+
+    def __repr__(self):
+        return "ResBlockSE_withdropout(%d, %d, drop=%f)" % (self.input_dim, self.output_dim, self.dropout_ratio)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.non_linearity = nn.ELU()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.conv1 = nn.Conv2d(input_dim, output_dim, 1, 1)
+        self.conv2 = nn.Conv2d(output_dim, output_dim, 1, 1)
+        g = min(self.output_dim // 4, 32)
+        self.normalize1 = nn.GroupNorm(num_groups=g, num_channels=self.output_dim, eps=1e-6)
+        self.normalize2 = nn.GroupNorm(num_groups=g, num_channels=self.output_dim, eps=1e-6)
+
+    def forward(self, x, t):
+        x = x + t
+        h = self.non_linearity(self.normalize1(self.conv1(x)))
+        h = self.non_linearity(self.normalize2(self.conv2(h)))
+        return x + h
+
+    def __repr__(self):
+        return "ResBlock(%d, %d)" % (self.input_dim, self.output_dim)
+
+
+class Prior(nn.Module):
+    building_block = ResBlock
+
+    def __init__(self, args, num_input_channels, *oargs, **kwargs):
+        super().__init__()
+        # args: cfg.sde ; oargs[0]: the global cfg
+        self.condition_input = kwargs.get('condition_input', False)
+        self.cfg = oargs[0]
+        self.clip_forge_enable = self.cfg.clipforge.enable
+        self.act = nn.SiLU()
+        self.num_scales = args.num_scales_dae
+        self.num_input_channels = num_input_channels
+        self.nf = nf = args.num_channels_dae
+        if self.clip_forge_enable:
+            self.clip_feat_mapping = nn.Conv1d(self.cfg.clipforge.feat_dim, self.nf, 1)
+        self.mixed_prediction = args.mixed_prediction
+        if self.mixed_prediction:
+            assert args.mixing_logit_init, 'require learning'
+            init = args.mixing_logit_init * torch.ones(size=[1, num_input_channels, 1, 1])
+            self.mixing_logit = torch.nn.Parameter(init, requires_grad=True)
+        else:
+            self.mixing_logit = None
+        self.is_active = None
+        self.embedding_dim = args.embedding_dim
+        self.embedding_dim_mult = 4
+        self.temb_fun = init_temb_fun(args.embedding_type, args.embedding_scale, args.embedding_dim)
+        self.temb_layer = nn.Sequential(
+            nn.Conv2d(self.embedding_dim, self.embedding_dim * 4, 1, 1),
+            nn.Conv2d(self.embedding_dim * 4, nf, 1, 1))
+        self.input_layer = nn.Conv2d(num_input_channels, nf, 1, 1)
+        blocks = [self.building_block(nf, nf) for _ in range(args.num_cell_per_scale_dae)]
+        self.output_layer = nn.Conv2d(nf, num_input_channels, 1, 1)  # registered before the blocks,
+        self.all_modules = nn.ModuleList(blocks)                       # as in the reference (:188-191)
+
+    def forward(self, x, t, **kwargs):
+        if t.dim() == 0:
+            t = t.expand(1)
+        temb = self.temb_layer(self.temb_fun(t)[:, :, None, None])
+        if self.clip_forge_enable:
+            clip_feat = kwargs['clip_feat']
+            clip_feat = self.clip_feat_mapping(clip_feat[:, :, None])[:, :, :, None]
+            if temb.shape[0] == 1 and temb.shape[0] < clip_feat.shape[0]:
+                temb = temb.expand(clip_feat.shape[0], -1, -1, -1)
+            temb = torch.cat([temb, clip_feat], dim=1)
+        if self.mixed_prediction and self.is_active is not None:
+            x = mask_inactive_variables(x, self.is_active)
+        x = self.input_layer(x)
+        for layer in self.all_modules:
+            x = layer(x, temb)
+        return self.output_layer(x)
+
+
+class PriorSEDrop(Prior):
+    def __init__(self, *args, **kwargs):
+        self.building_block = functools.partial(ResBlockSEDrop, dropout=args[0].dropout)
+        super().__init__(*args, **kwargs)
+
+
+class PriorSEClip(Prior):
+    building_block = ResBlockSEClip

@@ -345,3 +345,14 @@ class TorchBackend:
 
     def avg_voxelize_backward(self, grad_y, ind, cnt):
         return self._t(self.l.avg_voxelize_backward(grad_y.numpy(), ind.numpy(), cnt.numpy()))
+
+    # fused Voxelization.forward (not in the reference module; lion_amd.models call it)
+    def voxelize_points_forward(self, features, coords, resolution, normalize=True, eps=0.0):
+        nc, vox = self.l.voxelize_coords(coords.numpy(), int(resolution), normalize, eps)
+        if features is None:
+            b, _, n = coords.shape
+            f0 = np.zeros((b, 1, n), np.float32)
+            _, i, c = self.l.avg_voxelize_forward(f0, vox, int(resolution))
+            return None, self._t(nc), self._t(i), self._t(c)
+        o, i, c = self.l.avg_voxelize_forward(features.numpy(), vox, int(resolution))
+        return self._t(o), self._t(nc), self._t(i), self._t(c)

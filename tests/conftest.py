@@ -39,3 +39,35 @@ def voxel_coords(rng, b, n, r, kind="gauss"):
     nrm = np.sqrt((c ** 2).sum(1, keepdims=True)).max(2, keepdims=True)
     c = c / (np.maximum(nrm, 1e-12) * 2.0) + 0.5
     return np.clip(c * r, 0, r - 1).astype(np.float32)
+
+
+def fill_(module, seed=0):
+    """Same name-derived deterministic weights as tests/golden/make_golden.py:fill_."""
+    import zlib
+    import torch
+    with torch.no_grad():
+        for name, t in sorted(module.state_dict().items()):
+            if not t.is_floating_point():
+                continue
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + seed) & 0x7fffffff)
+            r = torch.randn(t.shape, generator=g)
+            if t.dim() >= 2:
+                fan_in = t[0].numel()
+                t.copy_((r * (0.8 / np.sqrt(fan_in))).to(t.device))
+            elif name.endswith("norm.weight") or "normalize" in name and name.endswith("weight"):
+                t.copy_((1.0 + 0.1 * r).to(t.device))
+            else:
+                t.copy_((0.1 * r).to(t.device))
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture()
+def oracle_backend(monkeypatch):
+    """Runs lion_amd's nn.Modules on the CPU by injecting the oracle as the operator backend.
+    TEST-ONLY: the product has no CPU path (lion_amd never imports oracle)."""
+    import oracle
+    import lion_amd.functional.backend as bk
+    monkeypatch.setattr(bk, "_backend", oracle.TorchBackend())
+    return bk._backend
