@@ -142,6 +142,16 @@ int lion_ddpm_update(const float *x, const float *eps, const float *z, size_t nu
                      int t_is_zero, float k_outer, float k_a, float k_b, float scale,
                      float temp, float *out, lionStream_t stream);
 
+/* ---- C3: nn.Conv3d(kernel 3, stride 1, padding 1) of PVConv, models/pvcnn2_ada.py:211-222 --------
+ * fp32-input MFMA implicit GEMM (exact fp32).  Weights are re-packed once per weight tensor:
+ * w f32[Cout,Cin,3,3,3] -> wp f32[ceil4(Cin),27,Cout] (lion_conv3d_packed_floats floats).
+ * x f32[B,Cin,r,r,r] with Cin % 4 == 0, r in {8,16,32}, Cout % 32 == 0 -> y f32[B,Cout,r,r,r];
+ * bias f32[Cout] or NULL.  Other shapes: LION_EUNSUPPORTED (callers keep the library convolution). */
+size_t lion_conv3d_packed_floats(int Cout, int Cin);
+int lion_conv3d_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream);
+int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
+                           int Cout, int r, float *y, lionStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,9 @@ SIGNATURES = {
     "lion_emd_approxmatch": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lion_emd_matchcost": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lion_emd_matchcost_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "lion_conv3d_packed_floats": (_sz, [_i, _i]),
+    "lion_conv3d_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lion_conv3d_k3_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_ddim_update": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp]),
     "lion_ddpm_update": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp, _vp]),
 }

@@ -1,0 +1,79 @@
+"""Conv3d (3x3x3, pad 1) on the fp32 matrix cores: lion_conv3d_k3_forward over the C ABI."""
+import torch
+
+from . import _lib
+
+_PACK_CACHE = {}
+
+
+def supported(cin, cout, r):
+    return r in (8, 16, 32) and cout % 32 == 0 and cin >= 1
+
+
+def packed_weight(weight):
+    """[Cout,Cin,3,3,3] -> packed [ceil4(Cin),27,Cout]; cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _PACK_CACHE.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    cout, cin = weight.shape[:2]
+    lib = _lib.load()
+    wp = torch.empty((lib.lion_conv3d_packed_floats(cout, cin),), device=weight.device, dtype=torch.float32)
+    _lib.check(lib.lion_conv3d_pack_weights(_lib.ptr(weight.detach().contiguous()), cout, cin, _lib.ptr(wp),
+                                            _lib.stream_ptr(weight.device)), "conv3d_pack_weights")
+    _PACK_CACHE[id(weight)] = (key, wp)
+    return wp
+
+
+def conv3d_k3(x, weight, bias=None):
+    """x [B,Cin,r,r,r] fp32 -> [B,Cout,r,r,r]; Cin is zero-padded to a multiple of 4 if needed."""
+    _lib.require_cuda(x)
+    b, cin, r = x.shape[0], x.shape[1], x.shape[2]
+    cout = weight.shape[0]
+    if cin % 4:
+        pad = 4 - cin % 4
+        x = torch.cat([x, x.new_zeros(b, pad, r, r, r)], dim=1)
+        cin_p = cin + pad
+    else:
+        cin_p = cin
+    x = x.contiguous()
+    wp = packed_weight(weight)
+    y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().lion_conv3d_k3_forward(
+        _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias.detach().contiguous()) if bias is not None else None,
+        b, cin_p, cout, r, _lib.ptr(y), _lib.stream_ptr(x.device)), "conv3d_k3_forward")
+    return y
+
+
+class _Conv3dK3(torch.autograd.Function):
+    """forward on the fp32 MFMA kernel; backward through ATen's convolution_backward (MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return conv3d_k3(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx, gw, gb = torch.ops.aten.convolution_backward(
+            gy.contiguous(), x, weight, [weight.shape[0]] if ctx.has_bias else None,
+            [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+        return gx, gw, gb
+
+
+def conv3d_module(conv: torch.nn.Conv3d, x):
+    """Run an nn.Conv3d(k=3, s=1, p=1) module through the MFMA kernel when the shape is supported
+    (r in {8,16,32}, Cout % 32 == 0, fp32, HIP tensor); otherwise the library convolution."""
+    ok = (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3, 3)
+          and conv.stride == (1, 1, 1) and conv.padding == (1, 1, 1) and conv.dilation == (1, 1, 1)
+          and conv.groups == 1 and x.shape[2] == x.shape[3] == x.shape[4]
+          and supported(conv.in_channels, conv.out_channels, x.shape[2])
+          and not torch.is_autocast_enabled())
+    if not ok:
+        return conv(x)
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return _Conv3dK3.apply(x, conv.weight, conv.bias)
+    return conv3d_k3(x, conv.weight, conv.bias)

@@ -1,0 +1,213 @@
+// conv3d.hip -- C3: the 3x3x3 / pad 1 / stride 1 Conv3d of PVConv's voxel branch (97 % of the
+// denoiser's FLOPs) as an implicit GEMM on the fp32-input matrix cores.
+//
+// Reference: nn.Conv3d in models/pvcnn2_ada.py:211-222 (cuDNN there, MIOpen's CK grouped-conv here:
+// 49 TFLOP/s in the measured step, plus NCDHW<->NDHWC transposes around every call).
+//
+// D[co, voxel] = sum_{ci, tap} W[co, ci, tap] * X[ci, voxel + tap]      (per batch element)
+// is computed with v_mfma_f32_32x32x2_f32: A = weights (32 output channels x 2 k), B = input
+// (2 k x 32 voxels), exact fp32 (each MFMA is an fmaf chain, one rounding per product), so the
+// result differs from any other fp32 convolution only by summation order.  Putting the voxels on the
+// MFMA columns makes every accumulator register a run of 32 consecutive voxels of one channel, i.e.
+// the NCDHW output is written with 128-byte coalesced stores and needs no layout change at all.
+//
+// Workgroup = TD x TH x TW output voxels (256) x COT output channels, 4 waves; wave w owns voxels
+// [64w, 64w+64) x COT channels = 2x2 MFMA tiles (64 accumulator VGPRs).  K is walked in chunks of
+// KC = 4 input channels: the haloed input tile [KC][TD+2][TH+2][TW+2] (zero padded at the borders)
+// and the weight slice [KC][27][COT] (pre-packed once per weight tensor into [Cin][27][Cout]) are
+// staged in 41 KiB of LDS; the next chunk's global loads are in flight while the current chunk's
+// 54 k-steps (216 MFMAs per wave) execute.  Each k-step is 4 conflict-free ds_read_b32 + 4 MFMAs.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KC = 4;
+
+template <int TD, int TH, int TW, int COT>
+__global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ wp,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ y, int Cin,
+                                                                int Cout, int r) {
+  constexpr int TM = TD * TH * TW;
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
+  constexpr int NX = (KC * HALO + TM - 1) / TM;          // staged input floats per thread
+  constexpr int WV4 = KC * 27 * COT / 4;                 // float4 of weights per chunk
+  constexpr int NWV = (WV4 + TM - 1) / TM;               // staged weight float4 per thread
+  constexpr int CB = COT / 32;                           // 32-channel MFMA row blocks
+  __shared__ float sx[KC * HALO];
+  __shared__ __attribute__((aligned(16))) float sw[KC * 27 * COT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, co0 = blockIdx.y * COT;
+  const int ntw = r / TW, nth = r / TH;
+  const int tw_i = blockIdx.x % ntw, th_i = (blockIdx.x / ntw) % nth, td_i = blockIdx.x / (ntw * nth);
+  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+  const int r2 = r * r, r3 = r2 * r;
+
+  // global offsets (relative to the chunk's first channel) of the input elements this thread stages
+  int goff[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = tid + i * TM;
+    const int c = e / HALO, p = e - c * HALO;
+    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+    const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+    const bool ok = e < KC * HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+    goff[i] = ok ? c * r3 + (gd * r + gh) * r + gw : -1;
+  }
+  // LDS offsets of this lane's B operands (input): voxel (d,h,w) of each of the wave's 2 column blocks
+  int boff[2];
+#pragma unroll
+  for (int vb = 0; vb < 2; ++vb) {
+    const int v = wave * 64 + vb * 32 + (lane & 31);
+    const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+    boff[vb] = (lane >> 5) * HALO + (d * HH + h) * HW + w;
+  }
+  const int aoff = (lane >> 5) * 27 * COT + (lane & 31);
+
+  f32x16 acc[CB][2];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int vb = 0; vb < 2; ++vb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][vb][i] = 0.f;
+
+  const float *xb = x + (size_t)b * Cin * r3;
+  float rx[NX];
+  float4 rw[NWV];
+  auto load_chunk = [&](int q) {
+    const float *xc = xb + (size_t)q * KC * r3;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rx[i] = goff[i] >= 0 ? xc[goff[i]] : 0.f;
+    // weight slice: rows (ci, tap) of the packed [Cin][27][Cout] tensor, COT contiguous floats each
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int e = tid + i * TM;
+      if (e < WV4) {
+        const int row = e / (COT / 4), j4 = e - row * (COT / 4);
+        rw[i] = *reinterpret_cast<const float4 *>(wp + ((size_t)q * KC * 27 + row) * Cout + co0 + j4 * 4);
+      }
+    }
+  };
+
+  const int nchunks = Cin / KC;
+  load_chunk(0);
+  for (int q = 0; q < nchunks; ++q) {
+    __syncthreads(); // everyone is done reading the previous chunk from LDS
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + i * TM;
+      if (e < KC * HALO) sx[e] = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int e = tid + i * TM;
+      if (e < WV4) *reinterpret_cast<float4 *>(sw + e * 4) = rw[i];
+    }
+    __syncthreads();
+    if (q + 1 < nchunks) load_chunk(q + 1); // in flight during the MFMAs below
+
+#pragma unroll
+    for (int cp = 0; cp < KC / 2; ++cp) {
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = (kd * 3 + kh) * 3 + kw;
+            const int toff = (kd * HH + kh) * HW + kw + cp * 2 * HALO;
+            const float b0 = sx[boff[0] + toff], b1 = sx[boff[1] + toff];
+            const float *ap = sw + aoff + (cp * 2 * 27 + tap) * COT;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+              const float a = ap[cb * 32];
+              acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[cb][0], 0, 0, 0);
+              acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[cb][1], 0, 0, 0);
+            }
+          }
+    }
+  }
+
+  // epilogue: + bias, NCDHW store.  acc register i of lane l: channel row (i&3) + 8*(i>>2) + 4*(l>>5),
+  // voxel column l&31 -> 32 consecutive voxels per (register, half-wave).
+  float *yb = y + ((size_t)b * Cout + co0) * r3;
+#pragma unroll
+  for (int vb = 0; vb < 2; ++vb) {
+    const int v = wave * 64 + vb * 32 + (lane & 31);
+    const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+    const int gv = ((d0 + d) * r + (h0 + h)) * r + (w0 + w);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        yb[(size_t)co * r3 + gv] = acc[cb][vb][i] + (bias ? bias[co0 + co] : 0.f);
+      }
+  }
+}
+
+// [Cout][Cin][27] (PyTorch) -> [Cin_pad][27][Cout], Cin padded with zeros to a multiple of KC
+__global__ void conv3d_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int Cin_pad,
+                                   float *__restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = Cin_pad * 27 * Cout;
+  if (i >= total) return;
+  const int co = i % Cout, t = (i / Cout) % 27, ci = i / (Cout * 27);
+  wp[i] = ci < Cin ? w[((size_t)co * Cin + ci) * 27 + t] : 0.f;
+}
+
+template <int TD, int TH, int TW>
+static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int B, int Cin,
+                       int Cout, int r, hipStream_t st) {
+  const int tiles = (r / TD) * (r / TH) * (r / TW);
+  // small grids (r = 8): prefer 32-channel tiles so that >= 2 workgroups per CU overlap each other's staging
+  if (Cout % 64 == 0 && (long)tiles * (Cout / 64) * B >= 512) {
+    conv3d_k3_kernel<TD, TH, TW, 64><<<dim3(tiles, Cout / 64, B), TD * TH * TW, 0, st>>>(x, wp, bias, y, Cin, Cout, r);
+  } else if (Cout % 32 == 0) {
+    conv3d_k3_kernel<TD, TH, TW, 32><<<dim3(tiles, Cout / 32, B), TD * TH * TW, 0, st>>>(x, wp, bias, y, Cin, Cout, r);
+  } else {
+    return LION_EUNSUPPORTED;
+  }
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+// packed size in floats: ceil(Cin / 4) * 4 * 27 * Cout
+size_t lion_conv3d_packed_floats(int Cout, int Cin) {
+  return (size_t)((Cin + KC - 1) / KC * KC) * 27 * Cout;
+}
+
+int lion_conv3d_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream) {
+  if (!w || !wp || Cout <= 0 || Cin <= 0) return LION_EINVAL;
+  const int Cin_pad = (Cin + KC - 1) / KC * KC;
+  const int total = Cin_pad * 27 * Cout;
+  conv3d_pack_kernel<<<lion_cdiv(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cout, Cin, Cin_pad, wp);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// x f32[B,Cin_pad,r,r,r] (Cin_pad = Cin rounded up to 4; the pad channels are multiplied by zero
+// weights, so x may simply be the [B,Cin,...] tensor when Cin % 4 == 0), wp from
+// lion_conv3d_pack_weights, bias f32[Cout] or NULL -> y f32[B,Cout,r,r,r].   r in {8, 16, 32}.
+int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
+                           int Cout, int r, float *y, lionStream_t stream) {
+  if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
+  if (Cin % KC != 0) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (r) {
+  case 32: return launch_conv<2, 4, 32>(x, wp, bias, y, B, Cin, Cout, r, st);
+  case 16: return launch_conv<4, 4, 16>(x, wp, bias, y, B, Cin, Cout, r, st);
+  case 8:  return launch_conv<4, 8, 8>(x, wp, bias, y, B, Cin, Cout, r, st);
+  default: return LION_EUNSUPPORTED;
+  }
+}
+
+} // extern "C"

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as F
+from ..conv_ops import conv3d_module
 from .pvcnn2_ada import BallQuery, LinearAttention, SE3d, Swish, Voxelization
 
 
@@ -58,7 +59,8 @@ class PVConv(nn.Module):
         assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2]
         assert coords.shape[1] == 3, f'expect coords: B,3,Npoint, get: {coords.shape}'
         grid, voxel_coords = self.voxelization(features, coords)
-        grid = self.voxel_layers(grid)
+        for layer in self.voxel_layers:
+            grid = conv3d_module(layer, grid) if isinstance(layer, nn.Conv3d) else layer(grid)
         fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
         if self.add_point_feat:
             fused = fused + self.point_features(features)

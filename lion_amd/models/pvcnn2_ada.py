@@ -16,6 +16,7 @@ import torch.nn as nn
 from einops import rearrange
 
 from .. import functional as F
+from ..conv_ops import conv3d_module
 from .adagn import AdaGN
 
 
@@ -193,7 +194,12 @@ class PVConv(nn.Module):
         assert coords.shape[1] == 3, f'expect coords: B,3,Npoint, get: {coords.shape}'
         grid, voxel_coords = self.voxelization(features, coords)
         for layer in self.voxel_layers:
-            grid = layer(grid, style) if isinstance(layer, AdaGN) else layer(grid)
+            if isinstance(layer, AdaGN):
+                grid = layer(grid, style)
+            elif isinstance(layer, nn.Conv3d):
+                grid = conv3d_module(layer, grid)  # fp32-MFMA implicit GEMM (csrc/conv3d.hip)
+            else:
+                grid = layer(grid)
         fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
         if self.add_point_feat:
             fused = fused + self.point_features(features, style)

@@ -363,3 +363,35 @@ def test_full_size_properties(bk):
     d = (torch.gather(co, 2, nb.view(B, 1, -1).long().expand(-1, 3, -1)).view(B, 3, 1024, 32)
          - ctr.unsqueeze(-1)).pow(2).sum(1)
     assert (d < 0.25 + 1e-6).all()  # centre itself is always a hit, so no empty rows
+
+
+@pytest.mark.parametrize("cin,cout,r", [(64, 64, 32), (4, 32, 32), (128, 64, 16), (192, 128, 8), (33, 32, 8)])
+def test_conv3d_mfma_matches_fp64_reference(cin, cout, r):
+    """C3: fp32-MFMA implicit-GEMM Conv3d vs an fp64 convolution of the same fp32 operands: the
+    error must be of fp32-roundoff class (each MFMA is an fmaf chain), forward and backward."""
+    from lion_amd.conv_ops import conv3d_k3, conv3d_module
+    torch.manual_seed(cin + cout + r)
+    B = 2
+    conv = torch.nn.Conv3d(cin, cout, 3, padding=1).cuda()
+    x = torch.randn(B, cin, r, r, r, device="cuda")
+    with torch.no_grad():
+        ref = torch.nn.functional.conv3d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        got = conv3d_k3(x, conv.weight, conv.bias)
+        lib = conv(x)
+    scale = ref.abs().max().item()
+    err = (got.double() - ref).abs().max().item() / scale
+    err_lib = (lib.double() - ref).abs().max().item() / scale
+    assert err < 5e-6, (err, err_lib)       # measured ~1e-6; MIOpen's own fp32 kernel is in the same class
+    # boundary voxels (zero padding) are the classic place to be wrong: check faces explicitly
+    assert torch.allclose(got[..., 0, :, :].double(), ref[..., 0, :, :], rtol=1e-4, atol=1e-5 * scale)
+    assert torch.allclose(got[..., :, :, -1].double(), ref[..., :, :, -1], rtol=1e-4, atol=1e-5 * scale)
+    # autograd path
+    x2 = x.clone().requires_grad_(True)
+    y = conv3d_module(conv, x2)
+    y.square().sum().backward()
+    gw, gx = conv.weight.grad.clone(), x2.grad.clone()
+    conv.weight.grad = None
+    x3 = x.clone().requires_grad_(True)
+    conv(x3).square().sum().backward()
+    assert torch.allclose(gx, x3.grad, rtol=1e-3, atol=1e-3 * x3.grad.abs().max().item())
+    assert torch.allclose(gw, conv.weight.grad, rtol=1e-3, atol=1e-3 * gw.abs().max().item())
