@@ -152,6 +152,24 @@ int lion_conv3d_pack_weights(const float *w, int Cout, int Cin, float *wp, lionS
 int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
                            int Cout, int r, float *y, lionStream_t stream);
 
+/* ---- P2+P3+P4 folded into C3 / K4 (inference): PVConv.forward voxel branch, pvcnn2_ada.py:211-226 ----
+ * conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize without a single stand-alone pass over
+ * the grid: the conv epilogue emits per-tile channel sums (stats f32[B,Cout,T,2], T =
+ * lion_conv3d_stat_tiles(r)), lion_groupnorm_fold turns them into per-(batch, channel) scalars
+ * A, Bs (GroupNorm(G) x adaptive affine fac/gbias, models/adagn.py:61-64) and the channel mean,
+ * the next conv applies swish(x*A+Bs) while staging its input (pro_a/pro_b f32[B,Cin]), and
+ * lion_trilinear_devoxelize_affine_forward interpolates scale*feat+shift (second AdaGN x SE gate). */
+int lion_conv3d_stat_tiles(int r);
+int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
+                                 int Cout, int r, const float *pro_a, const float *pro_b, float *y,
+                                 float *stats, lionStream_t stream);
+int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
+                        const float *beta, const float *fac, const float *gbias, float eps, float *A,
+                        float *Bs, float *chmean, lionStream_t stream);
+int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *feat, const float *scale,
+                                             const float *shift, int B, int C, int N, int r, float *out,
+                                             lionStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,10 @@ SIGNATURES = {
     "lion_conv3d_packed_floats": (_sz, [_i, _i]),
     "lion_conv3d_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_conv3d_k3_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_conv3d_stat_tiles": (_i, [_i]),
+    "lion_conv3d_k3_fused_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "lion_trilinear_devoxelize_affine_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_ddim_update": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp]),
     "lion_ddpm_update": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp, _vp]),
 }

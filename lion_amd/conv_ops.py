@@ -19,7 +19,8 @@ def packed_weight(weight):
     cout, cin = weight.shape[:2]
     lib = _lib.load()
     wp = torch.empty((lib.lion_conv3d_packed_floats(cout, cin),), device=weight.device, dtype=torch.float32)
-    _lib.check(lib.lion_conv3d_pack_weights(_lib.ptr(weight.detach().contiguous()), cout, cin, _lib.ptr(wp),
+    w_c = weight.detach().contiguous()  # local reference: see fused_ops.groupnorm_fold
+    _lib.check(lib.lion_conv3d_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
                                             _lib.stream_ptr(weight.device)), "conv3d_pack_weights")
     _PACK_CACHE[id(weight)] = (key, wp)
     return wp
@@ -39,8 +40,9 @@ def conv3d_k3(x, weight, bias=None):
     x = x.contiguous()
     wp = packed_weight(weight)
     y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
+    bias_c = bias.detach().contiguous() if bias is not None else None
     _lib.check(_lib.load().lion_conv3d_k3_forward(
-        _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias.detach().contiguous()) if bias is not None else None,
+        _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias_c),
         b, cin_p, cout, r, _lib.ptr(y), _lib.stream_ptr(x.device)), "conv3d_k3_forward")
     return y
 

@@ -24,12 +24,19 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 4;
 
-template <int TD, int TH, int TW, int COT>
+// PRO:   the staged input is swish(x * pro_a[b][ci] + pro_b[b][ci]) (AdaGN affine + Swish of the
+//        previous layer, pvcnn2_ada.py:212-218, applied on the fly; zero padding stays zero).
+// STATS: per (batch, output channel, spatial tile) sum and sum of squares of the output are written
+//        to stats[b][co][tile][2] (GroupNorm statistics of the NEXT AdaGN without another pass).
+template <int TD, int TH, int TW, int COT, bool PRO, bool STATS>
 __global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__restrict__ x,
                                                                 const float *__restrict__ wp,
                                                                 const float *__restrict__ bias,
                                                                 float *__restrict__ y, int Cin,
-                                                                int Cout, int r) {
+                                                                int Cout, int r,
+                                                                const float *__restrict__ pro_a,
+                                                                const float *__restrict__ pro_b,
+                                                                float *__restrict__ stats) {
   constexpr int TM = TD * TH * TW;
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
   constexpr int NX = (KC * HALO + TM - 1) / TM;          // staged input floats per thread
@@ -38,6 +45,8 @@ __global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__re
   constexpr int CB = COT / 32;                           // 32-channel MFMA row blocks
   __shared__ float sx[KC * HALO];
   __shared__ __attribute__((aligned(16))) float sw[KC * 27 * COT];
+  __shared__ float spa[PRO ? 256 : 1], spb[PRO ? 256 : 1];              // prologue scalars, Cin <= 256
+  __shared__ float sred[STATS ? (TD * TH * TW / 64) * COT * 2 : 1];     // per-wave channel sums
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, co0 = blockIdx.y * COT;
@@ -46,6 +55,9 @@ __global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__re
   const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
   const int r2 = r * r, r3 = r2 * r;
 
+  if (PRO) {
+    for (int c = tid; c < Cin; c += TM) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
+  }
   // global offsets (relative to the chunk's first channel) of the input elements this thread stages
   int goff[NX];
 #pragma unroll
@@ -100,7 +112,15 @@ __global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__re
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int e = tid + i * TM;
-      if (e < KC * HALO) sx[e] = rx[i];
+      if (e < KC * HALO) {
+        float v = rx[i];
+        if (PRO) {
+          const int c = q * KC + e / HALO;
+          const float t = v * spa[c] + spb[c];
+          v = goff[i] >= 0 ? t / (1.0f + __expf(-t)) : 0.f; // swish; padding stays zero
+        }
+        sx[e] = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
@@ -145,8 +165,76 @@ __global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__re
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        yb[(size_t)co * r3 + gv] = acc[cb][vb][i] + (bias ? bias[co0 + co] : 0.f);
+        const float o = acc[cb][vb][i] + (bias ? bias[co0 + co] : 0.f);
+        acc[cb][vb][i] = o;
+        yb[(size_t)co * r3 + gv] = o;
       }
+  }
+  if (STATS) {
+    // channel sums over this tile: columns (voxels) live in the 32 lanes of a half-wave
+    constexpr int NWAVE = TM / 64;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float s1 = acc[cb][0][i] + acc[cb][1][i];
+        float s2 = acc[cb][0][i] * acc[cb][0][i] + acc[cb][1][i] * acc[cb][1][i];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        if ((lane & 31) == 0) {
+          const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+          sred[(wave * COT + co) * 2] = s1;
+          sred[(wave * COT + co) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < COT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
+      float *o = stats + (((size_t)b * Cout + co0 + tid) * gridDim.x + blockIdx.x) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+}
+
+// GroupNorm(G groups) + adaptive affine folded into per-(batch, channel) scalars:
+//   AdaGN(x)[b,c,:] = x * A[b,c] + Bs[b,c],  A = rstd_g * gamma_c * f_bc,
+//   Bs = (beta_c - mean_g * rstd_g * gamma_c) * f_bc + g_bc            (models/adagn.py:61-64)
+// from the conv epilogue's tile sums (fixed summation order, double accumulation).  Also emits the
+// per-channel mean of the conv output (SE3d needs the mean of the normalised grid, which is affine in it).
+__global__ void gn_fold_kernel(const float *__restrict__ stats, int C, int T, int G, float count,
+                               const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ fac, const float *__restrict__ gbias, float eps,
+                               float *__restrict__ A, float *__restrict__ Bs, float *__restrict__ chmean) {
+  // one workgroup per (batch, group); C/G channels per group
+  __shared__ double gs[2];
+  const int b = blockIdx.y, g = blockIdx.x, cpg = C / G, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  if (tid < cpg) {
+    const float *p = stats + (((size_t)b * C + g * cpg + tid) * T) * 2;
+    for (int t = 0; t < T; ++t) { s1 += (double)p[2 * t]; s2 += (double)p[2 * t + 1]; }
+    chmean[(size_t)b * C + g * cpg + tid] = (float)(s1 / count);
+  }
+  if (tid == 0) { gs[0] = 0.0; gs[1] = 0.0; }
+  __syncthreads();
+  // channels per group <= 32: serialised adds in channel order (deterministic)
+  for (int c = 0; c < cpg; ++c) {
+    if (tid == c) { gs[0] += s1; gs[1] += s2; }
+    __syncthreads();
+  }
+  if (tid < cpg) {
+    const double n = (double)count * cpg;
+    const double mean = gs[0] / n;
+    double var = gs[1] / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const int c = g * cpg + tid;
+    const float f = fac[(size_t)b * C + c], gb = gbias[(size_t)b * C + c];
+    const float a0 = rstd * gamma[c];
+    A[(size_t)b * C + c] = a0 * f;
+    Bs[(size_t)b * C + c] = (beta[c] - (float)mean * a0) * f + gb;
   }
 }
 
@@ -160,21 +248,33 @@ __global__ void conv3d_pack_kernel(const float *__restrict__ w, int Cout, int Ci
   wp[i] = ci < Cin ? w[((size_t)co * Cin + ci) * 27 + t] : 0.f;
 }
 
-template <int TD, int TH, int TW>
-static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int B, int Cin,
-                       int Cout, int r, hipStream_t st) {
+template <int TD, int TH, int TW, int COT>
+static int launch_conv_t(const float *x, const float *wp, const float *bias, float *y, int B, int Cin,
+                         int Cout, int r, const float *pa, const float *pb, float *stats, hipStream_t st) {
   const int tiles = (r / TD) * (r / TH) * (r / TW);
-  // small grids (r = 8): prefer 32-channel tiles so that >= 2 workgroups per CU overlap each other's staging
-  if (Cout % 64 == 0 && (long)tiles * (Cout / 64) * B >= 512) {
-    conv3d_k3_kernel<TD, TH, TW, 64><<<dim3(tiles, Cout / 64, B), TD * TH * TW, 0, st>>>(x, wp, bias, y, Cin, Cout, r);
-  } else if (Cout % 32 == 0) {
-    conv3d_k3_kernel<TD, TH, TW, 32><<<dim3(tiles, Cout / 32, B), TD * TH * TW, 0, st>>>(x, wp, bias, y, Cin, Cout, r);
-  } else {
-    return LION_EUNSUPPORTED;
-  }
+  const dim3 grid(tiles, Cout / COT, B);
+  constexpr int NT = TD * TH * TW;
+  if (pa && stats) conv3d_k3_kernel<TD, TH, TW, COT, true, true><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
+  else if (pa) conv3d_k3_kernel<TD, TH, TW, COT, true, false><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
+  else if (stats) conv3d_k3_kernel<TD, TH, TW, COT, false, true><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
+  else conv3d_k3_kernel<TD, TH, TW, COT, false, false><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
   LION_LAUNCH_CHECK();
   return 0;
 }
+
+template <int TD, int TH, int TW>
+static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int B, int Cin,
+                       int Cout, int r, const float *pa, const float *pb, float *stats, hipStream_t st) {
+  const int tiles = (r / TD) * (r / TH) * (r / TW);
+  // small grids (r = 8): prefer 32-channel tiles so that >= 2 workgroups per CU overlap each other's staging
+  if (Cout % 64 == 0 && (long)tiles * (Cout / 64) * B >= 512)
+    return launch_conv_t<TD, TH, TW, 64>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, stats, st);
+  if (Cout % 32 == 0)
+    return launch_conv_t<TD, TH, TW, 32>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, stats, st);
+  return LION_EUNSUPPORTED;
+}
+
+static int conv_tiles(int r) { return r == 32 ? 128 : r == 16 ? 16 : r == 8 ? 2 : 0; }
 
 } // namespace
 
@@ -194,20 +294,42 @@ int lion_conv3d_pack_weights(const float *w, int Cout, int Cin, float *wp, lionS
   return 0;
 }
 
-// x f32[B,Cin_pad,r,r,r] (Cin_pad = Cin rounded up to 4; the pad channels are multiplied by zero
-// weights, so x may simply be the [B,Cin,...] tensor when Cin % 4 == 0), wp from
-// lion_conv3d_pack_weights, bias f32[Cout] or NULL -> y f32[B,Cout,r,r,r].   r in {8, 16, 32}.
-int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
-                           int Cout, int r, float *y, lionStream_t stream) {
+// x f32[B,Cin,r,r,r] with Cin % 4 == 0, wp from lion_conv3d_pack_weights, bias f32[Cout] or NULL
+// -> y f32[B,Cout,r,r,r].   r in {8, 16, 32}.
+// pro_a / pro_b f32[B,Cin] (both or neither): input is swish(x*a+b) (fused AdaGN + Swish prologue).
+// stats f32[B,Cout,lion_conv3d_stat_tiles(r),2] or NULL: per-tile channel sums of the output.
+int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
+                                 int Cout, int r, const float *pro_a, const float *pro_b, float *y,
+                                 float *stats, lionStream_t stream) {
   if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
-  if (Cin % KC != 0) return LION_EUNSUPPORTED;
+  if ((pro_a == nullptr) != (pro_b == nullptr)) return LION_EINVAL;
+  if (Cin % KC != 0 || (pro_a && Cin > 256)) return LION_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (r) {
-  case 32: return launch_conv<2, 4, 32>(x, wp, bias, y, B, Cin, Cout, r, st);
-  case 16: return launch_conv<4, 4, 16>(x, wp, bias, y, B, Cin, Cout, r, st);
-  case 8:  return launch_conv<4, 8, 8>(x, wp, bias, y, B, Cin, Cout, r, st);
+  case 32: return launch_conv<2, 4, 32>(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, st);
+  case 16: return launch_conv<4, 4, 16>(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, st);
+  case 8:  return launch_conv<4, 8, 8>(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, st);
   default: return LION_EUNSUPPORTED;
   }
+}
+
+int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
+                           int Cout, int r, float *y, lionStream_t stream) {
+  return lion_conv3d_k3_fused_forward(x, wp, bias, B, Cin, Cout, r, nullptr, nullptr, y, nullptr, stream);
+}
+
+int lion_conv3d_stat_tiles(int r) { return conv_tiles(r); }
+
+// stats f32[B,C,T,2] -> A, Bs, chmean f32[B,C]   (GroupNorm(G) folded with the AdaGN affine fac/gbias f32[B,C])
+int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
+                        const float *beta, const float *fac, const float *gbias, float eps, float *A,
+                        float *Bs, float *chmean, lionStream_t stream) {
+  if (!stats || !gamma || !beta || !fac || !gbias || !A || !Bs || !chmean) return LION_EINVAL;
+  if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G != 0 || C / G > 64) return LION_EINVAL;
+  gn_fold_kernel<<<dim3(G, B), 64, 0, static_cast<hipStream_t>(stream)>>>(stats, C, T, G, (float)voxels, gamma,
+                                                                         beta, fac, gbias, eps, A, Bs, chmean);
+  LION_LAUNCH_CHECK();
+  return 0;
 }
 
 } // extern "C"

@@ -52,13 +52,18 @@ __device__ __forceinline__ Corners corners_of(float x, float y, float z, int r, 
   return k;
 }
 
-template <int CT>
+// AFF: out = scale[b,c] * interp(feat) + shift[b,c] * sum(w)  ==  interp(scale*feat + shift): the
+// per-(batch, channel) affine that AdaGN + the SE gate apply to the whole grid (pvcnn2_ada.py:219-226)
+// commutes with the interpolation, so the two full-grid passes are replaced by two scalars here.
+template <int CT, bool AFF>
 __global__ __launch_bounds__(256) void devox_fwd_kernel(const float *__restrict__ coords,
                                                         const float *__restrict__ feat, int C,
                                                         int N, int r, int training,
                                                         float *__restrict__ out,
                                                         int32_t *__restrict__ inds,
-                                                        float *__restrict__ wgts) {
+                                                        float *__restrict__ wgts,
+                                                        const float *__restrict__ scale,
+                                                        const float *__restrict__ shift) {
   const int b = blockIdx.z, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int r2 = r * r, r3 = r2 * r;
@@ -77,6 +82,12 @@ __global__ __launch_bounds__(256) void devox_fwd_kernel(const float *__restrict_
   const int c0 = blockIdx.y * CT, c1 = min(C, c0 + CT);
   const float *f = feat + ((size_t)b * C + c0) * r3;
   float *o = out + ((size_t)b * C + c0) * N + i;
+  float wsum = 0.f;
+  if (AFF) {
+    wsum = k.w[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) wsum += k.w[q];
+  }
 #pragma unroll 4
   for (int c = c0; c < c1; ++c, f += r3, o += N) {
     float v[8];
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(256) void devox_fwd_kernel(const float *__restrict_
     float acc = mul_rn(k.w[0], v[0]); // :96-103, left to right
 #pragma unroll
     for (int q = 1; q < 8; ++q) acc = add_rn(acc, mul_rn(k.w[q], v[q]));
+    if (AFF) acc = acc * scale[(size_t)b * C + c] + shift[(size_t)b * C + c] * wsum;
     *o = acc;
   }
 }
@@ -143,25 +155,44 @@ __global__ void devox_bwd_atomic_kernel(const float *__restrict__ gy,
 
 extern "C" {
 
-int lion_trilinear_devoxelize_forward(const float *coords, const float *feat, int B, int C, int N,
-                                      int r, int training, float *out, int32_t *inds, float *wgts,
-                                      lionStream_t stream) {
-  if (!coords || !feat || !out || B <= 0 || C <= 0 || N <= 0 || r <= 0) return LION_EINVAL;
-  if (training && (!inds || !wgts)) return LION_EINVAL;
-  hipStream_t st = static_cast<hipStream_t>(stream);
+static int devox_launch(const float *coords, const float *feat, int B, int C, int N, int r,
+                        int training, float *out, int32_t *inds, float *wgts, const float *scale,
+                        const float *shift, hipStream_t st) {
   const int pt = lion_cdiv(N, 256);
   // channel tile: keep >= ~2048 workgroups in flight, amortise the corner computation
   int ct = 16;
   while (ct > 2 && (long)B * pt * lion_cdiv(C, ct) < 2048) ct >>= 1;
   dim3 grid(pt, lion_cdiv(C, ct), B);
+#define DEVOX_CASE(CT_)                                                                                   \
+  if (scale) devox_fwd_kernel<CT_, true><<<grid, 256, 0, st>>>(coords, feat, C, N, r, training, out, inds, wgts, scale, shift); \
+  else devox_fwd_kernel<CT_, false><<<grid, 256, 0, st>>>(coords, feat, C, N, r, training, out, inds, wgts, scale, shift)
   switch (ct) {
-  case 16: devox_fwd_kernel<16><<<grid, 256, 0, st>>>(coords, feat, C, N, r, training, out, inds, wgts); break;
-  case 8:  devox_fwd_kernel<8><<<grid, 256, 0, st>>>(coords, feat, C, N, r, training, out, inds, wgts); break;
-  case 4:  devox_fwd_kernel<4><<<grid, 256, 0, st>>>(coords, feat, C, N, r, training, out, inds, wgts); break;
-  default: devox_fwd_kernel<2><<<grid, 256, 0, st>>>(coords, feat, C, N, r, training, out, inds, wgts); break;
+  case 16: DEVOX_CASE(16); break;
+  case 8:  DEVOX_CASE(8); break;
+  case 4:  DEVOX_CASE(4); break;
+  default: DEVOX_CASE(2); break;
   }
+#undef DEVOX_CASE
   LION_LAUNCH_CHECK();
   return 0;
+}
+
+int lion_trilinear_devoxelize_forward(const float *coords, const float *feat, int B, int C, int N,
+                                      int r, int training, float *out, int32_t *inds, float *wgts,
+                                      lionStream_t stream) {
+  if (!coords || !feat || !out || B <= 0 || C <= 0 || N <= 0 || r <= 0) return LION_EINVAL;
+  if (training && (!inds || !wgts)) return LION_EINVAL;
+  return devox_launch(coords, feat, B, C, N, r, training, out, inds, wgts, nullptr, nullptr,
+                      static_cast<hipStream_t>(stream));
+}
+
+// devoxelize(scale[b,c] * feat + shift[b,c]) without materialising the scaled grid (inference path).
+int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *feat, const float *scale,
+                                             const float *shift, int B, int C, int N, int r, float *out,
+                                             lionStream_t stream) {
+  if (!coords || !feat || !out || !scale || !shift || B <= 0 || C <= 0 || N <= 0 || r <= 0) return LION_EINVAL;
+  return devox_launch(coords, feat, B, C, N, r, 0, out, nullptr, nullptr, scale, shift,
+                      static_cast<hipStream_t>(stream));
 }
 
 int lion_trilinear_devoxelize_backward(const float *gy, const int32_t *inds, const float *wgts,

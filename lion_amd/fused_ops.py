@@ -1,0 +1,72 @@
+"""Inference-time fusions of PVConv's voxel branch (SURVEY.md 8a P2-P4 folded into C3 / K4):
+conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize with no stand-alone pass over the grid.
+Thin wrappers over lion_conv3d_k3_fused_forward / lion_groupnorm_fold /
+lion_trilinear_devoxelize_affine_forward (include/lion_hip.h)."""
+import torch
+
+from . import _lib
+from .conv_ops import packed_weight, supported
+
+
+def conv3d_fused(x, conv, pro=None, want_stats=True):
+    """x [B,Cin,r,r,r] -> (y [B,Cout,r,r,r], stats [B,Cout,T,2] | None).  pro = (A, Bs) applies
+    swish(x*A+Bs) to the input on the fly."""
+    lib = _lib.load()
+    b, cin, r = x.shape[0], x.shape[1], x.shape[2]
+    cout = conv.out_channels
+    if cin % 4:
+        assert pro is None
+        x = torch.cat([x, x.new_zeros(b, 4 - cin % 4, r, r, r)], dim=1)
+        cin = x.shape[1]
+    x = x.contiguous()
+    wp = packed_weight(conv.weight)
+    y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty((b, cout, lib.lion_conv3d_stat_tiles(r), 2), device=x.device, dtype=torch.float32)
+    pa = pb = None
+    if pro is not None:
+        pa, pb = pro[0].contiguous(), pro[1].contiguous()
+    bias = conv.bias.detach().contiguous() if conv.bias is not None else None
+    _lib.check(lib.lion_conv3d_k3_fused_forward(
+        _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
+        b, cin, cout, r, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats),
+        _lib.stream_ptr(x.device)), "conv3d_k3_fused_forward")
+    return y, stats
+
+
+def groupnorm_fold(stats, gn: torch.nn.GroupNorm, fac, gbias, voxels):
+    """per-tile channel sums -> (A, Bs, chmean) with AdaGN(x) == x*A + Bs per (batch, channel)."""
+    b, c, t, _ = stats.shape
+    A = torch.empty((b, c), device=stats.device, dtype=torch.float32)
+    Bs = torch.empty_like(A)
+    cm = torch.empty_like(A)
+    # keep every temporary alive in a local until the launch is enqueued: a temporary created inside
+    # the argument list is freed before the next argument is evaluated and the caching allocator
+    # hands the same block to the next .contiguous() (fac would silently become gbias)
+    fac_c, gb_c = fac.contiguous(), gbias.contiguous()
+    _lib.check(_lib.load().lion_groupnorm_fold(
+        _lib.ptr(stats), b, c, t, gn.num_groups, int(voxels), _lib.ptr(gn.weight.detach()),
+        _lib.ptr(gn.bias.detach()), _lib.ptr(fac_c), _lib.ptr(gb_c), float(gn.eps),
+        _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(cm), _lib.stream_ptr(stats.device)), "groupnorm_fold")
+    return A, Bs, cm
+
+
+def devoxelize_affine(grid, coords, r, scale, shift):
+    """trilinear_devoxelize(scale[b,c]*grid + shift[b,c]) without materialising the scaled grid."""
+    b, c = grid.shape[:2]
+    n = coords.shape[2]
+    out = torch.empty((b, c, n), device=grid.device, dtype=torch.float32)
+    co_c, gr_c, sc_c, sh_c = coords.contiguous(), grid.contiguous(), scale.contiguous(), shift.contiguous()
+    _lib.check(_lib.load().lion_trilinear_devoxelize_affine_forward(
+        _lib.ptr(co_c), _lib.ptr(gr_c), _lib.ptr(sc_c), _lib.ptr(sh_c), b, c, n, int(r), _lib.ptr(out),
+        _lib.stream_ptr(grid.device)),
+        "trilinear_devoxelize_affine_forward")
+    return out
+
+
+def fusable(conv1, conv2, r, x):
+    return (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and supported(conv1.in_channels, conv1.out_channels, r)
+            and supported(conv2.in_channels, conv2.out_channels, r)
+            and conv2.in_channels % 4 == 0 and conv2.in_channels <= 256)

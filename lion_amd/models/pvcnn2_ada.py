@@ -17,6 +17,9 @@ from einops import rearrange
 
 from .. import functional as F
 from ..conv_ops import conv3d_module
+from .. import fused_ops
+
+FUSE_INFERENCE = True  # module-level switch (tests compare the fused and the layer-by-layer paths)
 from .adagn import AdaGN
 
 
@@ -186,6 +189,25 @@ class PVConv(nn.Module):
             self.point_features = SharedMLP(in_channels, out_channels, cfg=cfg)
         self.add_point_feat = add_point_feat
 
+    def _fused_voxel_branch(self, grid, voxel_coords, style):
+        """eval-mode voxel branch with every pointwise stage folded into the convolutions / the
+        devoxelisation (lion_amd/fused_ops.py): conv1 (+GN sums) -> fold -> conv2 with the
+        swish(AdaGN1(.)) prologue (+GN sums) -> fold, SE gate from the channel means ->
+        devoxelize(scale*grid + shift).  Dropout is the identity in eval mode."""
+        conv1, gn1, conv2, gn2 = self.voxel_layers[0], self.voxel_layers[1], self.voxel_layers[4], self.voxel_layers[5]
+        se = self.voxel_layers[6] if len(self.voxel_layers) > 6 else None
+        r = self.resolution
+        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True)
+        f1, g1 = gn1.affine(style)
+        a1, b1, _ = fused_ops.groupnorm_fold(st1, gn1.norm, f1, g1, r ** 3)
+        y2, st2 = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True)
+        f2, g2 = gn2.affine(style)
+        a2, b2, m2 = fused_ops.groupnorm_fold(st2, gn2.norm, f2, g2, r ** 3)
+        if se is not None:
+            gate = se.fc(a2 * m2 + b2)  # mean over the grid of AdaGN2(y2) is affine in mean(y2)
+            a2, b2 = a2 * gate, b2 * gate
+        return fused_ops.devoxelize_affine(y2, voxel_coords, r, a2, b2)
+
     def forward(self, inputs):
         features, coords_input, time_emb, style = inputs
         coords = coords_input[:, :3] if coords_input.shape[1] > 3 else coords_input
@@ -193,6 +215,14 @@ class PVConv(nn.Module):
             f'get feat: {features.shape} and {coords.shape}'
         assert coords.shape[1] == 3, f'expect coords: B,3,Npoint, get: {coords.shape}'
         grid, voxel_coords = self.voxelization(features, coords)
+        if (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled()
+                and fused_ops.fusable(self.voxel_layers[0], self.voxel_layers[4], self.resolution, grid)):
+            fused = self._fused_voxel_branch(grid, voxel_coords, style)
+            if self.add_point_feat:
+                fused = fused + self.point_features(features, style)
+            if self.attn is not None:
+                fused = self.attn(fused)
+            return fused, coords_input, time_emb, style
         for layer in self.voxel_layers:
             if isinstance(layer, AdaGN):
                 grid = layer(grid, style)

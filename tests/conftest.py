@@ -56,6 +56,10 @@ def fill_(module, seed=0):
                 t.copy_((r * (0.8 / np.sqrt(fan_in))).to(t.device))
             elif name.endswith("norm.weight") or "normalize" in name and name.endswith("weight"):
                 t.copy_((1.0 + 0.1 * r).to(t.device))
+            elif name.endswith("emd.bias"):
+                v = 0.1 * r
+                v[: t.numel() // 2] += 1.0
+                t.copy_(v.to(t.device))
             else:
                 t.copy_((0.1 * r).to(t.device))
 

@@ -62,6 +62,10 @@ def fill_(module, seed=0):
                 t.copy_(r * (0.8 / np.sqrt(fan_in)))
             elif name.endswith("norm.weight") or "normalize" in name and name.endswith("weight"):
                 t.copy_(1.0 + 0.1 * r)
+            elif name.endswith("emd.bias"):   # AdaGN: factor half around 1 (as the reference inits it), bias half around 0
+                v = 0.1 * r
+                v[: t.numel() // 2] += 1.0
+                t.copy_(v)
             else:
                 t.copy_(0.1 * r)
 
