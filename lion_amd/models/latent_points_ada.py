@@ -78,8 +78,12 @@ class PVCNN2Unet(nn.Module):
         assert len(timesteps.shape) == 1, f'get shape: {timesteps.shape}'
         timesteps = timesteps * self.time_emb_scales
         half_dim = self.embed_dim // 2
-        scale = np.log(10000) / (half_dim - 1)
-        freq = torch.from_numpy(np.exp(np.arange(0, half_dim) * -scale)).float().to(device)
+        cache = self.__dict__.setdefault('_freq_cache', {})  # per device; a per-call H2D copy is not graph-capturable
+        freq = cache.get(device)
+        if freq is None:
+            scale = np.log(10000) / (half_dim - 1)
+            freq = torch.from_numpy(np.exp(np.arange(0, half_dim) * -scale)).float().to(device)
+            cache[device] = freq
         emb = timesteps[:, None] * freq[None, :]
         emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
         if self.embed_dim % 2 == 1:

@@ -14,11 +14,16 @@ class PositionalEmbedding(nn.Module):
         super().__init__()
         self.embedding_dim = embedding_dim
         self.scale = scale
+        self._freq = {}  # device -> frequencies (built on the CPU exactly as the reference does, cached:
+        #                  a host->device copy per call cannot be captured in a hipGraph)
 
     def forward(self, timesteps):
         assert timesteps.dim() == 1
         half = self.embedding_dim // 2
-        freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(timesteps.device)
+        freq = self._freq.get(timesteps.device)
+        if freq is None:
+            freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(timesteps.device)
+            self._freq[timesteps.device] = freq
         ang = (timesteps * self.scale)[:, None] * freq[None, :]
         return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
 

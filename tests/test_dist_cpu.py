@@ -1,0 +1,129 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path: the data-parallel gradient step
+(lion_amd/dist.py, replaces utils/utils.py:717-770) and the sharding / gathering of a sampling job
+(lion_amd/sampling.py, trainers/base_trainer.py:447-487)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(fn, world=2):
+    port = _free_port()
+    mp.spawn(_entry, args=(world, port, fn), nprocs=world, join=True)
+
+
+def _entry(rank, world, port, fn):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(13, 32), torch.nn.SiLU(), torch.nn.Linear(32, 32),
+                               torch.nn.SiLU(), torch.nn.Linear(32, 5))
+
+
+def _w_bucketed(rank, world):
+    from lion_amd.dist import BucketedGradAverager, average_gradients, broadcast_params
+    m = _model(100 + rank)                       # different init per rank ...
+    broadcast_params(m.parameters())             # ... made identical by ONE flat broadcast
+    ref = _model(100)
+    for p, q in zip(m.parameters(), ref.parameters()):
+        assert torch.equal(p, q)
+    torch.manual_seed(7 + rank)
+    x, y = torch.randn(16, 13), torch.randn(16, 5)
+    # reference semantics: utils.average_gradients == mean of the per-rank gradients
+    m2 = _model(100)
+    (m2(x) - y).square().mean().backward()
+    average_gradients(m2.parameters())
+    # bucketed + overlapped (tiny buckets force several of them, launched from the grad hooks)
+    avg = BucketedGradAverager(m.parameters(), bucket_bytes=256, overlap=True)
+    assert len(avg.buckets) >= 3
+    for step in range(2):                         # second step: buffers reused, hooks still armed
+        avg.zero_grad()
+        (m(x) - y).square().mean().backward()
+        avg.finish()
+        for p, q in zip(m.parameters(), m2.parameters()):
+            torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7)
+    # every rank ends with the same averaged gradient
+    flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert torch.equal(other[0], other[1])
+    # a parameter that gets no gradient must not dead-lock its bucket
+    m3 = _model(100)
+    avg3 = BucketedGradAverager(m3.parameters(), bucket_bytes=256, overlap=True)
+    avg3.zero_grad()
+    (m3[0](x)).sum().backward()                   # only the first layer receives gradients
+    avg3.finish()
+    avg3.remove_hooks()
+    # non-overlapped mode gives the same numbers
+    m4 = _model(100)
+    avg4 = BucketedGradAverager(m4.parameters(), bucket_bytes=4096, overlap=False)
+    avg4.zero_grad()
+    (m4(x) - y).square().mean().backward()
+    avg4.finish()
+    for p, q in zip(m4.parameters(), m2.parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7)
+
+
+def _w_sampling(rank, world):
+    from lion_amd.sampling import gather_samples, rank_seed, shard_batch
+    total = 7                                     # ragged split: 4 + 3
+    mine = shard_batch(total, rank, world)
+    assert mine == (4 if rank == 0 else 3)
+    seeds = [rank_seed(1234, r) for r in range(world)]
+    assert len(set(seeds)) == world              # the reference reseeds every rank identically (bug)
+    torch.manual_seed(rank_seed(1234, rank))
+    pts = torch.randn(mine, 2048, 3)
+    allp = gather_samples(pts, world)
+    assert tuple(allp.shape) == (total, 2048, 3)
+    lo = 0 if rank == 0 else 4
+    assert torch.equal(allp[lo:lo + mine], pts)
+    # different ranks really drew different clouds
+    assert not torch.equal(allp[0], allp[4])
+
+
+def test_bucketed_gradient_averaging_two_ranks():
+    _run(_w_bucketed)
+
+
+def test_sampling_shard_and_gather_two_ranks():
+    _run(_w_sampling)
+
+
+def test_single_process_is_a_noop():
+    """is_distributed=False / world 1: every helper degenerates (utils/utils.py:719,768)."""
+    from lion_amd.dist import BucketedGradAverager, average_gradients, broadcast_params
+    from lion_amd.sampling import gather_samples, shard_batch
+    m = _model(0)
+    broadcast_params(m.parameters(), is_distributed=False)
+    (m(torch.randn(4, 13))).sum().backward()
+    g = [p.grad.clone() for p in m.parameters()]
+    average_gradients(m.parameters(), is_distributed=False)
+    for a, b in zip(g, m.parameters()):
+        assert torch.equal(a, b.grad)
+    avg = BucketedGradAverager(m.parameters())
+    avg.zero_grad()
+    (m(torch.randn(4, 13))).sum().backward()
+    avg.finish()
+    assert shard_batch(32, 0, 1) == 32
+    x = torch.randn(3, 8, 3)
+    assert gather_samples(x, 1) is x
