@@ -206,9 +206,10 @@ def main():
                     conv = m
                     break
             xin = torch.randn(B, 64, 32, 32, 32, device=dev)
-            tconv = ev_time(lambda: conv(xin), 10)
+            from lion_amd.conv_ops import conv3d_module
+            tconv = ev_time(lambda: conv3d_module(conv, xin), 10)
             flops = 2.0 * 27 * 64 * 64 * 32 ** 3 * B
-            roof = {"kernel": "Conv3d 3x3x3 64->64 @32^3 (PVConv voxel branch; MIOpen fp32)", "bound": "mfma",
+            roof = {"kernel": "conv3d_k3_kernel: Conv3d 3x3x3 64->64 @32^3, B=32 (PVConv voxel branch; fp32-MFMA implicit GEMM, csrc/conv3d.hip)", "bound": "mfma",
                     "achieved": flops / tconv / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": flops / tconv / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                     "us_per_launch": tconv * 1e6}

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "liblion_hip.so")
+SO_PATH = os.environ.get("LION_HIP_SO") or os.path.join(_HERE, "csrc", "liblion_hip.so")  # env: A/B of kernel builds
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 

@@ -13,7 +13,9 @@
 //
 // Workgroup = TD x TH x TW output voxels (256) x COT output channels, 4 waves; wave w owns voxels
 // [64w, 64w+64) x COT channels = 2x2 MFMA tiles (64 accumulator VGPRs).  K is walked in chunks of
-// KC = 4 input channels: the haloed input tile [KC][TD+2][TH+2][TW+2] (zero padded at the borders)
+// KC = 4 input channels (in-situ A/B over the whole denoiser step: KC 4 / 2 waves per SIMD 29.2 ms,
+// KC 4 / 3 waves 30.2, KC 2 / 3 waves 31.4 -- although KC 2 wins the isolated micro-benchmark):
+// the haloed input tile [KC][TD+2][TH+2][TW+2] (zero padded at the borders)
 // and the weight slice [KC][27][COT] (pre-packed once per weight tensor into [Cin][27][Cout]) are
 // staged in 41 KiB of LDS; the next chunk's global loads are in flight while the current chunk's
 // 54 k-steps (216 MFMAs per wave) execute.  Each k-step is 4 conflict-free ds_read_b32 + 4 MFMAs.
@@ -22,14 +24,20 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int KC = 4;
+#ifndef LION_CONV_KC
+#define LION_CONV_KC 4
+#endif
+#ifndef LION_CONV_WAVES
+#define LION_CONV_WAVES 2
+#endif
+constexpr int KC = LION_CONV_KC;
 
 // PRO:   the staged input is swish(x * pro_a[b][ci] + pro_b[b][ci]) (AdaGN affine + Swish of the
 //        previous layer, pvcnn2_ada.py:212-218, applied on the fly; zero padding stays zero).
 // STATS: per (batch, output channel, spatial tile) sum and sum of squares of the output are written
 //        to stats[b][co][tile][2] (GroupNorm statistics of the NEXT AdaGN without another pass).
 template <int TD, int TH, int TW, int COT, bool PRO, bool STATS>
-__global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(const float *__restrict__ x,
                                                                 const float *__restrict__ wp,
                                                                 const float *__restrict__ bias,
                                                                 float *__restrict__ y, int Cin,
@@ -130,25 +138,32 @@ __global__ __launch_bounds__(TD *TH *TW) void conv3d_k3_kernel(const float *__re
     __syncthreads();
     if (q + 1 < nchunks) load_chunk(q + 1); // in flight during the MFMAs below
 
+    // 54 k-steps (2 channel pairs x 27 taps), software pipelined by hand: the LDS reads of step s+1
+    // are issued before the MFMAs of step s (the compiler otherwise places each ds_read right in front
+    // of its consumer and stalls ~100 cycles on lgkmcnt(0) every 256 MFMA cycles: 70 % -> MFMA-bound).
+    constexpr int NS = (KC / 2) * 27;
+    float av[2][CB], bv[2][2];
+    auto lds_step = [&](int st, int buf) {
+      const int cp = st / 27, tap = st % 27;
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int toff = (kd * HH + kh) * HW + kw + cp * 2 * HALO;
+      bv[buf][0] = sx[boff[0] + toff];
+      bv[buf][1] = sx[boff[1] + toff];
+      const float *ap = sw + aoff + (cp * 2 * 27 + tap) * COT;
 #pragma unroll
-    for (int cp = 0; cp < KC / 2; ++cp) {
+      for (int cb = 0; cb < CB; ++cb) av[buf][cb] = ap[cb * 32];
+    };
+    lds_step(0, 0);
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
+    for (int st = 0; st < NS; ++st) {
+      if (st + 1 < NS) lds_step(st + 1, (st + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0); // keep the prefetch above this step's MFMAs
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int tap = (kd * 3 + kh) * 3 + kw;
-            const int toff = (kd * HH + kh) * HW + kw + cp * 2 * HALO;
-            const float b0 = sx[boff[0] + toff], b1 = sx[boff[1] + toff];
-            const float *ap = sw + aoff + (cp * 2 * 27 + tap) * COT;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-              const float a = ap[cb * 32];
-              acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[cb][0], 0, 0, 0);
-              acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[cb][1], 0, 0, 0);
-            }
-          }
+      for (int cb = 0; cb < CB; ++cb) {
+        acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][cb], bv[st & 1][0], acc[cb][0], 0, 0, 0);
+        acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][cb], bv[st & 1][1], acc[cb][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
