@@ -170,6 +170,15 @@ int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *f
                                              const float *shift, int B, int C, int N, int r, float *out,
                                              lionStream_t stream);
 
+/* ---- P2+P3(+P6) for 1-D / 2-D SharedMLP layers (inference), pvcnn2_ada.py:120-164, :375-377 --------
+ * after the 1x1 convolution: row sums -> lion_groupnorm_fold (T = 1) -> y = swish(x*A+Bs), optionally
+ * reduced with max over the U neighbours of each centre.  x is [rows = B*C, L] (L = N or M*U). */
+int lion_row_stats(const float *x, int rows, int L, float *stats, lionStream_t stream);
+int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows, int L, float *y,
+                      lionStream_t stream);
+int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int rows, int M, int U,
+                          float *y, lionStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

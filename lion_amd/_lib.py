@@ -46,6 +46,9 @@ SIGNATURES = {
     "lion_conv3d_k3_fused_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "lion_trilinear_devoxelize_affine_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_row_stats": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lion_affine_swish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "lion_affine_swish_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_ddim_update": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp]),
     "lion_ddpm_update": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp, _vp]),
 }

@@ -1,0 +1,110 @@
+// pointwise.hip -- P2/P3/P6 for the point branch and the SA/FP SharedMLPs (inference):
+// AdaGN + Swish (+ the max over the neighbourhood) after a 1x1 convolution in two passes over the
+// activations instead of the ~8 ATen launches of GroupNorm, *factor, +bias, sigmoid, mul, max
+// (models/pvcnn2_ada.py:120-164, :375-377; models/adagn.py:45-65).
+//   row_stats_kernel        [B,C,L] -> per (b,c) sum and sum of squares (then lion_groupnorm_fold)
+//   affine_swish_kernel     y = swish(x * A[b,c] + Bs[b,c])
+//   affine_swish_max_kernel [B,C,M,U] -> [B,C,M]: max_u swish(x * A + Bs)   (P6 fused)
+// All HBM bound: one read (+ one write) of the tensor per kernel, 16-byte lanes.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float swishf(float t) { return t / (1.0f + __expf(-t)); }
+
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int L,
+                                                        float *__restrict__ stats) {
+  __shared__ float r1[4], r2[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *p = x + (size_t)row * L;
+  float s1 = 0.f, s2 = 0.f;
+  if ((L & 3) == 0) {
+    for (int i = tid * 4; i < L; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4 *>(p + i);
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (int i = tid; i < L; i += 256) { const float v = p[i]; s1 += v; s2 += v * v; }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (lane == 0) { r1[wave] = s1; r2[wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    stats[(size_t)row * 2] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    stats[(size_t)row * 2 + 1] = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_swish_kernel(const float *__restrict__ x,
+                                                           const float *__restrict__ A,
+                                                           const float *__restrict__ Bs, int L,
+                                                           float *__restrict__ y) {
+  const int row = blockIdx.y;
+  const float a = A[row], b = Bs[row];
+  const float *p = x + (size_t)row * L;
+  float *q = y + (size_t)row * L;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < L && (L & 3) == 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + i);
+    *reinterpret_cast<float4 *>(q + i) =
+        make_float4(swishf(v.x * a + b), swishf(v.y * a + b), swishf(v.z * a + b), swishf(v.w * a + b));
+  } else {
+    for (int j = i; j < L && j < i + 4; ++j) q[j] = swishf(p[j] * a + b);
+  }
+}
+
+// one lane per centre m: U consecutive floats (U % 4 == 0), max of the activated values
+__global__ __launch_bounds__(256) void affine_swish_max_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ A,
+                                                               const float *__restrict__ Bs, int M,
+                                                               int U, float *__restrict__ y) {
+  const int row = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float a = A[row], b = Bs[row];
+  const float *p = x + ((size_t)row * M + m) * U;
+  float best = -INFINITY;
+  if ((U & 3) == 0) {
+    for (int u = 0; u < U; u += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(p + u);
+      best = fmaxf(best, fmaxf(fmaxf(swishf(v.x * a + b), swishf(v.y * a + b)),
+                               fmaxf(swishf(v.z * a + b), swishf(v.w * a + b))));
+    }
+  } else {
+    for (int u = 0; u < U; ++u) best = fmaxf(best, swishf(p[u] * a + b));
+  }
+  y[(size_t)row * M + m] = best;
+}
+
+} // namespace
+
+extern "C" {
+
+// x f32[rows, L] (rows = B*C) -> stats f32[rows, 2] (== the [B,C,T=1,2] layout of lion_groupnorm_fold)
+int lion_row_stats(const float *x, int rows, int L, float *stats, lionStream_t stream) {
+  if (!x || !stats || rows <= 0 || L <= 0) return LION_EINVAL;
+  row_stats_kernel<<<rows, 256, 0, static_cast<hipStream_t>(stream)>>>(x, L, stats);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows, int L, float *y,
+                      lionStream_t stream) {
+  if (!x || !A || !Bs || !y || rows <= 0 || L <= 0) return LION_EINVAL;
+  affine_swish_kernel<<<dim3(lion_cdiv(lion_cdiv(L, 4), 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      x, A, Bs, L, y);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int rows, int M, int U,
+                          float *y, lionStream_t stream) {
+  if (!x || !A || !Bs || !y || rows <= 0 || M <= 0 || U <= 0) return LION_EINVAL;
+  affine_swish_max_kernel<<<dim3(lion_cdiv(M, 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      x, A, Bs, M, U, y);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+} // extern "C"

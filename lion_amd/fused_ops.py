@@ -70,3 +70,26 @@ def fusable(conv1, conv2, r, x):
             and supported(conv1.in_channels, conv1.out_channels, r)
             and supported(conv2.in_channels, conv2.out_channels, r)
             and conv2.in_channels % 4 == 0 and conv2.in_channels <= 256)
+
+
+def adagn_swish(x, adagn, style, reduce_max=False):
+    """swish(AdaGN(x)) for a 1-D [B,C,N] / 2-D [B,C,M,U] activation in 3 launches (row sums, fold,
+    apply); reduce_max=True additionally takes the max over the last (neighbour) dimension."""
+    lib = _lib.load()
+    x = x.contiguous()
+    b, c = x.shape[:2]
+    L = x[0, 0].numel()
+    stats = torch.empty((b, c, 1, 2), device=x.device, dtype=torch.float32)
+    st = _lib.stream_ptr(x.device)
+    _lib.check(lib.lion_row_stats(_lib.ptr(x), b * c, L, _lib.ptr(stats), st), "row_stats")
+    f, g = adagn.affine(style)
+    A, Bs, _ = groupnorm_fold(stats, adagn.norm, f, g, L)
+    if reduce_max:
+        m, u = x.shape[2], x.shape[3]
+        y = torch.empty((b, c, m), device=x.device, dtype=torch.float32)
+        _lib.check(lib.lion_affine_swish_max(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), b * c, m, u, _lib.ptr(y), st),
+                   "affine_swish_max")
+        return y
+    y = torch.empty_like(x)
+    _lib.check(lib.lion_affine_swish(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), b * c, L, _lib.ptr(y), st), "affine_swish")
+    return y

@@ -121,10 +121,25 @@ class SharedMLP(nn.Module):
             in_channels = oc
         self.layers = nn.ModuleList(layers)
 
-    def _run(self, x, style):
+    def _fusable(self, x):
+        return (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled() and x.is_cuda
+                and x.dtype == torch.float32 and not torch.is_autocast_enabled())
+
+    def _run(self, x, style, reduce_max=False):
+        """reduce_max: additionally take the max over the last dimension (the SA modules' pooling,
+        reference :375-377), fused into the last layer's activation pass on the inference path."""
+        if self._fusable(x):
+            n = len(self.layers) // 3
+            for i in range(n):  # (1x1 conv, AdaGN, Swish) triples: conv on the library GEMM, the rest fused
+                x = self.layers[3 * i](x)
+                x = fused_ops.adagn_swish(x, self.layers[3 * i + 1], style, reduce_max and i == n - 1)
+            return x
         for layer in self.layers:
             x = layer(x, style) if isinstance(layer, AdaGN) else layer(x)
-        return x
+        return x.max(dim=-1).values if reduce_max else x
+
+    def forward_max(self, x, style):
+        return self._run(x, style, reduce_max=True)
 
     def forward(self, *inputs):
         if len(inputs) == 1 and len(inputs[0]) == 4:  # first layer of a Sequential: one 4-tuple
@@ -302,7 +317,7 @@ class PointNetSAModule(nn.Module):
         S = centers_coords.shape[-1]
         if time_emb is not None and type(time_emb) is not dict:
             time_emb = time_emb[:, :, :S]
-        pooled = [mlp(grouper(coords, centers_coords, features), style).max(dim=-1).values
+        pooled = [mlp.forward_max(grouper(coords, centers_coords, features), style)
                   for grouper, mlp in zip(self.groupers, self.mlps)]
         out = torch.cat(pooled, dim=1) if len(pooled) > 1 else pooled[0]
         return out, centers_coords, time_emb, style

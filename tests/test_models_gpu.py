@@ -144,3 +144,24 @@ def test_fused_pvconv_matches_layer_by_layer(cin, cout, r, n):
         got = pv((feat, coords, None, sty))[0]
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < 1e-4, err
+
+
+def test_fused_shared_mlp_and_sa_module_match_layer_by_layer():
+    """inference fusion of the 1-D / 2-D SharedMLP (row sums -> fold -> swish(AdaGN) [-> max over U])
+    == the torch layer sequence."""
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models import pvcnn2_ada as m
+    cfg = released_prior_cfg()
+    torch.manual_seed(5)
+    mlp1 = m.SharedMLP(19, [32, 48], dim=1, cfg=cfg); fill_(mlp1); mlp1.cuda().eval()
+    sa = m.PointNetSAModule(64, 0.6, 32, 16, [32, 64], cfg=cfg); fill_(sa); sa.cuda().eval()
+    x1 = torch.randn(3, 19, 777, device="cuda"); sty = torch.randn(3, 128, device="cuda")
+    feat = torch.randn(3, 16, 512, device="cuda"); coords = torch.randn(3, 3, 512, device="cuda")
+    with torch.no_grad():
+        m.FUSE_INFERENCE = False
+        r1 = mlp1(x1, sty); r2 = sa((feat, coords, None, sty))[0]
+        m.FUSE_INFERENCE = True
+        g1 = mlp1(x1, sty); g2 = sa((feat, coords, None, sty))[0]
+    for got, ref in ((g1, r1), (g2, r2)):
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-4, err
