@@ -220,7 +220,13 @@ def main():
             vbytes = 4.0 * B * (3 * N + C * N + C * r ** 3 + N + r ** 3) + 4.0 * B * 3 * N
             roofv = {"kernel": "voxelize_points (P1+K1+K2) C=64 N=2048 r=32: vox_index + vox_mean + vox_dense",
                      "bound": "hbm", "achieved": vbytes / tv / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": vbytes / tv / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_call": tv * 1e6}
+                     "frac": vbytes / tv / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_call": tv * 1e6,
+                     "algorithmic_bytes": vbytes}
+            try:  # HBM bytes per call from the separate rocprofv3 --pmc passes (cannot be collected live)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_voxelize_traffic.json")))
+                roofv["traffic"] = tj["hbm_bytes_per_call"]
+            except Exception:
+                pass
         out = {
             "metric": "shapes/sec @1000-step DDIM, Bx2048pts", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
                                                                 float *__restrict__ stats) {
   constexpr int TM = TD * TH * TW;
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
-  constexpr int NX = (KC * HALO + TM - 1) / TM;          // staged input floats per thread
+  constexpr int NJ = (HALO + TM - 1) / TM;               // staged input floats per thread and channel
   constexpr int WV4 = KC * 27 * COT / 4;                 // float4 of weights per chunk
   constexpr int NWV = (WV4 + TM - 1) / TM;               // staged weight float4 per thread
   constexpr int CB = COT / 32;                           // 32-channel MFMA row blocks
@@ -66,16 +66,19 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
   if (PRO) {
     for (int c = tid; c < Cin; c += TM) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
   }
-  // global offsets (relative to the chunk's first channel) of the input elements this thread stages
-  int goff[NX];
+  // spatial offsets of the halo positions this thread stages (the same for every input channel:
+  // slot (c, j) is position p = tid + j*TM of channel c, so the channel -- and with it the prologue
+  // scalars -- is uniform per slot and needs no per-element lookup).  Out-of-range positions (zero
+  // padding) load address 0 and are zeroed by a select: no branch around any load.
+  int goff[NJ];
+  bool gok[NJ];
 #pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int e = tid + i * TM;
-    const int c = e / HALO, p = e - c * HALO;
+  for (int j = 0; j < NJ; ++j) {
+    const int p = tid + j * TM;
     const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
     const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-    const bool ok = e < KC * HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
-    goff[i] = ok ? c * r3 + (gd * r + gh) * r + gw : -1;
+    gok[j] = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+    goff[j] = gok[j] ? (gd * r + gh) * r + gw : 0;
   }
   // LDS offsets of this lane's B operands (input): voxel (d,h,w) of each of the wave's 2 column blocks
   int boff[2];
@@ -96,12 +99,14 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
       for (int i = 0; i < 16; ++i) acc[cb][vb][i] = 0.f;
 
   const float *xb = x + (size_t)b * Cin * r3;
-  float rx[NX];
+  float rx[KC][NJ];
   float4 rw[NWV];
   auto load_chunk = [&](int q) {
     const float *xc = xb + (size_t)q * KC * r3;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) rx[i] = goff[i] >= 0 ? xc[goff[i]] : 0.f;
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) rx[c][j] = xc[(size_t)c * r3 + goff[j]];
     // weight slice: rows (ci, tap) of the packed [Cin][27][Cout] tensor, COT contiguous floats each
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
@@ -118,16 +123,18 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
   for (int q = 0; q < nchunks; ++q) {
     __syncthreads(); // everyone is done reading the previous chunk from LDS
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int e = tid + i * TM;
-      if (e < KC * HALO) {
-        float v = rx[i];
+    for (int c = 0; c < KC; ++c) {
+      float pa = 1.f, pb = 0.f;
+      if (PRO) { pa = spa[q * KC + c]; pb = spb[q * KC + c]; } // uniform: one broadcast read per channel
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int p = tid + j * TM;
+        float v = rx[c][j];
         if (PRO) {
-          const int c = q * KC + e / HALO;
-          const float t = v * spa[c] + spb[c];
-          v = goff[i] >= 0 ? t / (1.0f + __expf(-t)) : 0.f; // swish; padding stays zero
+          const float t = v * pa + pb;
+          v = t * __frcp_rn(1.0f + __expf(-t)); // swish(t) = t * sigmoid(t), v_exp + v_rcp
         }
-        sx[e] = v;
+        if (p < HALO) sx[c * HALO + p] = gok[j] ? v : 0.f; // zero padding stays zero
       }
     }
 #pragma unroll
