@@ -292,6 +292,11 @@ def lib() -> _Lib:
     return _lib
 
 
+def _n(t):
+    """CPU tensor -> numpy (autograd-tracked inputs are detached: the backends never differentiate)."""
+    return t.detach().contiguous().numpy()
+
+
 class TorchBackend:
     """The 12 ``_backend`` callables of bindings.cpp:10-37 over CPU torch tensors."""
 
@@ -304,55 +309,55 @@ class TorchBackend:
         return self.torch.from_numpy(a)
 
     def gather_features_forward(self, features, indices):
-        return self._t(self.l.gather_features_forward(features.numpy(), indices.numpy()))
+        return self._t(self.l.gather_features_forward(_n(features), _n(indices)))
 
     def gather_features_backward(self, grad_y, indices, n):
-        return self._t(self.l.gather_features_backward(grad_y.numpy(), indices.numpy(), n))
+        return self._t(self.l.gather_features_backward(_n(grad_y), _n(indices), n))
 
     def furthest_point_sampling(self, coords, m):
-        return self._t(self.l.furthest_point_sampling(coords.numpy(), m))
+        return self._t(self.l.furthest_point_sampling(_n(coords), m))
 
     def ball_query(self, centers, points, radius, k):
-        return self._t(self.l.ball_query(centers.numpy(), points.numpy(), radius, k))
+        return self._t(self.l.ball_query(_n(centers), _n(points), radius, k))
 
     def grouping_forward(self, features, indices):
-        return self._t(self.l.grouping_forward(features.numpy(), indices.numpy()))
+        return self._t(self.l.grouping_forward(_n(features), _n(indices)))
 
     def grouping_backward(self, grad_y, indices, n):
-        return self._t(self.l.grouping_backward(grad_y.numpy(), indices.numpy(), n))
+        return self._t(self.l.grouping_backward(_n(grad_y), _n(indices), n))
 
     def three_nearest_neighbors_interpolate_forward(self, points, centers, cfeat):
-        o, i, w = self.l.three_nn_interpolate_forward(points.numpy(), centers.numpy(),
-                                                      cfeat.numpy())
+        o, i, w = self.l.three_nn_interpolate_forward(_n(points), _n(centers),
+                                                      _n(cfeat))
         return self._t(o), self._t(i), self._t(w)
 
     def three_nearest_neighbors_interpolate_backward(self, grad_y, idx, w, m):
-        return self._t(self.l.three_nn_interpolate_backward(grad_y.numpy(), idx.numpy(),
-                                                            w.numpy(), m))
+        return self._t(self.l.three_nn_interpolate_backward(_n(grad_y), _n(idx),
+                                                            _n(w), m))
 
     def trilinear_devoxelize_forward(self, r, is_training, coords, feats):
-        o, i, w = self.l.trilinear_devoxelize_forward(r, is_training, coords.numpy(),
-                                                      feats.numpy())
+        o, i, w = self.l.trilinear_devoxelize_forward(r, is_training, _n(coords),
+                                                      _n(feats))
         return self._t(o), self._t(i), self._t(w)
 
     def trilinear_devoxelize_backward(self, grad_y, inds, wgts, r):
-        return self._t(self.l.trilinear_devoxelize_backward(grad_y.numpy(), inds.numpy(),
-                                                            wgts.numpy(), r))
+        return self._t(self.l.trilinear_devoxelize_backward(_n(grad_y), _n(inds),
+                                                            _n(wgts), r))
 
     def avg_voxelize_forward(self, feats, coords, r):
-        o, i, c = self.l.avg_voxelize_forward(feats.numpy(), coords.numpy(), r)
+        o, i, c = self.l.avg_voxelize_forward(_n(feats), _n(coords), r)
         return self._t(o), self._t(i), self._t(c)
 
     def avg_voxelize_backward(self, grad_y, ind, cnt):
-        return self._t(self.l.avg_voxelize_backward(grad_y.numpy(), ind.numpy(), cnt.numpy()))
+        return self._t(self.l.avg_voxelize_backward(_n(grad_y), _n(ind), _n(cnt)))
 
     # fused Voxelization.forward (not in the reference module; lion_amd.models call it)
     def voxelize_points_forward(self, features, coords, resolution, normalize=True, eps=0.0):
-        nc, vox = self.l.voxelize_coords(coords.numpy(), int(resolution), normalize, eps)
+        nc, vox = self.l.voxelize_coords(_n(coords), int(resolution), normalize, eps)
         if features is None:
             b, _, n = coords.shape
             f0 = np.zeros((b, 1, n), np.float32)
             _, i, c = self.l.avg_voxelize_forward(f0, vox, int(resolution))
             return None, self._t(nc), self._t(i), self._t(c)
-        o, i, c = self.l.avg_voxelize_forward(features.numpy(), vox, int(resolution))
+        o, i, c = self.l.avg_voxelize_forward(_n(features), vox, int(resolution))
         return self._t(o), self._t(nc), self._t(i), self._t(c)

@@ -199,6 +199,25 @@ def main():
     dif["alpha_bars_f32"] = Alpha_bar.numpy()
     dif["ddim_coef_1000"] = np.array(coef, np.float64)
     np.savez_compressed(os.path.join(HERE, "diffusion_constants.npz"), **dif)
+    # ---- (g) VAE style encoder (non-ada pvcnn2 blocks) forward + backward, N = 1024 ---------------
+    from models.shapelatent_modules import PointNetPlusEncoder
+    se = PointNetPlusEncoder(zdim=128, input_dim=3, args=cfg)
+    fill_(se)
+    se.train()
+    for mod in se.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    xs = torch.from_numpy((rng.standard_normal((1, 1024, 3)) * 0.5).astype(np.float32))
+    o = se(xs)
+    wv = torch.from_numpy(rng.standard_normal((1, 128)).astype(np.float32))
+    ((o['mu_1d'] * wv).sum() + (o['sigma_1d'] * wv).sum()).backward()
+    names = ['layers.0.0.voxel_layers.0.weight', 'layers.0.1.voxel_layers.6.fc.0.weight',
+             'layers.0.2.mlps.0.layers.0.weight', 'layers.1.0.voxel_layers.4.weight', 'mlp.weight']
+    sed = dict(x=xs.numpy(), w=wv.numpy(), mu=o['mu_1d'].detach().numpy(), sigma=o['sigma_1d'].detach().numpy())
+    P = dict(se.named_parameters())
+    for n in names:
+        sed['g_' + n] = P[n].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "style_encoder.npz"), **sed)
     print("golden fixtures written to", HERE)
 
 

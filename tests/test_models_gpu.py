@@ -165,3 +165,26 @@ def test_fused_shared_mlp_and_sa_module_match_layer_by_layer():
     for got, ref in ((g1, r1), (g2, r2)):
         err = (got - ref).abs().max().item() / ref.abs().max().item()
         assert err < 1e-4, err
+
+
+def test_style_encoder_forward_backward_vs_reference():
+    """VAE style encoder (non-ada pvcnn2 blocks, N=1024) forward + backward against the reference's
+    PointNetPlusEncoder (golden, PyTorch-CPU + oracle operators)."""
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models.shapelatent_modules import PointNetPlusEncoder
+    z = g("style_encoder.npz")
+    m = PointNetPlusEncoder(zdim=128, input_dim=3, args=released_prior_cfg())
+    fill_(m)
+    m.cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    o = m(torch.from_numpy(z["x"]).cuda())
+    w = torch.from_numpy(z["w"]).cuda()
+    ((o['mu_1d'] * w).sum() + (o['sigma_1d'] * w).sum()).backward()
+    close(o['mu_1d'], z["mu"])
+    close(o['sigma_1d'], z["sigma"])
+    P = dict(m.named_parameters())
+    for k in z.files:
+        if k.startswith("g_"):
+            close(P[k[2:]].grad, z[k], 1e-4)
