@@ -5,26 +5,22 @@
 //
 // MI355X design (not the reference's "one block per cloud + global float atomics + memset").
 // What was measured on the chip (tools/exp/*.hip) shaped it: a plain zero fill of the [B,C,r^3] grid
-// with one 16-byte store per lane per channel reaches 7.5-8.0 TB/s; every load that a store has to
-// wait for costs dearly once the memory pipe is saturated with stores (two dependent round trips
-// + a block barrier in front of the stores: 2.3 TB/s; one int4 load + one batch of independent
-// gathers: 5.8 TB/s).  Hence three kernels:
-//   1  vox_index_kernel  one 1024-thread workgroup per cloud.  The r^3 occupancy histogram lives in
-//      LDS (128 KiB at r=32, padded so the segmented scan is bank-conflict free); points are
-//      counting-sorted by (voxel, point index); outputs: ind, the dense count grid, a dense "slot"
-//      grid (rank of the voxel among the occupied ones, -1 if empty), the occupied-voxel list
-//      (start,count) and the sorted point list.  No memset, no global atomics.  With FUSE_P1 the
-//      kernel first normalises the raw float coordinates (mean / max-norm / round-half-even) with
-//      the fixed summation tree the oracle documents, so voxel indices are bit-exact.
-//   2  vox_mean_kernel   one lane per (occupied voxel, channel tile): sums the voxel's points in
-//      ascending point index (bit-exact vs the sequential oracle; 1-2 gathers from the L2-resident
-//      feature row on average) into a compact table vmean[B,C,U].
-//   3  vox_dense_kernel  writes the dense [C, r^3] grid exactly once: int4 slot load, (rare)
-//      independent table gathers for a 16-channel tile, then 16 back-to-back 16-byte stores per lane.
-//      >= 94 % of the lanes store zeros and never wait for anything but the slot load.
-// HBM traffic ~= the algorithmic 4*B*(3N + C*N + C*r^3 + N + r^3) bytes + the slot grid (4*B*r^3 x2).
-//   fallback (r^3 or N too large for LDS): memset + integer/float atomics, like the reference but
-//            with a (points x batch) grid.  Within 1e-6 of the oracle, not bit-exact.
+// with one 16-byte store per lane per channel reaches 7.5-8.0 TB/s; every global load that a store
+// has to wait for costs dearly once the memory pipe is saturated with stores (vmcnt counts stores
+// too: two dependent round trips in front of the stores -> 2.3 TB/s); random 4-byte gathers cost one
+// TA cycle per lane and a 128-byte line per miss, so they must be spread over many CUs and kept on
+// one XCD's L2 per cloud.  Hence ONE kernel whose store phase depends on LDS only:
+//   vox_fused_kernel  grid = (cloud, slab of r^3/S voxels), 1024 threads, the S slabs of a cloud on
+//   the same XCD.  A) voxel ids of all N points (optionally the fused P1 normalisation with the
+//   oracle's fixed summation tree -> bit-exact indices), LDS histogram of the slab, count slab out;
+//   scan + counting sort of the slab's points by (voxel, point index) in LDS.  B) per-voxel feature
+//   means for a chunk of channels gathered from the L2-resident rows into LDS (ascending point
+//   index -> bit-exact vs the sequential oracle; 8 independent gathers in flight per lane).
+//   C) the slab of the dense grid is written exactly once: per channel one int4 slot read + 4 LDS
+//   lookups + one 16-byte store per lane, no global load anywhere near the stores.
+// No memset, no global atomics, no workspace.
+//   fallback (r^3 or N too large for LDS, misaligned output): memset + integer/float atomics, like
+//            the reference but with a (points x batch) grid.  Within 1e-6 of the oracle, not bit-exact.
 #include "common.h"
 
 namespace {
@@ -36,44 +32,45 @@ constexpr int LDS_LIMIT = 160 * 1024;
 __device__ __forceinline__ int padv(int v) { return v + (v >> 5); }
 __host__ __device__ inline int align4i(int x) { return (x + 3) & ~3; }
 
-struct IndexLds {
-  int hist_words, n_words;
-  size_t bytes;
-};
-static inline IndexLds index_lds(int N, long r3) {
-  IndexLds l;
-  l.hist_words = align4i((int)(r3 + (r3 >> 5) + 1));
-  l.n_words = align4i(N);
-  // hist | tmp[N] | ust[N] | 64 floats | 64 ints
-  l.bytes = ((size_t)l.hist_words + 2 * (size_t)l.n_words + 128) * 4;
-  return l;
-}
-
-template <bool FUSE_P1>
-__global__ __launch_bounds__(VT) void vox_index_kernel(
-    const int32_t *__restrict__ coords_i, const float *__restrict__ coords_f, int N, int r,
-    int normalize, float eps, float *__restrict__ norm_coords, int32_t *__restrict__ ind,
-    int32_t *__restrict__ cnt, int32_t *__restrict__ vslot, int32_t *__restrict__ sorted,
-    int32_t *__restrict__ uinfo, int32_t *__restrict__ ucount, int hist_words, int n_words) {
+// ---------------------------------------------------------------------------------------------
+// vox_fused_kernel: see the header comment.  NP = points per thread (N <= NP * 1024).
+// LDS (dynamic): slot[SVP] | ust[nw] | fscr[64] | iscr[32] | arena[arena_words]; during phase A the
+// arena holds hist[SVP] | tmp[nw], afterwards prod[ch * my_pts] | vm[ch * my_occ].
+// ---------------------------------------------------------------------------------------------
+template <bool FUSE_P1, int NP>
+__global__ __launch_bounds__(VT) void vox_fused_kernel(
+    const float *__restrict__ feat, const int32_t *__restrict__ coords_i,
+    const float *__restrict__ coords_f, int B, int C, int N, int r, int S, int CS, int SV, int n_words,
+    int arena_words, int ch_cap, int normalize, float eps, float *__restrict__ out,
+    float *__restrict__ norm_coords, int32_t *__restrict__ ind, int32_t *__restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t *hist = reinterpret_cast<uint32_t *>(smem); // count, later (urank << 16) | count
-  int32_t *tmp = reinterpret_cast<int32_t *>(hist + hist_words);
-  int32_t *ust = tmp + n_words;                         // (start << 16) | count per occupied voxel
-  float *fscr = reinterpret_cast<float *>(ust + n_words); // 64 floats
-  int *iscr = reinterpret_cast<int *>(fscr + 64);         // 64 ints
+  const int SVP = ((SV + (SV >> 5) + 3) & ~3) + 4;         // padded (1 word per 32) + 16-byte aligned
+  int32_t *slot = reinterpret_cast<int32_t *>(smem);       // [SVP] arrival counters, later dense slots
+  int32_t *ust = slot + SVP;                               // [nw] (start << 16) | count per occupied voxel
+  float *fscr = reinterpret_cast<float *>(ust + n_words);  // 64
+  int *iscr = reinterpret_cast<int *>(fscr + 64);          // 32
+  float *arena = reinterpret_cast<float *>(iscr + 32);     // [arena_words]
+  uint32_t *hist = reinterpret_cast<uint32_t *>(arena);    // [SVP] count, later (urank << 16) | count
+  int32_t *tmp = reinterpret_cast<int32_t *>(hist + SVP);  // [nw] bucket contents in arrival order
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
+  // workgroups go round-robin over the 8 XCDs: keep the S slabs of a cloud on one XCD so that
+  // its feature rows are fetched into one L2 only
+  const int W = S * CS; // workgroups per cloud: S voxel slabs x CS channel ranges
+  const int L = blockIdx.x, grp = L / (8 * W), j8 = L - grp * 8 * W;
+  const int b = grp * 8 + (j8 & 7), wq = j8 >> 3, slab = wq % S, cs = wq / S;
+  if (b >= B) return;
   const int r2 = r * r, r3 = r2 * r;
+  const int lo = slab * SV;
 
-  for (int v = tid; v < hist_words; v += VT) hist[v] = 0u;
+  for (int v = tid; v < SVP; v += VT) { hist[v] = 0u; slot[v] = 0; }
 
-  int myv[MAXP];
+  int myv[NP];
   if (FUSE_P1) {
     const float *co = coords_f + (size_t)b * 3 * N;
-    float px[MAXP], py[MAXP], pz[MAXP];
+    float px[NP], py[NP], pz[NP];
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int i = tid + p * VT;
       px[p] = py[p] = pz[p] = 0.0f;
       if (i < N) { px[p] = co[i]; py[p] = co[i + N]; pz[p] = co[i + 2 * N]; }
@@ -82,7 +79,7 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
     // then p[t] += p[t+s], s = 1..512.  An xor butterfly evaluates the same tree bit for bit.
     float part[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int i = tid + p * VT;
       if (i < N) {
         part[0] = add_rn(part[0], px[p]);
@@ -109,7 +106,7 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
     if (normalize) {
       float mx = 0.0f;
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p) {
+      for (int p = 0; p < NP; ++p) {
         const int i = tid + p * VT;
         if (i < N) {
           const float x = sub_rn(px[p], mean[0]), y = sub_rn(py[p], mean[1]),
@@ -130,7 +127,7 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
     float *nc = norm_coords + (size_t)b * 3 * N;
     const float rf = (float)r, hi = (float)(r - 1);
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int i = tid + p * VT;
       myv[p] = 0;
       if (i < N) {
@@ -143,7 +140,7 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
           v = mul_rn(v, rf);
           v = v < 0.0f ? 0.0f : v;
           v = v > hi ? hi : v;
-          nc[i + a * N] = v;
+          if (wq == 0) nc[i + a * N] = v;
           q[a] = (int)rintf(v);
         }
         myv[p] = q[0] * r2 + q[1] * r + q[2];
@@ -152,179 +149,146 @@ __global__ __launch_bounds__(VT) void vox_index_kernel(
   } else {
     const int32_t *co = coords_i + (size_t)b * 3 * N;
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int i = tid + p * VT;
       myv[p] = 0;
       if (i < N) myv[p] = co[i] * r2 + co[i + N] * r + co[i + 2 * N]; // vox.cu:31
     }
   }
-
-  int myarr[MAXP];
   __syncthreads(); // hist zeroed
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int i = tid + p * VT;
-    myarr[p] = 0;
     if (i < N) {
-      ind[(size_t)b * N + i] = myv[p];
+      if (wq == 0) ind[(size_t)b * N + i] = myv[p];
       // memory safety only: coordinates outside [0,r) are a caller error (as in the reference)
-      myv[p] = min(max(myv[p], 0), r3 - 1);
-      myarr[p] = (int)atomicAdd(&hist[padv(myv[p])], 1u);
+      myv[p] = min(max(myv[p], 0), r3 - 1) - lo;
+      if (myv[p] >= 0 && myv[p] < SV) atomicAdd(&hist[padv(myv[p])], 1u);
     }
   }
   __syncthreads();
+  // dense count slab (16 bytes per lane)
+  for (int v = tid * 4; v < SV && cs == 0; v += VT * 4)
+    *reinterpret_cast<int4 *>(cnt + (size_t)b * r3 + lo + v) =
+        make_int4((int)hist[padv(v)], (int)hist[padv(v + 1)], (int)hist[padv(v + 2)], (int)hist[padv(v + 3)]);
+  if (feat == nullptr) return;
 
-  // exclusive scan of the histogram: thread t owns voxels [t*VPT, (t+1)*VPT) (conflict free
-  // thanks to the +v/32 padding); one packed block scan gives both the point offset (start) and
-  // the rank among occupied voxels; each entry becomes (urank << 16) | count.
-  const int VPT = (r3 + VT - 1) / VT;
-  const int v0 = min(tid * VPT, r3), v1 = min(v0 + VPT, r3);
-  int lp = 0, lo = 0;
-  for (int v = v0; v < v1; ++v) { const int c = (int)hist[padv(v)]; lp += c; lo += (c > 0); }
-  const int packed = (lp << 16) | lo; // points < 2^14, occupied <= N < 2^14
+  // ---- scan: rank among the slab's occupied voxels + start in the sorted list -------------------
+  const int VPT = (SV + VT - 1) / VT;
+  const int v0 = min(tid * VPT, SV), v1 = min(v0 + VPT, SV);
+  int lp = 0, lq = 0;
+  for (int v = v0; v < v1; ++v) { const int c = (int)hist[padv(v)]; lp += c; lq += (c > 0); }
+  const int packed = (lp << 16) | lq;
   const int incl = wave_incl_scan(packed, lane);
   if (lane == 63) iscr[wave] = incl;
   __syncthreads();
-  int excl = incl - packed;
-  for (int w = 0; w < wave; ++w) excl += iscr[w];
-  int run = excl >> 16, urun = excl & 0xffff;
-  for (int v = v0; v < v1; ++v) {
-    const uint32_t c = hist[padv(v)];
-    if (c) {
-      hist[padv(v)] = ((uint32_t)urun << 16) | c;
-      ust[urun] = (run << 16) | (int)c;
-      ++urun;
-      run += (int)c;
+  int excl = incl - packed, total = 0;
+  for (int w = 0; w < VT / 64; ++w) { const int t = iscr[w]; if (w < wave) excl += t; total += t; }
+  const int my_pts = total >> 16, my_occ = total & 0xffff;
+  {
+    int run = excl >> 16, urun = excl & 0xffff;
+    for (int v = v0; v < v1; ++v) {
+      const uint32_t c = hist[padv(v)];
+      if (c) {
+        hist[padv(v)] = ((uint32_t)urun << 16) | c;
+        ust[urun] = (run << 16) | (int)c;
+        ++urun;
+        run += (int)c;
+      }
     }
   }
-  if (tid == VT - 1) ucount[b] = urun;
   __syncthreads();
-
-  // bucket placement in arrival order, then the deterministic rank inside the bucket
+  // ---- counting sort by (voxel, point index): arrival order, then the rank inside the bucket ----
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int i = tid + p * VT;
-    if (i < N) tmp[(ust[hist[padv(myv[p])] >> 16] >> 16) + myarr[p]] = i;
+    if (i < N && myv[p] >= 0 && myv[p] < SV) {
+      const int a = atomicAdd(&slot[padv(myv[p])], 1);
+      tmp[(ust[hist[padv(myv[p])] >> 16] >> 16) + a] = i;
+    }
   }
   __syncthreads();
+  // rank inside the bucket = number of smaller point indices -> position in the (voxel, index) order
+  int posv[NP];
+  float invp[NP];
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int i = tid + p * VT;
-    if (i < N) {
+    posv[p] = -1;
+    invp[p] = 0.f;
+    if (i < N && myv[p] >= 0 && myv[p] < SV) {
       const int h = ust[hist[padv(myv[p])] >> 16];
       const int s = h >> 16, c = h & 0xffff;
       int rank = 0;
-      for (int k = 0; k < c; ++k) rank += (tmp[s + k] < i) ? 1 : 0;
-      sorted[(size_t)b * N + s + rank] = i;
+      for (int q = 0; q < c; ++q) rank += (tmp[s + q] < i) ? 1 : 0;
+      posv[p] = s + rank;
+      invp[p] = div_rn(1.0f, (float)c); // vox.cu:66 (== float(1.0 / cnt))
     }
   }
-  // dense outputs, 16 bytes per lane: counts and slots (r3 % 4 == 0)
-  for (int v = tid * 4; v < r3; v += VT * 4) {
-    int4 c, sl;
-    const uint32_t h0 = hist[padv(v)], h1 = hist[padv(v + 1)], h2 = hist[padv(v + 2)], h3 = hist[padv(v + 3)];
-    c.x = h0 & 0xffff; c.y = h1 & 0xffff; c.z = h2 & 0xffff; c.w = h3 & 0xffff;
-    sl.x = c.x ? (int)(h0 >> 16) : -1; sl.y = c.y ? (int)(h1 >> 16) : -1;
-    sl.z = c.z ? (int)(h2 >> 16) : -1; sl.w = c.w ? (int)(h3 >> 16) : -1;
-    *reinterpret_cast<int4 *>(cnt + (size_t)b * r3 + v) = c;
-    *reinterpret_cast<int4 *>(vslot + (size_t)b * r3 + v) = sl;
+  // dense slots, unpadded so that phase C reads them 16 bytes at a time
+  for (int v = tid; v < SV; v += VT) {
+    const uint32_t h = hist[padv(v)];
+    slot[v] = (h & 0xffff) ? (int)(h >> 16) : -1;
   }
-  for (int u = tid; u < N; u += VT) uinfo[(size_t)b * N + u] = ust[u]; // entries >= U are unused
-}
 
-// vmean[b][c][u] = sum_k feat[b][c][p_k] * (1/n), p_k ascending (vox.cu:59-71 with the order fixed
-// to ascending point index, as in the oracle).  One workgroup per (batch, tile of CT channels): the
-// CT feature rows are staged in LDS with coalesced 16-byte loads (random 4-byte gathers straight
-// from global memory cost one TA cycle per lane: 53 us for 3.2 M gathers; from LDS they are free),
-// then lanes walk the occupied voxels and write the table coalesced.
-__global__ __launch_bounds__(256) void vox_mean_kernel(const float *__restrict__ feat,
-                                                       const int32_t *__restrict__ sorted,
-                                                       const int32_t *__restrict__ uinfo,
-                                                       const int32_t *__restrict__ ucount, int C,
-                                                       int N, int CT, float *__restrict__ vmean) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *rows = reinterpret_cast<float *>(smem);            // [CT][N]
-  int32_t *ssrt = reinterpret_cast<int32_t *>(rows + (size_t)CT * N); // [N] sorted point list
-  int32_t *sinf = ssrt + N;                                  // [N] (start << 16) | count
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int c0 = blockIdx.x * CT, nc = min(CT, C - c0);
-  const float *src = feat + ((size_t)b * C + c0) * N;
-  const int tot = nc * N;
-  if ((N & 3) == 0) {
-    for (int i = tid * 4; i < tot; i += 1024)
-      *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
-  } else {
-    for (int i = tid; i < tot; i += 256) rows[i] = src[i];
-  }
-  // everything a lane will need comes in with this one batch of coalesced loads (a per-voxel
-  // uinfo -> sorted -> feature chain of dependent global loads was 7x slower)
-  const int U = ucount[b];
-  for (int i = tid; i < N; i += 256) ssrt[i] = sorted[(size_t)b * N + i];
-  for (int i = tid; i < U; i += 256) sinf[i] = uinfo[(size_t)b * N + i];
-  __syncthreads();
-  float *dst = vmean + ((size_t)b * C + c0) * N;
-  for (int u = tid; u < U; u += 256) {
-    const int info = sinf[u], st = info >> 16, n = info & 0xffff;
-    const float inv = div_rn(1.0f, (float)n); // vox.cu:66 (== float(1.0 / cnt))
-    const int32_t *srt = ssrt + st;
-    if (n <= 4) {
-      int p[4];
+  // ---- phases B + C per chunk of channels ---------------------------------------------------------
+  const int q4 = SV >> 2; // int4 groups in the slab
+  const int ch_max = min(ch_cap, my_pts > 0 ? min(C, arena_words / (my_pts + my_occ)) : C);
+  const int step_c = VT / q4, step_g = VT - step_c * q4;
+  const int c_per = (C + CS - 1) / CS, c_lo = cs * c_per, c_hi = min(C, c_lo + c_per);
+  for (int c0 = c_lo; c0 < c_hi; c0 += ch_max) {
+    const int ch = min(ch_max, c_hi - c0);
+    float *prod = arena, *vm = arena + ch * my_pts;
+    __syncthreads(); // hist/tmp (or the previous chunk's vm) are dead from here on
+    if (my_pts > 0) {
+      // B1: every lane reads ITS points' feature rows fully coalesced (the 8 slabs of a cloud share
+      // the rows through one L2); only lanes whose point lies in the slab keep feat * (1 / count),
+      // at the point's sorted position.  No gathers, no dependent loads.
+      const float *fb = feat + ((size_t)b * C + c0) * N;
+      constexpr int CU = 16 / NP; // 16 independent row loads in flight per lane
+      for (int cl0 = 0; cl0 < ch; cl0 += CU) {
+        float f[CU][NP];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) p[k] = srt[k < n ? k : 0];
-      for (int c = 0; c < nc; ++c) {
-        const float *rw = rows + c * N;
-        float acc = mul_rn(rw[p[0]], inv); // 0 + x == x
-        const float a1 = add_rn(acc, mul_rn(rw[p[1]], inv));
-        acc = n > 1 ? a1 : acc;
-        const float a2 = add_rn(acc, mul_rn(rw[p[2]], inv));
-        acc = n > 2 ? a2 : acc;
-        const float a3 = add_rn(acc, mul_rn(rw[p[3]], inv));
-        acc = n > 3 ? a3 : acc;
-        dst[(size_t)c * N + u] = acc;
+        for (int k = 0; k < CU; ++k)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            f[k][p] = fb[(size_t)min(cl0 + k, ch - 1) * N + min(tid + p * VT, N - 1)];
+#pragma unroll
+        for (int k = 0; k < CU; ++k)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            if (posv[p] >= 0 && cl0 + k < ch) prod[(cl0 + k) * my_pts + posv[p]] = mul_rn(f[k][p], invp[p]);
       }
-    } else {
-      for (int c = 0; c < nc; ++c) {
-        const float *rw = rows + c * N;
-        float acc = 0.f;
-        for (int k = 0; k < n; ++k) acc = add_rn(acc, mul_rn(rw[srt[k]], inv));
-        dst[(size_t)c * N + u] = acc;
+      __syncthreads();
+      // B2: per-voxel means from LDS, summed in ascending point index (vox.cu:59-71)
+      const int items = my_occ * ch;
+      for (int it = tid; it < items; it += VT) {
+        const int cl = it / my_occ, u = it - cl * my_occ;
+        const int info = ust[u], st = info >> 16, n = info & 0xffff;
+        const float *pr = prod + cl * my_pts + st;
+        float acc = add_rn(0.f, pr[0]);
+        for (int k = 1; k < n; ++k) acc = add_rn(acc, pr[k]);
+        vm[it] = acc; // it == cl * my_occ + u
       }
     }
-  }
-}
-
-// Dense write: 128-thread workgroups, 512 voxels x CT channels each.
-template <int CT>
-__global__ __launch_bounds__(128) void vox_dense_kernel(const int32_t *__restrict__ vslot,
-                                                        const float *__restrict__ vmean, int C,
-                                                        int N, int r3, float *__restrict__ out) {
-  const int b = blockIdx.z, c0 = blockIdx.y * CT;
-  const int v0 = (blockIdx.x * 128 + threadIdx.x) * 4;
-  if (v0 >= r3) return;
-  float *ob = out + ((size_t)b * C + c0) * r3 + v0;
-  const int4 s = *reinterpret_cast<const int4 *>(vslot + (size_t)b * r3 + v0);
-  const int nc = min(CT, C - c0);
-  if ((s.x & s.y & s.z & s.w) < 0) { // all four slots are -1: empty
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-      if (c < nc) *reinterpret_cast<float4 *>(ob + (size_t)c * r3) = z;
-    return;
-  }
-  const float *tb = vmean + ((size_t)b * C + c0) * N;
-  float4 v[CT];
-#pragma unroll
-  for (int c = 0; c < CT; ++c) { // all gathers first ...
-    v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < nc) {
-      if (s.x >= 0) v[c].x = tb[(size_t)c * N + s.x];
-      if (s.y >= 0) v[c].y = tb[(size_t)c * N + s.y];
-      if (s.z >= 0) v[c].z = tb[(size_t)c * N + s.z];
-      if (s.w >= 0) v[c].w = tb[(size_t)c * N + s.w];
+    __syncthreads();
+    // C: the slab of the dense grid for channels [c0, c0 + ch): LDS -> 16-byte stores only
+    int cl = tid / q4, g = tid - cl * q4;
+    float *obase = out + ((size_t)b * C + c0) * r3 + lo;
+    while (cl < ch) {
+      const int4 sl = *reinterpret_cast<const int4 *>(slot + 4 * g);
+      const float *vmc = vm + cl * my_occ;
+      const float x = vmc[max(sl.x, 0)], y = vmc[max(sl.y, 0)], z = vmc[max(sl.z, 0)], w = vmc[max(sl.w, 0)];
+      float4 o;
+      o.x = sl.x >= 0 ? x : 0.f;
+      o.y = sl.y >= 0 ? y : 0.f;
+      o.z = sl.z >= 0 ? z : 0.f;
+      o.w = sl.w >= 0 ? w : 0.f;
+      *reinterpret_cast<float4 *>(obase + (size_t)cl * r3 + 4 * g) = o;
+      cl += step_c; g += step_g;
+      if (g >= q4) { g -= q4; ++cl; }
     }
   }
-#pragma unroll
-  for (int c = 0; c < CT; ++c) // ... then nothing but stores
-    if (c < nc) *reinterpret_cast<float4 *>(ob + (size_t)c * r3) = v[c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,8 +390,9 @@ __global__ __launch_bounds__(256) void vox_grad_kernel(const float *__restrict__
 
 struct VoxPlan {
   bool fast;
-  IndexLds lds;
-  size_t off_sorted, off_uinfo, off_ucount, off_vslot, off_vmean, off_vox, total;
+  int S, CS, SV, n_words, arena_words, NP;
+  size_t lds;
+  size_t off_vox, total;
 };
 
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -435,54 +400,45 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static VoxPlan make_plan(int B, int C, int N, int r) {
   VoxPlan p;
   const long r3 = (long)r * r * r;
-  p.lds = index_lds(N, r3 < (1L << 20) ? r3 : 0);
-  p.fast = r3 <= (1L << 17) && (r3 % 4 == 0) && N <= MAXP * VT && N < 16384 && N >= 1 &&
-           p.lds.bytes <= (size_t)LDS_LIMIT;
+  // slabs per cloud: enough workgroups to touch every CU, slabs of >= 512 voxels (int4 groups)
+  int S = 1;
+  while (S < 16 && (long)B * S < 256 && r3 / (S * 2) >= 512 && (r3 % (S * 2 * 4)) == 0) S *= 2;
+  p.S = S;
+  // ... and, for small grids, ranges of channels (each workgroup redoes the cheap index phase)
+  int CS = 1;
+  while ((long)B * S * CS < 256 && C / (CS * 2) >= 8) CS *= 2;
+  p.CS = CS;
+  p.SV = (int)(r3 / S);
+  p.n_words = align4i(N);
+  p.NP = N <= VT ? 1 : N <= 2 * VT ? 2 : N <= 4 * VT ? 4 : 8;
+  const size_t svp = (((size_t)p.SV + (p.SV >> 5) + 3) & ~(size_t)3) + 4;
+  const size_t fixed = (svp + (size_t)p.n_words + 64 + 32) * 4;
+  // arena: phase A needs hist + tmp; afterwards (points + occupied voxels of the slab) floats per
+  // channel, for as many channels as fit
+  const size_t need_a = (svp + (size_t)p.n_words) * 4;
+  const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
+  size_t want = ((size_t)N + nocc) * (C > 0 ? C : 1) * 4;
+  if (want < need_a) want = need_a;
+  const size_t avail = fixed < (size_t)LDS_LIMIT ? (size_t)LDS_LIMIT - fixed : 0;
+  const size_t arena = want < avail ? want : avail;
+  p.arena_words = (int)(arena / 4);
+  p.lds = fixed + (size_t)p.arena_words * 4;
+  p.fast = r3 <= (1L << 17) && (r3 % 4 == 0) && (p.SV % 4 == 0) && N <= MAXP * VT && N >= 1 &&
+           arena >= need_a && (size_t)p.arena_words >= (size_t)N + nocc;
   size_t o = 0;
-  p.off_sorted = o; o += up256((size_t)B * N * 4);
-  p.off_uinfo = o;  o += up256((size_t)B * N * 4);
-  p.off_ucount = o; o += up256((size_t)B * 4);
-  p.off_vslot = o;  o += up256((size_t)B * r3 * 4);
-  p.off_vmean = o;  o += up256((size_t)B * (C > 0 ? C : 1) * N * 4);
-  p.off_vox = o;    o += up256((size_t)B * 3 * N * 4); // int coords (fallback P1)
+  p.off_vox = o; o += up256((size_t)B * 3 * N * 4); // int coords (fallback P1)
   p.total = o;
   return p;
 }
 
-template <bool FUSE_P1>
-static int set_index_lds(size_t bytes) {
-  static size_t configured = 0;
-  if (bytes > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&vox_index_kernel<FUSE_P1>),
+template <typename K>
+static int set_dyn_lds(K kernel, size_t bytes, size_t *configured) {
+  if (bytes > *configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    configured = bytes;
+    *configured = bytes;
   }
-  return 0;
-}
-
-static int launch_mean_dense(const float *feat, const int32_t *sorted, const int32_t *uinfo,
-                             const int32_t *ucount, const int32_t *vslot, float *vmean, int B, int C,
-                             int N, int r3, float *out, hipStream_t st) {
-  {
-    int ct = (int)((32 * 1024) / ((size_t)N * 4)); // rows per workgroup: <= 32 KiB of LDS (+ 2 index rows)
-    if (ct < 1) ct = 1;                           // N <= 8192 on this path -> one row is <= 32 KiB
-    if (ct > 8) ct = 8;
-    while (ct > 1 && (long)B * lion_cdiv(C, ct) < 512) ct >>= 1;
-    vox_mean_kernel<<<dim3(lion_cdiv(C, ct), B), 256, ((size_t)ct + 2) * N * 4, st>>>(
-        feat, sorted, uinfo, ucount, C, N, ct, vmean);
-    LION_LAUNCH_CHECK();
-  }
-  const int vt = lion_cdiv(r3, 512);
-  int ct = 16;
-  while (ct > 4 && (long)B * vt * lion_cdiv(C, ct) < 2048) ct >>= 1;
-  dim3 grid(vt, lion_cdiv(C, ct), B);
-  switch (ct) {
-  case 16: vox_dense_kernel<16><<<grid, 128, 0, st>>>(vslot, vmean, C, N, r3, out); break;
-  case 8:  vox_dense_kernel<8><<<grid, 128, 0, st>>>(vslot, vmean, C, N, r3, out); break;
-  default: vox_dense_kernel<4><<<grid, 128, 0, st>>>(vslot, vmean, C, N, r3, out); break;
-  }
-  LION_LAUNCH_CHECK();
   return 0;
 }
 
@@ -499,28 +455,30 @@ static int voxelize_impl(const float *feat, const int32_t *coords_i, const float
   if (!ws || ws_bytes < p.total) return LION_EWORKSPACE;
   const int r3 = r * r * r;
   char *w = static_cast<char *>(ws);
-  int32_t *sorted = reinterpret_cast<int32_t *>(w + p.off_sorted);
-  int32_t *uinfo = reinterpret_cast<int32_t *>(w + p.off_uinfo);
-  int32_t *ucount = reinterpret_cast<int32_t *>(w + p.off_ucount);
-  int32_t *vslot = reinterpret_cast<int32_t *>(w + p.off_vslot);
-  float *vmean = reinterpret_cast<float *>(w + p.off_vmean);
-  if (p.fast) {
-    if (coords_f) {
-      int e = set_index_lds<true>(p.lds.bytes);
-      if (e) return e;
-      vox_index_kernel<true><<<B, VT, p.lds.bytes, st>>>(nullptr, coords_f, N, r, normalize, eps,
-                                                         norm_coords, ind, cnt, vslot, sorted, uinfo,
-                                                         ucount, p.lds.hist_words, p.lds.n_words);
-    } else {
-      int e = set_index_lds<false>(p.lds.bytes);
-      if (e) return e;
-      vox_index_kernel<false><<<B, VT, p.lds.bytes, st>>>(coords_i, nullptr, N, r, 0, 0.f, nullptr,
-                                                          ind, cnt, vslot, sorted, uinfo, ucount,
-                                                          p.lds.hist_words, p.lds.n_words);
-    }
+  const bool aligned = (((uintptr_t)out | (uintptr_t)cnt) & 15) == 0;
+  if (p.fast && aligned) {
+    const int grid = ((B + 7) / 8) * 8 * p.S * p.CS;
+    const int ch_cap = 16; // channel chunk: the next chunk's row loads overlap the previous chunk's store drain
+#define LION_VOX_LAUNCH(P1, NPV)                                                                       \
+  {                                                                                                    \
+    static size_t cfg = 0;                                                                             \
+    int e = set_dyn_lds(&vox_fused_kernel<P1, NPV>, p.lds, &cfg);                                      \
+    if (e) return e;                                                                                   \
+    vox_fused_kernel<P1, NPV><<<grid, VT, p.lds, st>>>(feat, coords_i, coords_f, B, C, N, r, p.S, p.CS, p.SV, \
+                                                       p.n_words, p.arena_words, ch_cap, normalize, eps, out, \
+                                                       norm_coords, ind, cnt);                         \
+  }
+#define LION_VOX_NP(P1)                                                                                \
+  switch (p.NP) {                                                                                      \
+  case 1: LION_VOX_LAUNCH(P1, 1) break;                                                                \
+  case 2: LION_VOX_LAUNCH(P1, 2) break;                                                                \
+  case 4: LION_VOX_LAUNCH(P1, 4) break;                                                                \
+  default: LION_VOX_LAUNCH(P1, 8) break;                                                               \
+  }
+    if (coords_f) { LION_VOX_NP(true) } else { LION_VOX_NP(false) }
+#undef LION_VOX_NP
+#undef LION_VOX_LAUNCH
     LION_LAUNCH_CHECK();
-    if (feat)
-      return launch_mean_dense(feat, sorted, uinfo, ucount, vslot, vmean, B, C, N, r3, out, st);
     return 0;
   }
   // fallback
