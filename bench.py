@@ -218,7 +218,7 @@ def main():
             ft = torch.randn(B, C, N, device=dev)
             tv = ev_time(lambda: bk.voxelize_points_forward(ft, co, r, True, 0.0), 20)
             vbytes = 4.0 * B * (3 * N + C * N + C * r ** 3 + N + r ** 3) + 4.0 * B * 3 * N
-            roofv = {"kernel": "voxelize_points (P1+K1+K2) C=64 N=2048 r=32: vox_index + vox_mean + vox_dense",
+            roofv = {"kernel": "voxelize_points (P1+K1+K2) C=64 N=2048 r=32: vox_fused_kernel",
                      "bound": "hbm", "achieved": vbytes / tv / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": vbytes / tv / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_call": tv * 1e6,
                      "algorithmic_bytes": vbytes}

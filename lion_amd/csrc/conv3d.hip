@@ -51,12 +51,14 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
   constexpr int WV4 = KC * 27 * COT / 4;                 // float4 of weights per chunk
   constexpr int NWV = (WV4 + TM - 1) / TM;               // staged weight float4 per thread
   constexpr int CB = COT / 32;                           // 32-channel MFMA row blocks
-  __shared__ float sx[KC * HALO];
-  __shared__ __attribute__((aligned(16))) float sw[KC * 27 * COT];
-  __shared__ float spa[PRO ? 256 : 1], spb[PRO ? 256 : 1];              // prologue scalars, Cin <= 256
-  __shared__ float sred[STATS ? (TD * TH * TW / 64) * COT * 2 : 1];     // per-wave channel sums
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int SWS = ((KC * 27 * COT + 255) / 256) * 256 + 256; // floats per weight buffer (+1 KiB: DMA lanes past the slice)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sx = smem;                       // [KC][HALO]       input tile of the current chunk
+  float *sw = sx + ((KC * HALO + 3) & ~3); // [2][SWS]         weight slices, double buffered (LDS-DMA)
+  float *sbias = sw + 2 * SWS;            // [COT]
+  float *spa = sbias + COT, *spb = spa + 256; // prologue scalars, Cin <= 256
+  float *sred = spb + 256;                // [waves][COT][2]  per-wave channel sums (STATS)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, co0 = blockIdx.y * COT;
   const int ntw = r / TW, nth = r / TH;
   const int tw_i = blockIdx.x % ntw, th_i = (blockIdx.x / ntw) % nth, td_i = blockIdx.x / (ntw * nth);
@@ -66,10 +68,12 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
   if (PRO) {
     for (int c = tid; c < Cin; c += TM) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
   }
+  for (int c = tid; c < COT; c += TM) sbias[c] = bias ? bias[co0 + c] : 0.f;
   // spatial offsets of the halo positions this thread stages (the same for every input channel:
   // slot (c, j) is position p = tid + j*TM of channel c, so the channel -- and with it the prologue
   // scalars -- is uniform per slot and needs no per-element lookup).  Out-of-range positions (zero
-  // padding) load address 0 and are zeroed by a select: no branch around any load.
+  // padding) carry an offset past the buffer's num_records, for which buffer loads return 0: no
+  // branch around any load, no select.
   int goff[NJ];
   bool gok[NJ];
 #pragma unroll
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
     const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
     const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
     gok[j] = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
-    goff[j] = gok[j] ? (gd * r + gh) * r + gw : 0;
+    goff[j] = gok[j] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00; // out of range: the buffer load returns 0
   }
   // LDS offsets of this lane's B operands (input): voxel (d,h,w) of each of the wave's 2 column blocks
   int boff[2];
@@ -98,26 +102,37 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[cb][vb][i] = 0.f;
 
-  const float *xb = x + (size_t)b * Cin * r3;
+  // Input: raw buffer loads -- one VGPR (the halo offset, shared by all channels) + an SGPR channel
+  // offset per load instead of a 64-bit address pair each (the flat-address version of this kernel
+  // spilled its staging registers to scratch and serialised every load behind a vmcnt(0)).
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
   float rx[KC][NJ];
-  float4 rw[NWV];
+  // Weights: LDS-DMA (global_load_lds_dwordx4) straight into the other weight buffer: no staging
+  // registers, no ds_write pass.  Row (ci, tap) of the packed [Cin][27][Cout] tensor holds COT
+  // contiguous floats of this workgroup's channel tile; float4 e of the slice lands at sw + 16 e.
+  typedef __attribute__((address_space(3))) float lds_float;
+  const uint32_t sw_lds = (uint32_t)(uintptr_t)(lds_float *)sw;
   auto load_chunk = [&](int q) {
-    const float *xc = xb + (size_t)q * KC * r3;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int e0 = wave * 64 + i * TM; // wave-uniform
+      if (e0 < WV4) {
+        const int e = min(e0 + lane, WV4 - 1);
+        const int row = e / (COT / 4), j4 = e - row * (COT / 4);
+        const float *g = wp + ((size_t)q * KC * 27 + row) * Cout + co0 + j4 * 4;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(sw_lds + (uint32_t)(((q & 1) * SWS + e0 * 4) * 4));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+      }
+    }
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) rx[c][j] = xc[(size_t)c * r3 + goff[j]];
-    // weight slice: rows (ci, tap) of the packed [Cin][27][Cout] tensor, COT contiguous floats each
-#pragma unroll
-    for (int i = 0; i < NWV; ++i) {
-      const int e = tid + i * TM;
-      if (e < WV4) {
-        const int row = e / (COT / 4), j4 = e - row * (COT / 4);
-        rw[i] = *reinterpret_cast<const float4 *>(wp + ((size_t)q * KC * 27 + row) * Cout + co0 + j4 * 4);
-      }
-    }
+      for (int j = 0; j < NJ; ++j)
+        rx[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, goff[j], (q * KC + c) * r3 * 4, 0));
   };
-
   const int nchunks = Cin / KC;
   load_chunk(0);
   for (int q = 0; q < nchunks; ++q) {
@@ -134,14 +149,10 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
           const float t = v * pa + pb;
           v = t * __frcp_rn(1.0f + __expf(-t)); // swish(t) = t * sigmoid(t), v_exp + v_rcp
         }
-        if (p < HALO) sx[c * HALO + p] = gok[j] ? v : 0.f; // zero padding stays zero
+        if (p < HALO) sx[c * HALO + p] = (!PRO || gok[j]) ? v : 0.f; // zero padding stays zero
       }
     }
-#pragma unroll
-    for (int i = 0; i < NWV; ++i) {
-      const int e = tid + i * TM;
-      if (e < WV4) *reinterpret_cast<float4 *>(sw + e * 4) = rw[i];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of the weight slice q has landed
     __syncthreads();
     if (q + 1 < nchunks) load_chunk(q + 1); // in flight during the MFMAs below
 
@@ -149,6 +160,7 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
     // are issued before the MFMAs of step s (the compiler otherwise places each ds_read right in front
     // of its consumer and stalls ~100 cycles on lgkmcnt(0) every 256 MFMA cycles: 70 % -> MFMA-bound).
     constexpr int NS = (KC / 2) * 27;
+    const float *swq = sw + (q & 1) * SWS;
     float av[2][CB], bv[2][2];
     auto lds_step = [&](int st, int buf) {
       const int cp = st / 27, tap = st % 27;
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
       const int toff = (kd * HH + kh) * HW + kw + cp * 2 * HALO;
       bv[buf][0] = sx[boff[0] + toff];
       bv[buf][1] = sx[boff[1] + toff];
-      const float *ap = sw + aoff + (cp * 2 * 27 + tap) * COT;
+      const float *ap = swq + aoff + (cp * 2 * 27 + tap) * COT;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) av[buf][cb] = ap[cb * 32];
     };
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        const float o = acc[cb][vb][i] + (bias ? bias[co0 + co] : 0.f);
+        const float o = acc[cb][vb][i] + sbias[co];
         acc[cb][vb][i] = o;
         yb[(size_t)co * r3 + gv] = o;
       }
@@ -276,10 +288,27 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
   const int tiles = (r / TD) * (r / TH) * (r / TW);
   const dim3 grid(tiles, Cout / COT, B);
   constexpr int NT = TD * TH * TW;
-  if (pa && stats) conv3d_k3_kernel<TD, TH, TW, COT, true, true><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
-  else if (pa) conv3d_k3_kernel<TD, TH, TW, COT, true, false><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
-  else if (stats) conv3d_k3_kernel<TD, TH, TW, COT, false, true><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
-  else conv3d_k3_kernel<TD, TH, TW, COT, false, false><<<grid, NT, 0, st>>>(x, wp, bias, y, Cin, Cout, r, pa, pb, stats);
+  constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
+  constexpr int SWS = ((KC * 27 * COT + 255) / 256) * 256 + 256;
+  constexpr size_t LDS = (size_t)(((KC * HALO + 3) & ~3) + 2 * SWS + COT + 512 + (NT / 64) * COT * 2) * 4;
+#define LION_CONV_GO(PRO_, ST_)                                                                           \
+  {                                                                                                       \
+    static bool cfg = false;                                                                              \
+    if (!cfg) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute(                                                                 \
+          reinterpret_cast<const void *>(&conv3d_k3_kernel<TD, TH, TW, COT, PRO_, ST_>),                  \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);                                          \
+      if (e != hipSuccess) return (int)e;                                                                 \
+      cfg = true;                                                                                         \
+    }                                                                                                     \
+    conv3d_k3_kernel<TD, TH, TW, COT, PRO_, ST_><<<grid, NT, LDS, st>>>(x, wp, bias, y, Cin, Cout, r, pa, \
+                                                                        pb, stats);                      \
+  }
+  if (pa && stats) LION_CONV_GO(true, true)
+  else if (pa) LION_CONV_GO(true, false)
+  else if (stats) LION_CONV_GO(false, true)
+  else LION_CONV_GO(false, false)
+#undef LION_CONV_GO
   LION_LAUNCH_CHECK();
   return 0;
 }
