@@ -156,7 +156,8 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
  * conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize without a single stand-alone pass over
  * the grid: the conv epilogue emits per-tile channel sums (stats f32[B,Cout,T,2], T =
  * lion_conv3d_stat_tiles(r)), lion_groupnorm_fold turns them into per-(batch, channel) scalars
- * A, Bs (GroupNorm(G) x adaptive affine fac/gbias, models/adagn.py:61-64) and the channel mean,
+ * A, Bs (GroupNorm(G) x adaptive affine fac/gbias, models/adagn.py:61-64; fac/gbias rows are ld_fg floats
+ * apart, so the two halves of the [B,2C] style projection are consumed in place) and the channel mean,
  * the next conv applies swish(x*A+Bs) while staging its input (pro_a/pro_b f32[B,Cin]), and
  * lion_trilinear_devoxelize_affine_forward interpolates scale*feat+shift (second AdaGN x SE gate). */
 int lion_conv3d_stat_tiles(int r);
@@ -164,8 +165,12 @@ int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *b
                                  int Cout, int r, const float *pro_a, const float *pro_b, float *y,
                                  float *stats, lionStream_t stream);
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
-                        const float *beta, const float *fac, const float *gbias, float eps, float *A,
-                        float *Bs, float *chmean, lionStream_t stream);
+                        const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
+                        float *A, float *Bs, float *chmean, lionStream_t stream);
+/* SE3d (pvcnn2_ada.py:27-41) on the folded scalars: A, Bs f32[B,C] are multiplied in place by
+ * sigmoid(W2 relu(W1 (A*chmean + Bs))), w1 f32[H,C], w2 f32[C,H] (C <= 1024, H <= 128). */
+int lion_se_gate(const float *chmean, const float *w1, const float *w2, int B, int C, int H, float *A,
+                 float *Bs, lionStream_t stream);
 int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *feat, const float *scale,
                                              const float *shift, int B, int C, int N, int r, float *out,
                                              lionStream_t stream);

@@ -44,7 +44,8 @@ SIGNATURES = {
     "lion_conv3d_k3_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_conv3d_stat_tiles": (_i, [_i]),
     "lion_conv3d_k3_fused_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "lion_se_gate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_trilinear_devoxelize_affine_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_row_stats": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_affine_swish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

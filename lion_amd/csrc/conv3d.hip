@@ -240,7 +240,7 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
 // per-channel mean of the conv output (SE3d needs the mean of the normalised grid, which is affine in it).
 __global__ void gn_fold_kernel(const float *__restrict__ stats, int C, int T, int G, float count,
                                const float *__restrict__ gamma, const float *__restrict__ beta,
-                               const float *__restrict__ fac, const float *__restrict__ gbias, float eps,
+                               const float *__restrict__ fac, const float *__restrict__ gbias, int ld_fg, float eps,
                                float *__restrict__ A, float *__restrict__ Bs, float *__restrict__ chmean) {
   // one workgroup per (batch, group); C/G channels per group
   __shared__ double gs[2];
@@ -265,7 +265,7 @@ __global__ void gn_fold_kernel(const float *__restrict__ stats, int C, int T, in
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const int c = g * cpg + tid;
-    const float f = fac[(size_t)b * C + c], gb = gbias[(size_t)b * C + c];
+    const float f = fac[(size_t)b * ld_fg + c], gb = gbias[(size_t)b * ld_fg + c];
     const float a0 = rstd * gamma[c];
     A[(size_t)b * C + c] = a0 * f;
     Bs[(size_t)b * C + c] = (beta[c] - (float)mean * a0) * f + gb;
@@ -373,12 +373,12 @@ int lion_conv3d_stat_tiles(int r) { return conv_tiles(r); }
 
 // stats f32[B,C,T,2] -> A, Bs, chmean f32[B,C]   (GroupNorm(G) folded with the AdaGN affine fac/gbias f32[B,C])
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
-                        const float *beta, const float *fac, const float *gbias, float eps, float *A,
-                        float *Bs, float *chmean, lionStream_t stream) {
+                        const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
+                        float *A, float *Bs, float *chmean, lionStream_t stream) {
   if (!stats || !gamma || !beta || !fac || !gbias || !A || !Bs || !chmean) return LION_EINVAL;
-  if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G != 0 || C / G > 64) return LION_EINVAL;
+  if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G != 0 || C / G > 64 || ld_fg < C) return LION_EINVAL;
   gn_fold_kernel<<<dim3(G, B), 64, 0, static_cast<hipStream_t>(stream)>>>(stats, C, T, G, (float)voxels, gamma,
-                                                                         beta, fac, gbias, eps, A, Bs, chmean);
+                                                                         beta, fac, gbias, ld_fg, eps, A, Bs, chmean);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -77,6 +77,37 @@ __global__ __launch_bounds__(256) void affine_swish_max_kernel(const float *__re
   y[(size_t)row * M + m] = best;
 }
 
+
+// SE3d gate folded into the AdaGN scalars (pvcnn2_ada.py:27-41 + :219-226): the mean over the grid of
+// AdaGN(y) is A*mean(y) + Bs per (batch, channel), so the gate needs no pass over the grid:
+//   h = relu(W1 (A*m + Bs)),  g = sigmoid(W2 h),  A <- A*g,  Bs <- Bs*g.
+// One workgroup per batch element (C <= 1024, hidden <= 128); 8 tiny launches (2 GEMMs, 6 elementwise)
+// become one.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ chmean,
+                                                      const float *__restrict__ w1,
+                                                      const float *__restrict__ w2, int C, int H,
+                                                      float *__restrict__ A, float *__restrict__ Bs) {
+  __shared__ float sm[1024], sh[128];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) sm[c] = A[(size_t)b * C + c] * chmean[(size_t)b * C + c] + Bs[(size_t)b * C + c];
+  __syncthreads();
+  for (int j = wave; j < H; j += 4) { // one wave per hidden unit: coalesced row of W1
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * C + c] * sm[c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) sh[j] = acc > 0.f ? acc : 0.f;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < H; ++j) acc += w2[(size_t)c * H + j] * sh[j];
+    const float g = 1.0f / (1.0f + expf(-acc));
+    A[(size_t)b * C + c] *= g;
+    Bs[(size_t)b * C + c] *= g;
+  }
+}
+
 } // namespace
 
 extern "C" {
@@ -103,6 +134,16 @@ int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int r
   if (!x || !A || !Bs || !y || rows <= 0 || M <= 0 || U <= 0) return LION_EINVAL;
   affine_swish_max_kernel<<<dim3(lion_cdiv(M, 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
       x, A, Bs, M, U, y);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// A, Bs f32[B,C] (in place) *= sigmoid(W2 relu(W1 (A*chmean + Bs))); w1 f32[H,C], w2 f32[C,H] (nn.Linear layouts)
+int lion_se_gate(const float *chmean, const float *w1, const float *w2, int B, int C, int H, float *A,
+                 float *Bs, lionStream_t stream) {
+  if (!chmean || !w1 || !w2 || !A || !Bs || B <= 0 || C <= 0 || H <= 0) return LION_EINVAL;
+  if (C > 1024 || H > 128) return LION_EUNSUPPORTED;
+  se_gate_kernel<<<B, 256, 0, static_cast<hipStream_t>(stream)>>>(chmean, w1, w2, C, H, A, Bs);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -6,6 +6,14 @@ __all__ = ["ball_query"]
 
 def ball_query(centers_coords, points_coords, radius, num_neighbors):
     """centers f32[B,3,M], points f32[B,3,N] -> neighbour indices int32[B,M,U]."""
+    from .. import geometry
+    hit = geometry.lookup_ball_query(centers_coords, points_coords, radius, num_neighbors)
+    if hit is not None:  # prefetched on the side stream (inference)
+        return hit
     centers_coords = centers_coords[:, :3].contiguous()
     points_coords = points_coords[:, :3].contiguous()
+    return _bk._backend.ball_query(centers_coords, points_coords, radius, num_neighbors)
+
+
+def _ball_query_compute(centers_coords, points_coords, radius, num_neighbors):
     return _bk._backend.ball_query(centers_coords, points_coords, radius, num_neighbors)

@@ -36,12 +36,22 @@ def furthest_point_sample(coords, num_samples, normals=None):
     (sampling.py:39-54: only gathered coordinates leave this function, never the indices)."""
     assert len(coords.shape) == 3 and coords.shape[1] == 3, \
         f'expect input as B,3,N; get: {coords.shape}'
+    if normals is None:
+        from .. import geometry
+        hit = geometry.lookup_fps(coords, num_samples)  # prefetched on the side stream (inference)
+        if hit is not None:
+            return hit
     coords = coords.contiguous()
     indices = _bk._backend.furthest_point_sampling(coords, num_samples)
     centers_coords = gather(coords, indices)
     if normals is not None:
         return centers_coords, gather(normals, indices)
     return centers_coords
+
+
+def _fps_compute(coords, num_samples):
+    indices = _bk._backend.furthest_point_sampling(coords, num_samples)
+    return _bk._backend.gather_features_forward(coords, indices)
 
 
 def logits_mask(coords, logits, num_points_per_object):

@@ -41,15 +41,31 @@ def groupnorm_fold(stats, gn: torch.nn.GroupNorm, fac, gbias, voxels):
     A = torch.empty((b, c), device=stats.device, dtype=torch.float32)
     Bs = torch.empty_like(A)
     cm = torch.empty_like(A)
-    # keep every temporary alive in a local until the launch is enqueued: a temporary created inside
-    # the argument list is freed before the next argument is evaluated and the caching allocator
-    # hands the same block to the next .contiguous() (fac would silently become gbias)
-    fac_c, gb_c = fac.contiguous(), gbias.contiguous()
+    # fac / gbias are normally the two halves of the [B, 2C] style projection: consume them in place
+    # (row stride ld) instead of materialising two contiguous copies per fold.  Every temporary is
+    # kept alive in a local until the launch is enqueued: a temporary created inside the argument
+    # list is freed before the next argument is evaluated and the caching allocator hands the same
+    # block to the next allocation (fac would silently become gbias).
+    if not (fac.stride(1) == 1 and gbias.stride(1) == 1 and fac.stride(0) == gbias.stride(0) and fac.stride(0) >= c):
+        fac, gbias = fac.contiguous(), gbias.contiguous()
+    fac_c, gb_c, ld = fac, gbias, int(fac.stride(0))
     _lib.check(_lib.load().lion_groupnorm_fold(
         _lib.ptr(stats), b, c, t, gn.num_groups, int(voxels), _lib.ptr(gn.weight.detach()),
-        _lib.ptr(gn.bias.detach()), _lib.ptr(fac_c), _lib.ptr(gb_c), float(gn.eps),
+        _lib.ptr(gn.bias.detach()), _lib.ptr(fac_c), _lib.ptr(gb_c), ld, float(gn.eps),
         _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(cm), _lib.stream_ptr(stats.device)), "groupnorm_fold")
     return A, Bs, cm
+
+
+def se_gate_(A, Bs, chmean, se):
+    """in place: (A, Bs) *= SE3d gate computed from the folded scalars (mean of AdaGN(y) = A*mean(y)+Bs)."""
+    w1, w2 = se.fc[0].weight.detach(), se.fc[2].weight.detach()
+    h, c = w1.shape
+    if c > 1024 or h > 128 or not (w1.is_contiguous() and w2.is_contiguous()):
+        gate = se.fc(A * chmean + Bs)
+        return A * gate, Bs * gate
+    _lib.check(_lib.load().lion_se_gate(_lib.ptr(chmean), _lib.ptr(w1), _lib.ptr(w2), A.shape[0], c, h,
+                                        _lib.ptr(A), _lib.ptr(Bs), _lib.stream_ptr(A.device)), "se_gate")
+    return A, Bs
 
 
 def devoxelize_affine(grid, coords, r, scale, shift):

@@ -1,0 +1,86 @@
+"""Geometry prefetch for the PointNet++ set-abstraction chain (inference).
+
+Furthest-point sampling and the ball queries of a PVCNN2 U-Net depend on the point COORDINATES only
+(reference models/pvcnn2_ada.py:354-372: ``furthest_point_sample(coords, num_centers)`` feeds the next
+stage's coords), never on the features, yet in the module order they sit behind the stage's voxel
+convolutions.  FPS is a latency-bound serial loop (1024 rounds on one workgroup per cloud, 32 CUs
+busy); run in line it costs ~1 ms of a 22 ms denoiser step with 7/8 of the chip idle.  ``prefetch``
+issues the whole chain -- FPS 2048->1024->256->64->16 and every stage's ball query -- on a side HIP
+stream at the start of the forward pass, where it overlaps the first PVConv's MFMA convolutions;
+``furthest_point_sample`` / ``ball_query`` then pick the results up (event wait, no recomputation).
+Inside a hipGraph capture the side stream becomes a parallel branch of the graph.
+The lookup is keyed by tensor identity; a miss simply computes in line, so results never change.
+"""
+import contextlib
+
+import torch
+
+_PLAN = None
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def _take(entry):
+    tensor, event = entry[-2], entry[-1]
+    cur = torch.cuda.current_stream(tensor.device)
+    cur.wait_event(event)
+    tensor.record_stream(cur)
+    return tensor
+
+
+def lookup_fps(coords, num_samples):
+    if _PLAN is None:
+        return None
+    hit = _PLAN["fps"].get((id(coords), int(num_samples)))
+    return None if hit is None else _take(hit)
+
+
+def lookup_ball_query(centers, points, radius, num_neighbors):
+    if _PLAN is None:
+        return None
+    hit = _PLAN["bq"].get((id(centers), id(points), float(radius), int(num_neighbors)))
+    return None if hit is None else _take(hit)
+
+
+@contextlib.contextmanager
+def prefetch(sa_modules, coords):
+    """sa_modules: the PointNetSAModule of each stage, in order; coords f32[B,3,N] (the tensor object
+    the first stage will receive)."""
+    global _PLAN
+    if (not sa_modules or not coords.is_cuda or torch.is_grad_enabled() or coords.dim() != 3
+            or coords.shape[1] != 3 or not coords.is_contiguous() or coords.dtype != torch.float32):
+        yield
+        return
+    from .functional.ball_query import _ball_query_compute
+    from .functional.sampling import _fps_compute
+    main = torch.cuda.current_stream(coords.device)
+    side = _side_stream(coords.device)
+    side.wait_stream(main)
+    plan = {"fps": {}, "bq": {}}
+    with torch.cuda.stream(side):
+        cur = coords
+        for m in sa_modules:
+            if getattr(m, "num_centers", None) is None:
+                break
+            centers = _fps_compute(cur, m.num_centers)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            plan["fps"][(id(cur), int(m.num_centers))] = (cur, centers, ev)  # `cur` kept alive: its id is the key
+            for g in m.groupers:
+                idx = _ball_query_compute(centers, cur, g.radius, g.num_neighbors)
+                ev2 = torch.cuda.Event()
+                ev2.record(side)
+                plan["bq"][(id(centers), id(cur), float(g.radius), int(g.num_neighbors))] = (centers, cur, idx, ev2)
+            cur = centers
+    prev, _PLAN = _PLAN, plan
+    try:
+        yield
+    finally:
+        _PLAN = prev
+        main.wait_stream(side)  # join (closes the branch inside a graph capture; harmless otherwise)

@@ -4,6 +4,11 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import contextlib
+
+from .. import geometry
+from . import pvcnn2_ada
+from .adagn import StylePlan
 from .pvcnn2_ada import (LinearAttention, SharedMLP, create_mlp_components,
                          create_pointnet2_fp_modules, create_pointnet2_sa_components)
 
@@ -109,24 +114,31 @@ class PVCNN2Unet(nn.Module):
             clip_feat = self.clip_forge_mapping(clip_feat)
             style = self.style_clip(torch.cat([style, clip_feat], dim=1).contiguous())
 
-        coords_list, in_features_list = [], []
-        for i, sa_blocks in enumerate(self.sa_layers):
-            in_features_list.append(features)
-            coords_list.append(coords)
-            if i > 0 and temb is not None:
-                features = torch.cat([features, temb], dim=1)
-            features, coords, temb, _ = sa_blocks((features, coords, temb, style))
+        if getattr(self, '_style_plan', None) is None:
+            self._style_plan = StylePlan(self)
+        sa_mods = [blk[-1] if isinstance(blk, nn.Sequential) else blk for blk in self.sa_layers]
+        geo = geometry.prefetch(sa_mods, coords) if pvcnn2_ada.FUSE_INFERENCE and not self.training \
+            else contextlib.nullcontext()
+        # one GEMM for every AdaGN projection; FPS / ball-query chain on a side stream (inference)
+        with self._style_plan.projected(style), geo:
+            coords_list, in_features_list = [], []
+            for i, sa_blocks in enumerate(self.sa_layers):
+                in_features_list.append(features)
+                coords_list.append(coords)
+                if i > 0 and temb is not None:
+                    features = torch.cat([features, temb], dim=1)
+                features, coords, temb, _ = sa_blocks((features, coords, temb, style))
 
-        in_features_list[0] = inputs[:, 3:, :].contiguous()
-        if self.global_att is not None:
-            features = self.global_att(features)
-        for fp_idx, fp_blocks in enumerate(self.fp_layers):
-            cf = torch.cat([features, temb], dim=1) if temb is not None else features
-            features, coords, temb, _ = fp_blocks(
-                (coords_list[-1 - fp_idx], coords, cf, in_features_list[-1 - fp_idx], temb, style))
+            in_features_list[0] = inputs[:, 3:, :].contiguous()
+            if self.global_att is not None:
+                features = self.global_att(features)
+            for fp_idx, fp_blocks in enumerate(self.fp_layers):
+                cf = torch.cat([features, temb], dim=1) if temb is not None else features
+                features, coords, temb, _ = fp_blocks(
+                    (coords_list[-1 - fp_idx], coords, cf, in_features_list[-1 - fp_idx], temb, style))
 
-        for layer in self.classifier:
-            features = layer(features, style) if isinstance(layer, SharedMLP) else layer(features)
+            for layer in self.classifier:
+                features = layer(features, style) if isinstance(layer, SharedMLP) else layer(features)
         return features
 
 

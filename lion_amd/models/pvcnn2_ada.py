@@ -219,8 +219,7 @@ class PVConv(nn.Module):
         f2, g2 = gn2.affine(style)
         a2, b2, m2 = fused_ops.groupnorm_fold(st2, gn2.norm, f2, g2, r ** 3)
         if se is not None:
-            gate = se.fc(a2 * m2 + b2)  # mean over the grid of AdaGN2(y2) is affine in mean(y2)
-            a2, b2 = a2 * gate, b2 * gate
+            a2, b2 = fused_ops.se_gate_(a2, b2, m2, se)  # mean over the grid of AdaGN2(y2) is affine in mean(y2)
         return fused_ops.devoxelize_affine(y2, voxel_coords, r, a2, b2)
 
     def forward(self, inputs):
