@@ -155,12 +155,12 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
 /* ---- P2+P3+P4 folded into C3 / K4 (inference): PVConv.forward voxel branch, pvcnn2_ada.py:211-226 ----
  * conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize without a single stand-alone pass over
  * the grid: the conv epilogue emits per-tile channel sums (stats f32[B,Cout,T,2], T =
- * lion_conv3d_stat_tiles(r)), lion_groupnorm_fold turns them into per-(batch, channel) scalars
+ * lion_conv3d_stat_tiles(r, Cout, B): the spatial tiling depends on the shape), lion_groupnorm_fold turns them into per-(batch, channel) scalars
  * A, Bs (GroupNorm(G) x adaptive affine fac/gbias, models/adagn.py:61-64; fac/gbias rows are ld_fg floats
  * apart, so the two halves of the [B,2C] style projection are consumed in place) and the channel mean,
  * the next conv applies swish(x*A+Bs) while staging its input (pro_a/pro_b f32[B,Cin]), and
  * lion_trilinear_devoxelize_affine_forward interpolates scale*feat+shift (second AdaGN x SE gate). */
-int lion_conv3d_stat_tiles(int r);
+int lion_conv3d_stat_tiles(int r, int Cout, int B);
 int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
                                  int Cout, int r, const float *pro_a, const float *pro_b, float *y,
                                  float *stats, lionStream_t stream);

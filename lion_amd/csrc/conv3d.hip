@@ -36,8 +36,8 @@ constexpr int KC = LION_CONV_KC;
 //        previous layer, pvcnn2_ada.py:212-218, applied on the fly; zero padding stays zero).
 // STATS: per (batch, output channel, spatial tile) sum and sum of squares of the output are written
 //        to stats[b][co][tile][2] (GroupNorm statistics of the NEXT AdaGN without another pass).
-template <int TD, int TH, int TW, int COT, bool PRO, bool STATS>
-__global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(const float *__restrict__ x,
+template <int TD, int TH, int TW, int COT, int VB, bool PRO, bool STATS>
+__global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const float *__restrict__ x,
                                                                 const float *__restrict__ wp,
                                                                 const float *__restrict__ bias,
                                                                 float *__restrict__ y, int Cin,
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
                                                                 const float *__restrict__ pro_a,
                                                                 const float *__restrict__ pro_b,
                                                                 float *__restrict__ stats) {
-  constexpr int TM = TD * TH * TW;
+  constexpr int TM = 256;                                // threads: 4 waves, each owning VB x 32 voxels
+  static_assert(TD * TH * TW == 4 * VB * 32, "tile voxels = 4 waves x VB column blocks x 32");
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
   constexpr int NJ = (HALO + TM - 1) / TM;               // staged input floats per thread and channel
   constexpr int WV4 = KC * 27 * COT / 4;                 // float4 of weights per chunk
@@ -85,20 +86,20 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
     goff[j] = gok[j] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00; // out of range: the buffer load returns 0
   }
   // LDS offsets of this lane's B operands (input): voxel (d,h,w) of each of the wave's 2 column blocks
-  int boff[2];
+  int boff[VB];
 #pragma unroll
-  for (int vb = 0; vb < 2; ++vb) {
-    const int v = wave * 64 + vb * 32 + (lane & 31);
+  for (int vb = 0; vb < VB; ++vb) {
+    const int v = (wave * VB + vb) * 32 + (lane & 31);
     const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
     boff[vb] = (lane >> 5) * HALO + (d * HH + h) * HW + w;
   }
   const int aoff = (lane >> 5) * 27 * COT + (lane & 31);
 
-  f32x16 acc[CB][2];
+  f32x16 acc[CB][VB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-    for (int vb = 0; vb < 2; ++vb)
+    for (int vb = 0; vb < VB; ++vb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[cb][vb][i] = 0.f;
 
@@ -161,13 +162,13 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
     // of its consumer and stalls ~100 cycles on lgkmcnt(0) every 256 MFMA cycles: 70 % -> MFMA-bound).
     constexpr int NS = (KC / 2) * 27;
     const float *swq = sw + (q & 1) * SWS;
-    float av[2][CB], bv[2][2];
+    float av[2][CB], bv[2][VB];
     auto lds_step = [&](int st, int buf) {
       const int cp = st / 27, tap = st % 27;
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       const int toff = (kd * HH + kh) * HW + kw + cp * 2 * HALO;
-      bv[buf][0] = sx[boff[0] + toff];
-      bv[buf][1] = sx[boff[1] + toff];
+#pragma unroll
+      for (int vb = 0; vb < VB; ++vb) bv[buf][vb] = sx[boff[vb] + toff];
       const float *ap = swq + aoff + (cp * 2 * 27 + tap) * COT;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) av[buf][cb] = ap[cb * 32];
@@ -178,10 +179,10 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
       if (st + 1 < NS) lds_step(st + 1, (st + 1) & 1);
       __builtin_amdgcn_sched_barrier(0); // keep the prefetch above this step's MFMAs
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][cb], bv[st & 1][0], acc[cb][0], 0, 0, 0);
-        acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][cb], bv[st & 1][1], acc[cb][1], 0, 0, 0);
-      }
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb)
+          acc[cb][vb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][cb], bv[st & 1][vb], acc[cb][vb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
   // voxel column l&31 -> 32 consecutive voxels per (register, half-wave).
   float *yb = y + ((size_t)b * Cout + co0) * r3;
 #pragma unroll
-  for (int vb = 0; vb < 2; ++vb) {
-    const int v = wave * 64 + vb * 32 + (lane & 31);
+  for (int vb = 0; vb < VB; ++vb) {
+    const int v = (wave * VB + vb) * 32 + (lane & 31);
     const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
     const int gv = ((d0 + d) * r + (h0 + h)) * r + (w0 + w);
 #pragma unroll
@@ -206,13 +207,14 @@ __global__ __launch_bounds__(TD *TH *TW, LION_CONV_WAVES) void conv3d_k3_kernel(
   }
   if (STATS) {
     // channel sums over this tile: columns (voxels) live in the 32 lanes of a half-wave
-    constexpr int NWAVE = TM / 64;
+    constexpr int NWAVE = 4;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float s1 = acc[cb][0][i] + acc[cb][1][i];
-        float s2 = acc[cb][0][i] * acc[cb][0][i] + acc[cb][1][i] * acc[cb][1][i];
+        float s1 = acc[cb][0][i], s2 = acc[cb][0][i] * acc[cb][0][i];
+#pragma unroll
+        for (int vb = 1; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
 #pragma unroll
         for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
         if ((lane & 31) == 0) {
@@ -282,12 +284,12 @@ __global__ void conv3d_pack_kernel(const float *__restrict__ w, int Cout, int Ci
   wp[i] = ci < Cin ? w[((size_t)co * Cin + ci) * 27 + t] : 0.f;
 }
 
-template <int TD, int TH, int TW, int COT>
+template <int TD, int TH, int TW, int COT, int VB>
 static int launch_conv_t(const float *x, const float *wp, const float *bias, float *y, int B, int Cin,
                          int Cout, int r, const float *pa, const float *pb, float *stats, hipStream_t st) {
   const int tiles = (r / TD) * (r / TH) * (r / TW);
   const dim3 grid(tiles, Cout / COT, B);
-  constexpr int NT = TD * TH * TW;
+  constexpr int NT = 256;
   constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
   constexpr int SWS = ((KC * 27 * COT + 255) / 256) * 256 + 256;
   constexpr size_t LDS = (size_t)(((KC * HALO + 3) & ~3) + 2 * SWS + COT + 512 + (NT / 64) * COT * 2) * 4;
@@ -296,13 +298,13 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
     static bool cfg = false;                                                                              \
     if (!cfg) {                                                                                           \
       hipError_t e = hipFuncSetAttribute(                                                                 \
-          reinterpret_cast<const void *>(&conv3d_k3_kernel<TD, TH, TW, COT, PRO_, ST_>),                  \
+          reinterpret_cast<const void *>(&conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_>),              \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);                                          \
       if (e != hipSuccess) return (int)e;                                                                 \
       cfg = true;                                                                                         \
     }                                                                                                     \
-    conv3d_k3_kernel<TD, TH, TW, COT, PRO_, ST_><<<grid, NT, LDS, st>>>(x, wp, bias, y, Cin, Cout, r, pa, \
-                                                                        pb, stats);                      \
+    conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_><<<grid, NT, LDS, st>>>(x, wp, bias, y, Cin, Cout, r, \
+                                                                            pa, pb, stats);              \
   }
   if (pa && stats) LION_CONV_GO(true, true)
   else if (pa) LION_CONV_GO(true, false)
@@ -313,19 +315,35 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
   return 0;
 }
 
-template <int TD, int TH, int TW>
-static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int B, int Cin,
-                       int Cout, int r, const float *pa, const float *pb, float *stats, hipStream_t st) {
-  const int tiles = (r / TD) * (r / TH) * (r / TW);
-  // small grids (r = 8): prefer 32-channel tiles so that >= 2 workgroups per CU overlap each other's staging
-  if (Cout % 64 == 0 && (long)tiles * (Cout / 64) * B >= 512)
-    return launch_conv_t<TD, TH, TW, 64>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, stats, st);
-  if (Cout % 32 == 0)
-    return launch_conv_t<TD, TH, TW, 32>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, stats, st);
-  return LION_EUNSUPPORTED;
+// Tile choice per (r, Cout): spatial tile = 4 waves x VB x 32 voxels, COT output channels per workgroup.
+//   Cout % 64 == 0, enough workgroups : VB 2 x COT 64  (2x2 MFMA tiles per wave, 4 LDS reads per 4 MFMAs)
+//   Cout % 32 == 0 at r >= 16         : VB 4 x COT 32  (4x1 tiles: same MFMAs per step, less halo per voxel)
+//   small grids (r = 8)               : VB 1 x COT 32  (twice the waves: 2 per SIMD instead of 1, so that one
+//                                                        wave's staging / barriers hide under the other's MFMAs)
+struct ConvPlan { int vb, cot, tiles; };
+static ConvPlan conv_plan(int r, int Cout, int B) {
+  const int r3 = r * r * r;
+  if (Cout % 64 == 0 && (long)(r3 / 256) * (Cout / 64) * B >= 512) return {2, 64, r3 / 256};
+  if (Cout % 32 == 0 && r >= 16) return {4, 32, r3 / 512};
+  if (Cout % 32 == 0) return {1, 32, r3 / 128};
+  return {0, 0, 0};
 }
 
-static int conv_tiles(int r) { return r == 32 ? 128 : r == 16 ? 16 : r == 8 ? 2 : 0; }
+static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int B, int Cin, int Cout,
+                       int r, const float *pa, const float *pb, float *stats, hipStream_t st) {
+  const ConvPlan p = conv_plan(r, Cout, B);
+#define LION_CONV_TILE(R_, VB_, COT_, TD_, TH_, TW_)                                                       \
+  if (r == R_ && p.vb == VB_ && p.cot == COT_)                                                             \
+    return launch_conv_t<TD_, TH_, TW_, COT_, VB_>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, stats, st);
+  LION_CONV_TILE(32, 2, 64, 2, 4, 32)
+  LION_CONV_TILE(32, 4, 32, 4, 4, 32)
+  LION_CONV_TILE(16, 2, 64, 4, 4, 16)
+  LION_CONV_TILE(16, 4, 32, 8, 4, 16)
+  LION_CONV_TILE(8, 2, 64, 4, 8, 8)
+  LION_CONV_TILE(8, 1, 32, 2, 8, 8)
+#undef LION_CONV_TILE
+  return LION_EUNSUPPORTED;
+}
 
 } // namespace
 
@@ -348,7 +366,7 @@ int lion_conv3d_pack_weights(const float *w, int Cout, int Cin, float *wp, lionS
 // x f32[B,Cin,r,r,r] with Cin % 4 == 0, wp from lion_conv3d_pack_weights, bias f32[Cout] or NULL
 // -> y f32[B,Cout,r,r,r].   r in {8, 16, 32}.
 // pro_a / pro_b f32[B,Cin] (both or neither): input is swish(x*a+b) (fused AdaGN + Swish prologue).
-// stats f32[B,Cout,lion_conv3d_stat_tiles(r),2] or NULL: per-tile channel sums of the output.
+// stats f32[B,Cout,lion_conv3d_stat_tiles(r,Cout,B),2] or NULL: per-tile channel sums of the output.
 int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
                                  int Cout, int r, const float *pro_a, const float *pro_b, float *y,
                                  float *stats, lionStream_t stream) {
@@ -356,12 +374,8 @@ int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *b
   if ((pro_a == nullptr) != (pro_b == nullptr)) return LION_EINVAL;
   if (Cin % KC != 0 || (pro_a && Cin > 256)) return LION_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (r) {
-  case 32: return launch_conv<2, 4, 32>(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, st);
-  case 16: return launch_conv<4, 4, 16>(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, st);
-  case 8:  return launch_conv<4, 8, 8>(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, st);
-  default: return LION_EUNSUPPORTED;
-  }
+  if (r != 8 && r != 16 && r != 32) return LION_EUNSUPPORTED;
+  return launch_conv(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, st);
 }
 
 int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
@@ -369,7 +383,10 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
   return lion_conv3d_k3_fused_forward(x, wp, bias, B, Cin, Cout, r, nullptr, nullptr, y, nullptr, stream);
 }
 
-int lion_conv3d_stat_tiles(int r) { return conv_tiles(r); }
+int lion_conv3d_stat_tiles(int r, int Cout, int B) {
+  if (r != 8 && r != 16 && r != 32) return 0;
+  return conv_plan(r, Cout, B).tiles;
+}
 
 // stats f32[B,C,T,2] -> A, Bs, chmean f32[B,C]   (GroupNorm(G) folded with the AdaGN affine fac/gbias f32[B,C])
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,

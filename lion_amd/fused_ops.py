@@ -23,7 +23,7 @@ def conv3d_fused(x, conv, pro=None, want_stats=True):
     y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
     stats = None
     if want_stats:
-        stats = torch.empty((b, cout, lib.lion_conv3d_stat_tiles(r), 2), device=x.device, dtype=torch.float32)
+        stats = torch.empty((b, cout, lib.lion_conv3d_stat_tiles(r, cout, b), 2), device=x.device, dtype=torch.float32)
     pa = pb = None
     if pro is not None:
         pa, pb = pro[0].contiguous(), pro[1].contiguous()
