@@ -188,3 +188,41 @@ def test_style_encoder_forward_backward_vs_reference():
     for k in z.files:
         if k.startswith("g_"):
             close(P[k[2:]].grad, z[k], 1e-4)
+
+
+def test_geometry_prefetch_and_style_plan_do_not_change_the_local_prior():
+    """side-stream FPS / ball-query prefetch (lion_amd/geometry.py) is bit-identical to the in-line
+    evaluation; batching the AdaGN projections into one GEMM (adagn.StylePlan) stays within 1e-5."""
+    import contextlib
+    from lion_amd import geometry
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models import adagn
+    from lion_amd.models.lion import LION
+    torch.manual_seed(11)
+    lion = LION(released_prior_cfg())
+    prior = lion.priors[1].eval()
+    sh = lion.vae.latent_shape()
+    x = torch.randn([2] + sh[1], device="cuda")
+    style = lion.vae.global2style(torch.randn([2] + sh[0], device="cuda"))
+    t = torch.full((2,), 321.0, device="cuda")
+
+    def run():
+        with torch.no_grad():
+            return prior(x=x, t=t, condition_input=style, clip_feat=None).float()
+
+    full = run()
+    real_prefetch = geometry.prefetch
+    geometry.prefetch = lambda mods, coords: contextlib.nullcontext()
+    try:
+        no_prefetch = run()
+    finally:
+        geometry.prefetch = real_prefetch
+    assert torch.equal(full, no_prefetch)
+    real_projected = adagn.StylePlan.projected
+    adagn.StylePlan.projected = lambda self, style: contextlib.nullcontext()
+    try:
+        per_layer = run()
+    finally:
+        adagn.StylePlan.projected = real_projected
+    err = (full - per_layer).abs().max().item() / per_layer.abs().max().item()
+    assert err < 1e-5, err
