@@ -108,7 +108,7 @@ def cpu_baseline(cfg, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=1000, help="DDIM steps timed; 1000 = the full real chain (~20 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="shapes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
