@@ -179,6 +179,18 @@ int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *f
  * after the 1x1 convolution: row sums -> lion_groupnorm_fold (T = 1) -> y = swish(x*A+Bs), optionally
  * reduced with max over the U neighbours of each centre.  x is [rows = B*C, L] (L = N or M*U). */
 int lion_row_stats(const float *x, int rows, int L, float *stats, lionStream_t stream);
+/* G1 itself: the 1x1 Conv1d / Conv2d of SharedMLP (pvcnn2_ada.py:120) as an fp32-MFMA GEMM over
+ * x f32[B,Cin,L] (L = N or M*U) with the previous layer's AdaGN+Swish applied to the operand in flight
+ * (pro_a/pro_b f32[B,Cin] or both NULL) and this layer's GroupNorm sums in the epilogue
+ * (stats f32[B,Cout,lion_pwconv_stat_tiles(Cout,L),2] or NULL; fold with lion_groupnorm_fold).
+ * w f32[Cout,Cin] -> wp f32[ceil2(Cin),Cout] once per weight (lion_pwconv_packed_floats floats).
+ * Cout in {32,64,128,256} and a weight slice that fits LDS; otherwise LION_EUNSUPPORTED (callers keep the
+ * library GEMM, which also serves the short, latency-bound activations better). */
+size_t lion_pwconv_packed_floats(int Cout, int Cin);
+int lion_pwconv_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream);
+int lion_pwconv_stat_tiles(int Cout, int L);
+int lion_pwconv_forward(const float *x, const float *wp, const float *bias, int B, int Cin, int Cout, int L,
+                        const float *pro_a, const float *pro_b, float *y, float *stats, lionStream_t stream);
 int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows, int L, float *y,
                       lionStream_t stream);
 int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int rows, int M, int U,

@@ -88,6 +88,100 @@ def fusable(conv1, conv2, r, x):
             and conv2.in_channels % 4 == 0 and conv2.in_channels <= 256)
 
 
+_PW_CACHE = {}
+
+
+def pw_packed_weight(weight):
+    """[Cout,Cin,1(,1)] -> k-major [ceil2(Cin),Cout]; cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _PW_CACHE.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    cout, cin = weight.shape[:2]
+    lib = _lib.load()
+    wp = torch.empty((lib.lion_pwconv_packed_floats(cout, cin),), device=weight.device, dtype=torch.float32)
+    w_c = weight.detach().reshape(cout, cin).contiguous()
+    _lib.check(lib.lion_pwconv_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
+                                            _lib.stream_ptr(weight.device)), "pwconv_pack_weights")
+    _PW_CACHE[id(weight)] = (key, wp)
+    return wp
+
+
+def pw_supported(conv, x):
+    """large activations only (>= 4 M output elements, rows >= 1024 long): the short ones are latency
+    bound and stay on the library GEMM."""
+    cout, cin = conv.out_channels, conv.in_channels
+    L = x[0, 0].numel()
+    lds = (2 * ((cin + 1) // 2) * cout + 2 * cin + 8 * cout) * 4
+    return (cout in (32, 64, 128, 256) and lds <= 100 * 1024 and L >= 1024
+            and x.shape[0] * L * cout >= (1 << 22) and conv.groups == 1
+            and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
+            and all(p == 0 for p in conv.padding))
+
+
+def pwconv_fused(x, conv, pro=None):
+    """1x1 conv of a [B,Cin,*] activation on the MFMA kernel: y [B,Cout,*] and its GroupNorm tile sums
+    [B,Cout,T,2]; pro = (A, Bs) applies swish(x*A+Bs) (the previous layer's AdaGN + Swish) in flight."""
+    lib = _lib.load()
+    x = x.contiguous()
+    b, cin = x.shape[:2]
+    L = x[0, 0].numel()
+    cout = conv.out_channels
+    wp = pw_packed_weight(conv.weight)
+    y = torch.empty((b, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+    stats = torch.empty((b, cout, lib.lion_pwconv_stat_tiles(cout, L), 2), device=x.device, dtype=torch.float32)
+    pa = pb = None
+    if pro is not None:
+        pa, pb = pro[0].contiguous(), pro[1].contiguous()
+    bias = conv.bias.detach().contiguous() if conv.bias is not None else None
+    _lib.check(lib.lion_pwconv_forward(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), b, cin, cout, L,
+                                       _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats),
+                                       _lib.stream_ptr(x.device)), "pwconv_forward")
+    return y, stats
+
+
+def affine_swish(x, A, Bs, reduce_max=False):
+    """swish(x*A+Bs) per (batch, channel) row; reduce_max: max over the last (neighbour) dimension too."""
+    lib = _lib.load()
+    b, c = x.shape[:2]
+    st = _lib.stream_ptr(x.device)
+    if reduce_max:
+        m, u = x.shape[2], x.shape[3]
+        y = torch.empty((b, c, m), device=x.device, dtype=torch.float32)
+        _lib.check(lib.lion_affine_swish_max(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), b * c, m, u, _lib.ptr(y), st),
+                   "affine_swish_max")
+        return y
+    y = torch.empty_like(x)
+    _lib.check(lib.lion_affine_swish(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), b * c, x[0, 0].numel(), _lib.ptr(y), st),
+               "affine_swish")
+    return y
+
+
+def shared_mlp(x, convs, adagns, style, reduce_max=False):
+    """[1x1 conv -> AdaGN -> Swish] x n (inference).  Large activations: the conv runs on the MFMA kernel,
+    reads the RAW output of the previous conv and applies that layer's AdaGN + Swish in flight, and
+    emits its own GroupNorm sums -- one read and one write per layer instead of five passes.  Short
+    activations keep the library GEMM (+ one row-sum pass).  Only the last layer needs a stand-alone
+    apply pass (optionally with the max over the neighbourhood)."""
+    lib = _lib.load()
+    pro = None
+    for conv, gn in zip(convs, adagns):
+        if pw_supported(conv, x):
+            x, st = pwconv_fused(x, conv, pro)
+        else:
+            if pro is not None:
+                x = affine_swish(x, pro[0], pro[1])
+            x = conv(x).contiguous()
+            b, c = x.shape[:2]
+            st = torch.empty((b, c, 1, 2), device=x.device, dtype=torch.float32)
+            _lib.check(lib.lion_row_stats(_lib.ptr(x), b * c, x[0, 0].numel(), _lib.ptr(st),
+                                          _lib.stream_ptr(x.device)), "row_stats")
+        f, g = gn.affine(style)
+        A, Bs, _ = groupnorm_fold(st, gn.norm, f, g, x[0, 0].numel())
+        pro = (A, Bs)
+    return affine_swish(x, pro[0], pro[1], reduce_max)
+
+
 def adagn_swish(x, adagn, style, reduce_max=False):
     """swish(AdaGN(x)) for a 1-D [B,C,N] / 2-D [B,C,M,U] activation in 3 launches (row sums, fold,
     apply); reduce_max=True additionally takes the max over the last (neighbour) dimension."""

@@ -130,10 +130,8 @@ class SharedMLP(nn.Module):
         reference :375-377), fused into the last layer's activation pass on the inference path."""
         if self._fusable(x):
             n = len(self.layers) // 3
-            for i in range(n):  # (1x1 conv, AdaGN, Swish) triples: conv on the library GEMM, the rest fused
-                x = self.layers[3 * i](x)
-                x = fused_ops.adagn_swish(x, self.layers[3 * i + 1], style, reduce_max and i == n - 1)
-            return x
+            convs, gns = [self.layers[3 * i] for i in range(n)], [self.layers[3 * i + 1] for i in range(n)]
+            return fused_ops.shared_mlp(x, convs, gns, style, reduce_max)
         for layer in self.layers:
             x = layer(x, style) if isinstance(layer, AdaGN) else layer(x)
         return x.max(dim=-1).values if reduce_max else x
