@@ -10,7 +10,7 @@
 
 namespace {
 
-__device__ __forceinline__ float swishf(float t) { return t / (1.0f + __expf(-t)); }
+__device__ __forceinline__ float swishf(float t) { return t * __frcp_rn(1.0f + __expf(-t)); } // v_exp + v_rcp, as in the conv prologue
 
 __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int L,
                                                         float *__restrict__ stats) {
@@ -77,6 +77,36 @@ __global__ __launch_bounds__(256) void affine_swish_max_kernel(const float *__re
   y[(size_t)row * M + m] = best;
 }
 
+// U/4 lanes per centre (U in {8,16,32,64,...,256} -> 2..64 lanes): a wave reads 1 KiB of CONTIGUOUS
+// floats per instruction (the one-lane-per-centre layout above makes every lane walk its own 128-byte
+// line), the max is finished with xor-shuffles inside the lane group.
+template <int LPM>
+__global__ __launch_bounds__(256) void affine_swish_max_coop_kernel(const float *__restrict__ x,
+                                                                    const float *__restrict__ A,
+                                                                    const float *__restrict__ Bs, int M,
+                                                                    float *__restrict__ y) {
+  constexpr int MPW = 64 / LPM; // centres per wave instruction
+  constexpr int IT = 8;         // wave instructions per thread -> 8 KiB in flight per wave
+  const int row = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float a = A[row], b = Bs[row];
+  const int m0 = (blockIdx.x * 4 + wave) * MPW * IT;
+  const float4 *p = reinterpret_cast<const float4 *>(x + (size_t)row * M * (LPM * 4));
+  float4 v[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int m = min(m0 + i * MPW + lane / LPM, M - 1);
+    v[i] = p[(size_t)m * LPM + (lane % LPM)];
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    float best = fmaxf(fmaxf(swishf(v[i].x * a + b), swishf(v[i].y * a + b)),
+                       fmaxf(swishf(v[i].z * a + b), swishf(v[i].w * a + b)));
+#pragma unroll
+    for (int s = 1; s < LPM; s <<= 1) best = fmaxf(best, __shfl_xor(best, s, 64));
+    const int m = m0 + i * MPW + lane / LPM;
+    if ((lane % LPM) == 0 && m < M) y[(size_t)row * M + m] = best;
+  }
+}
 
 // SE3d gate folded into the AdaGN scalars (pvcnn2_ada.py:27-41 + :219-226): the mean over the grid of
 // AdaGN(y) is A*mean(y) + Bs per (batch, channel), so the gate needs no pass over the grid:
@@ -132,8 +162,15 @@ int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows,
 int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int rows, int M, int U,
                           float *y, lionStream_t stream) {
   if (!x || !A || !Bs || !y || rows <= 0 || M <= 0 || U <= 0) return LION_EINVAL;
-  affine_swish_max_kernel<<<dim3(lion_cdiv(M, 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      x, A, Bs, M, U, y);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool al = (((uintptr_t)x) & 15) == 0;
+#define LION_ASM_COOP(LPM_)                                                                                  \
+  affine_swish_max_coop_kernel<LPM_><<<dim3(lion_cdiv(M, 4 * (64 / LPM_) * 8), rows), 256, 0, st>>>(x, A, Bs, M, y)
+  if (al && U == 32) LION_ASM_COOP(8);
+  else if (al && U == 16) LION_ASM_COOP(4);
+  else if (al && U == 64) LION_ASM_COOP(16);
+  else affine_swish_max_kernel<<<dim3(lion_cdiv(M, 256), rows), 256, 0, st>>>(x, A, Bs, M, U, y);
+#undef LION_ASM_COOP
   LION_LAUNCH_CHECK();
   return 0;
 }
