@@ -316,13 +316,16 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
 }
 
 // Tile choice per (r, Cout): spatial tile = 4 waves x VB x 32 voxels, COT output channels per workgroup.
-//   Cout % 64 == 0, enough workgroups : VB 2 x COT 64  (2x2 MFMA tiles per wave, 4 LDS reads per 4 MFMAs)
+//   Cout % 64 == 0, >= 512 workgroups : VB 4 x COT 64  (4x2 MFMA tiles per wave: 6 LDS reads per 8 MFMAs, 2.4x halo
+//                                                        instead of 3.2x -> less staging / prologue per MFMA)
+//   Cout % 64 == 0 otherwise          : VB 2 x COT 64  (2x2 tiles, 4 LDS reads per 4 MFMAs)
 //   Cout % 32 == 0 at r >= 16         : VB 4 x COT 32  (4x1 tiles: same MFMAs per step, less halo per voxel)
 //   small grids (r = 8)               : VB 1 x COT 32  (twice the waves: 2 per SIMD instead of 1, so that one
 //                                                        wave's staging / barriers hide under the other's MFMAs)
 struct ConvPlan { int vb, cot, tiles; };
 static ConvPlan conv_plan(int r, int Cout, int B) {
   const int r3 = r * r * r;
+  if (Cout % 64 == 0 && r >= 16 && (long)(r3 / 512) * (Cout / 64) * B >= 512) return {4, 64, r3 / 512};
   if (Cout % 64 == 0 && (long)(r3 / 256) * (Cout / 64) * B >= 512) return {2, 64, r3 / 256};
   if (Cout % 32 == 0 && r >= 16) return {4, 32, r3 / 512};
   if (Cout % 32 == 0) return {1, 32, r3 / 128};
@@ -336,6 +339,8 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
   if (r == R_ && p.vb == VB_ && p.cot == COT_)                                                             \
     return launch_conv_t<TD_, TH_, TW_, COT_, VB_>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, stats, st);
   LION_CONV_TILE(32, 2, 64, 2, 4, 32)
+  LION_CONV_TILE(32, 4, 64, 4, 4, 32)
+  LION_CONV_TILE(16, 4, 64, 8, 4, 16)
   LION_CONV_TILE(32, 4, 32, 4, 4, 32)
   LION_CONV_TILE(16, 2, 64, 4, 4, 16)
   LION_CONV_TILE(16, 4, 32, 8, 4, 16)
