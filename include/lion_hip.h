@@ -167,6 +167,14 @@ int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *b
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
                         const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
                         float *A, float *Bs, float *chmean, lionStream_t stream);
+/* ---- D2: global denoiser, models/score_sde/resnet.py:60-90, :195-218 -----------------------------------
+ * one 1x1 conv of the [B, C, 1, 1] style-latent network as a 32-row GEMM on channel-major activations
+ * xT f32[nb][Cin][32] (batch padded to 32 per slab): yT[o][b] = epi(bias[o] + sum_k W[o,k] (xT[k][b] + addT[k][b])),
+ * wp = lion_pwconv_pack_weights(w f32[Cout,Cin]); act 0 none / 1 relu; gate/resid f32[nb][Cout][32] (both or
+ * neither): y = resid + gate * sigmoid(.)  (the squeeze-excite tail of ResBlockSEDrop).  Cout % 32 == 0. */
+int lion_skinny_gemm(const float *xT, const float *wp, const float *bias, int nb, int Cin, int Cout,
+                     const float *addT, int act, const float *gate, const float *resid, float *yT,
+                     lionStream_t stream);
 /* SE3d (pvcnn2_ada.py:27-41) on the folded scalars: A, Bs f32[B,C] are multiplied in place by
  * sigmoid(W2 relu(W1 (A*chmean + Bs))), w1 f32[H,C], w2 f32[C,H] (C <= 1024, H <= 128). */
 int lion_se_gate(const float *chmean, const float *w1, const float *w2, int B, int C, int H, float *A,

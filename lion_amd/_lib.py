@@ -45,6 +45,7 @@ SIGNATURES = {
     "lion_conv3d_stat_tiles": (_i, [_i, _i, _i]),
     "lion_conv3d_k3_fused_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "lion_skinny_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "lion_se_gate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_trilinear_devoxelize_affine_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_row_stats": (_i, [_vp, _i, _i, _vp, _vp]),

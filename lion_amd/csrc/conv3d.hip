@@ -244,22 +244,30 @@ __global__ void gn_fold_kernel(const float *__restrict__ stats, int C, int T, in
                                const float *__restrict__ gamma, const float *__restrict__ beta,
                                const float *__restrict__ fac, const float *__restrict__ gbias, int ld_fg, float eps,
                                float *__restrict__ A, float *__restrict__ Bs, float *__restrict__ chmean) {
-  // one workgroup per (batch, group); C/G channels per group
+  // one wave per (batch, group); C/G <= 64 channels per group, one lane each: lane c walks its T tile sums in
+  // order (double accumulation), the group total is an xor-butterfly over the 64 lanes (a fixed tree):
+  // deterministic, and no barrier chain.
   __shared__ double gs[2];
   const int b = blockIdx.y, g = blockIdx.x, cpg = C / G, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
   if (tid < cpg) {
-    const float *p = stats + (((size_t)b * C + g * cpg + tid) * T) * 2;
-    for (int t = 0; t < T; ++t) { s1 += (double)p[2 * t]; s2 += (double)p[2 * t + 1]; }
+    const float2 *p = reinterpret_cast<const float2 *>(stats + (((size_t)b * C + g * cpg + tid) * T) * 2);
+    int t = 0;
+    for (; t + 4 <= T; t += 4) { // 4 independent loads in flight
+      const float2 v0 = p[t], v1 = p[t + 1], v2 = p[t + 2], v3 = p[t + 3];
+      s1 += (double)v0.x; s2 += (double)v0.y;
+      s1 += (double)v1.x; s2 += (double)v1.y;
+      s1 += (double)v2.x; s2 += (double)v2.y;
+      s1 += (double)v3.x; s2 += (double)v3.y;
+    }
+    for (; t < T; ++t) { const float2 v = p[t]; s1 += (double)v.x; s2 += (double)v.y; }
     chmean[(size_t)b * C + g * cpg + tid] = (float)(s1 / count);
   }
-  if (tid == 0) { gs[0] = 0.0; gs[1] = 0.0; }
+  double g1 = s1, g2 = s2;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { g1 += __shfl_xor(g1, m, 64); g2 += __shfl_xor(g2, m, 64); }
+  if (tid == 0) { gs[0] = g1; gs[1] = g2; }
   __syncthreads();
-  // channels per group <= 32: serialised adds in channel order (deterministic)
-  for (int c = 0; c < cpg; ++c) {
-    if (tid == c) { gs[0] += s1; gs[1] += s2; }
-    __syncthreads();
-  }
   if (tid < cpg) {
     const double n = (double)count * cpg;
     const double mean = gs[0] / n;

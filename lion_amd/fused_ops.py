@@ -203,3 +203,33 @@ def adagn_swish(x, adagn, style, reduce_max=False):
     y = torch.empty_like(x)
     _lib.check(lib.lion_affine_swish(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), b * c, L, _lib.ptr(y), st), "affine_swish")
     return y
+
+
+# ---- D2: global denoiser on channel-major activations (csrc/skinny.hip) -----------------------------------
+
+def to_channel_major(x):
+    """[B, C, 1, 1] (or [B, C]) -> [nb, C, 32] with the batch zero-padded to a multiple of 32."""
+    b, c = x.shape[0], x.shape[1]
+    nb = (b + 31) // 32
+    xt = x.reshape(b, c)
+    if b != nb * 32:
+        xt = torch.cat([xt, xt.new_zeros(nb * 32 - b, c)], 0)
+    return xt.reshape(nb, 32, c).transpose(1, 2).contiguous()
+
+
+def from_channel_major(xt, b):
+    nb, c, _ = xt.shape
+    return xt.transpose(1, 2).reshape(nb * 32, c)[:b].reshape(b, c, 1, 1).contiguous()
+
+
+def skinny_conv(xt, conv, add=None, act=0, gate=None, resid=None):
+    """one 1x1 conv of the global denoiser on [nb, Cin, 32] activations (see lion_skinny_gemm)."""
+    nb, cin, _ = xt.shape
+    cout = conv.out_channels
+    wp = pw_packed_weight(conv.weight)
+    y = torch.empty((nb, cout, 32), device=xt.device, dtype=torch.float32)
+    bias = conv.bias.detach() if conv.bias is not None else None
+    _lib.check(_lib.load().lion_skinny_gemm(_lib.ptr(xt), _lib.ptr(wp), _lib.ptr(bias), nb, cin, cout,
+                                            _lib.ptr(add), int(act), _lib.ptr(gate), _lib.ptr(resid), _lib.ptr(y),
+                                            _lib.stream_ptr(xt.device)), "skinny_gemm")
+    return y

@@ -137,10 +137,36 @@ class Prior(nn.Module):
             temb = torch.cat([temb, clip_feat], dim=1)
         if self.mixed_prediction and self.is_active is not None:
             x = mask_inactive_variables(x, self.is_active)
+        if self._skinny_ok(x):
+            return self._forward_skinny(x, temb)
         x = self.input_layer(x)
         for layer in self.all_modules:
             x = layer(x, temb)
         return self.output_layer(x)
+
+    def _skinny_ok(self, x):
+        """inference on the GPU with ResBlockSEDrop blocks: every layer is a 32-row GEMM -> csrc/skinny.hip."""
+        from .. import pvcnn2_ada
+        return (pvcnn2_ada.FUSE_INFERENCE and not self.training and not torch.is_grad_enabled() and x.is_cuda
+                and x.dtype == torch.float32 and not torch.is_autocast_enabled() and not self.clip_forge_enable
+                and all(type(m) is ResBlockSEDrop for m in self.all_modules)
+                and x.dim() == 4 and x.shape[2] == 1 and x.shape[3] == 1)
+
+    def _forward_skinny(self, x, temb):
+        """4 launches per residual block instead of ~15 (channel-major [C, 32] activations throughout):
+        h1 = relu(conv1(x + t)); h2 = relu(conv2(h1)); s = relu(fc1 h2); x = x + h2 * sigmoid(fc2 s)."""
+        from ... import fused_ops as fo
+        b = x.shape[0]
+        if temb.shape[0] == 1 and b > 1:
+            temb = temb.expand(b, -1, -1, -1)
+        tt = fo.to_channel_major(temb)
+        h = fo.skinny_conv(fo.to_channel_major(x), self.input_layer)
+        for blk in self.all_modules:
+            h1 = fo.skinny_conv(h, blk.conv1, add=tt, act=1)
+            h2 = fo.skinny_conv(h1, blk.conv2, act=1)
+            s = fo.skinny_conv(h2, blk.SE.fc[0], act=1)
+            h = fo.skinny_conv(s, blk.SE.fc[2], gate=h2, resid=h)
+        return fo.from_channel_major(fo.skinny_conv(h, self.output_layer), b)
 
 
 class PriorSEDrop(Prior):
