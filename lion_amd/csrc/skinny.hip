@@ -12,7 +12,9 @@
 //   accumulator tile [32 outputs x 32 batch] is written back with coalesced rows;
 // * one workgroup of 16 waves owns a tile of 32 output channels and splits K over its waves (the
 //   partial tiles are reduced through LDS in a fixed order), so the weight stream of a layer is
-//   spread over Cout/32 CUs with 64 KB in flight each;
+//   spread over Cout/32 CUs with >= 256 KB in flight each.  (Splitting K across workgroups with a
+//   last-arriver reduction was measured 2-3x slower: a device-scope fence writes back / invalidates
+//   the XCD's L2 on this multi-die part.);
 // * prologue: + time embedding (ResBlockSEDrop: conv1(x + t)); epilogue: bias, ReLU, or the whole
 //   squeeze-excite tail x + h * sigmoid(acc).
 #include "common.h"
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restri
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  constexpr int UN = 16; // k-steps whose loads are all issued before the first MFMA: 8 KiB in flight per wave
+  constexpr int UN = 16; // k-steps whose loads are all issued before the first MFMA (4 / 8 / 16 measure the same)
   for (int s0 = s_lo; s0 < s_hi; s0 += UN) {
     float av[UN], bv[UN], cv[UN];
 #pragma unroll
