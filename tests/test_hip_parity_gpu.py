@@ -395,3 +395,82 @@ def test_conv3d_mfma_matches_fp64_reference(cin, cout, r):
     conv(x3).square().sum().backward()
     assert torch.allclose(gx, x3.grad, rtol=1e-3, atol=1e-3 * x3.grad.abs().max().item())
     assert torch.allclose(gw, conv.weight.grad, rtol=1e-3, atol=1e-3 * gw.abs().max().item())
+
+
+def _swish64(t):
+    return t * torch.sigmoid(t)
+
+
+@pytest.mark.parametrize("cin,cout,L,pro", [(35, 32, 4096, False), (32, 64, 4096, True), (67, 128, 1000, True),
+                                            (131, 128, 333, False), (64, 256, 2048, True)])
+def test_pwconv_matches_fp64_reference(cin, cout, L, pro):
+    """G1: 1x1 conv on the fp32-MFMA kernel (lion_pwconv_forward) with the AdaGN+Swish prologue and the
+    GroupNorm tile sums vs an fp64 evaluation of the same expression (odd Cin, ragged L, masked tail)."""
+    from lion_amd import _lib
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(cin + L)
+    B = 3
+    conv = torch.nn.Conv1d(cin, cout, 1).cuda()
+    x = torch.randn(B, cin, L, device="cuda")
+    A = torch.randn(B, cin, device="cuda") * 0.5 + 1.0
+    Bs = torch.randn(B, cin, device="cuda") * 0.3
+    xin = x.double()
+    if pro:
+        xin = _swish64(xin * A.double()[:, :, None] + Bs.double()[:, :, None])
+    ref = torch.einsum("oc,bcl->bol", conv.weight.double()[:, :, 0], xin) + conv.bias.double()[None, :, None]
+    y, st = fo.pwconv_fused(x, conv, (A, Bs) if pro else None)
+    scale = ref.abs().max().item()
+    assert (y.double() - ref).abs().max().item() / scale < 1e-5
+    sums = st.double().sum(2)  # [B, Cout, 2] over the column tiles
+    assert torch.allclose(sums[..., 0], ref.sum(-1), rtol=1e-4, atol=1e-4 * scale * L ** 0.5)
+    assert torch.allclose(sums[..., 1], ref.square().sum(-1), rtol=1e-4)
+    assert _lib.load().lion_pwconv_stat_tiles(cout, L) == st.shape[2]
+
+
+@pytest.mark.parametrize("cin,cout,B", [(2048, 2048, 32), (2048, 256, 32), (128, 2048, 5), (256, 128, 40)])
+def test_skinny_gemm_matches_fp64_reference(cin, cout, B):
+    """D2: 32-row GEMM on channel-major activations (lion_skinny_gemm): add prologue, ReLU epilogue and
+    the squeeze-excite tail x + h * sigmoid(.), batch padding (B = 5) and two slabs (B = 40)."""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(cin + B)
+    conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+    x = torch.randn(B, cin, 1, 1, device="cuda")
+    t = torch.randn(B, cin, 1, 1, device="cuda")
+    w, bias = conv.weight.double()[:, :, 0, 0], conv.bias.double()
+    ref = torch.relu((x + t).double()[:, :, 0, 0] @ w.t() + bias)
+    got = fo.from_channel_major(fo.skinny_conv(fo.to_channel_major(x), conv, add=fo.to_channel_major(t), act=1), B)
+    assert (got.double()[:, :, 0, 0] - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+    h = torch.randn(B, cout, 1, 1, device="cuda")
+    res = torch.randn(B, cout, 1, 1, device="cuda")
+    ref2 = res.double()[:, :, 0, 0] + h.double()[:, :, 0, 0] * torch.sigmoid(x.double()[:, :, 0, 0] @ w.t() + bias)
+    got2 = fo.from_channel_major(fo.skinny_conv(fo.to_channel_major(x), conv, gate=fo.to_channel_major(h),
+                                                resid=fo.to_channel_major(res)), B)
+    assert (got2.double()[:, :, 0, 0] - ref2).abs().max().item() / ref2.abs().max().item() < 1e-5
+
+
+def test_se_gate_and_groupnorm_fold_match_torch():
+    """lion_groupnorm_fold (strided fac/gbias, tile sums) + lion_se_gate vs GroupNorm / SE3d of torch."""
+    from lion_amd import fused_ops as fo
+    from lion_amd.models.pvcnn2_ada import SE3d
+    torch.manual_seed(3)
+    B, C, T, V = 4, 64, 16, 4096
+    y = torch.randn(B, C, V, device="cuda") * 2 + 0.5
+    tiles = y.view(B, C, T, V // T)
+    stats = torch.stack([tiles.sum(-1), tiles.square().sum(-1)], -1).contiguous()
+    gn = torch.nn.GroupNorm(8, C).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    e = torch.randn(B, 2 * C, device="cuda")
+    fac, gb = e.chunk(2, 1)  # strided views: consumed in place
+    with torch.no_grad():
+        A, Bs, cm = fo.groupnorm_fold(stats, gn, fac, gb, V)
+        ref = gn(y) * fac[:, :, None] + gb[:, :, None]
+        got = y * A[:, :, None] + Bs[:, :, None]
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(cm, y.mean(-1), rtol=1e-5, atol=1e-6)
+        se = SE3d(C).cuda()
+        ref_gate = se.fc(ref.mean(-1))
+        A2, B2 = fo.se_gate_(A.clone(), Bs.clone(), cm, se)
+        assert torch.allclose(A2, A * ref_gate, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(B2, Bs * ref_gate, rtol=1e-4, atol=1e-5)
