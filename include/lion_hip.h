@@ -163,7 +163,14 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
 int lion_conv3d_stat_tiles(int r, int Cout, int B);
 int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
                                  int Cout, int r, const float *pro_a, const float *pro_b, float *y,
-                                 float *stats, lionStream_t stream);
+                                 float *stats, int32_t *occ, lionStream_t stream);
+/* The first convolution of a PVConv reads the voxelised grid (>= 94 % zeros); spatial tiles whose whole halo is
+ * empty produce exactly bias.  occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] (per-tile flags: 1 = some voxel of
+ * the tile's halo holds a point; a work list, occupied tiles first; a queue counter) is derived from the
+ * voxelisation's cnt i32[B,r^3]; passing it to ONE fused forward (only without pro_a/pro_b) skips the K loop of
+ * empty tiles and balances the occupied ones over all CUs through the queue -- bit-identical output. */
+size_t lion_conv3d_occupancy_ints(int r, int Cout, int B);
+int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ, lionStream_t stream);
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
                         const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
                         float *A, float *Bs, float *chmean, lionStream_t stream);

@@ -8,9 +8,10 @@ from . import _lib
 from .conv_ops import packed_weight, supported
 
 
-def conv3d_fused(x, conv, pro=None, want_stats=True):
+def conv3d_fused(x, conv, pro=None, want_stats=True, counts=None):
     """x [B,Cin,r,r,r] -> (y [B,Cout,r,r,r], stats [B,Cout,T,2] | None).  pro = (A, Bs) applies
-    swish(x*A+Bs) to the input on the fly."""
+    swish(x*A+Bs) to the input on the fly.  counts (int32 [B,r^3], the voxelisation's occupancy, only for
+    the conv that reads the voxelised grid): tiles with an all-zero halo skip their K loop."""
     lib = _lib.load()
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = conv.out_channels
@@ -28,9 +29,15 @@ def conv3d_fused(x, conv, pro=None, want_stats=True):
     if pro is not None:
         pa, pb = pro[0].contiguous(), pro[1].contiguous()
     bias = conv.bias.detach().contiguous() if conv.bias is not None else None
+    occ = None
+    if counts is not None and pro is None and r >= 16:
+        occ = torch.empty((lib.lion_conv3d_occupancy_ints(r, cout, b),), device=x.device, dtype=torch.int32)
+        cnt_c = counts.contiguous()
+        _lib.check(lib.lion_conv3d_tile_occupancy(_lib.ptr(cnt_c), b, r, cout, _lib.ptr(occ),
+                                                  _lib.stream_ptr(x.device)), "conv3d_tile_occupancy")
     _lib.check(lib.lion_conv3d_k3_fused_forward(
         _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
-        b, cin, cout, r, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats),
+        b, cin, cout, r, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(occ),
         _lib.stream_ptr(x.device)), "conv3d_k3_fused_forward")
     return y, stats
 

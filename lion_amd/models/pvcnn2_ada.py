@@ -160,8 +160,16 @@ class Voxelization(nn.Module):
         self.normalize = normalize
         self.eps = eps
 
-    def forward(self, features, coords):
+    def forward(self, features, coords, return_counts=False):
+        """return_counts (inference only): also the per-voxel point counts int32 [B, r^3], from which
+        the first convolution derives its empty tiles."""
         coords = coords.detach()
+        if return_counts:
+            from ..functional.backend import _backend
+            b, c = features.shape[:2]
+            out, norm_coords, _, counts = _backend.voxelize_points_forward(
+                features.float().contiguous(), coords[:, :3].float().contiguous(), self.r, self.normalize, self.eps)
+            return out.view(b, c, self.r, self.r, self.r), norm_coords, counts
         if features is None:
             from ..functional.backend import _backend
             _, norm_coords, _, _ = _backend.voxelize_points_forward(
@@ -202,7 +210,7 @@ class PVConv(nn.Module):
             self.point_features = SharedMLP(in_channels, out_channels, cfg=cfg)
         self.add_point_feat = add_point_feat
 
-    def _fused_voxel_branch(self, grid, voxel_coords, style):
+    def _fused_voxel_branch(self, grid, voxel_coords, style, counts=None):
         """eval-mode voxel branch with every pointwise stage folded into the convolutions / the
         devoxelisation (lion_amd/fused_ops.py): conv1 (+GN sums) -> fold -> conv2 with the
         swish(AdaGN1(.)) prologue (+GN sums) -> fold, SE gate from the channel means ->
@@ -210,7 +218,7 @@ class PVConv(nn.Module):
         conv1, gn1, conv2, gn2 = self.voxel_layers[0], self.voxel_layers[1], self.voxel_layers[4], self.voxel_layers[5]
         se = self.voxel_layers[6] if len(self.voxel_layers) > 6 else None
         r = self.resolution
-        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True)
+        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, counts)  # skips tiles with an all-zero halo
         f1, g1 = gn1.affine(style)
         a1, b1, _ = fused_ops.groupnorm_fold(st1, gn1.norm, f1, g1, r ** 3)
         y2, st2 = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True)
@@ -226,10 +234,15 @@ class PVConv(nn.Module):
         assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2], \
             f'get feat: {features.shape} and {coords.shape}'
         assert coords.shape[1] == 3, f'expect coords: B,3,Npoint, get: {coords.shape}'
-        grid, voxel_coords = self.voxelization(features, coords)
+        counts = None
+        if (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled() and features.is_cuda
+                and not torch.is_autocast_enabled()):
+            grid, voxel_coords, counts = self.voxelization(features, coords, return_counts=True)
+        else:
+            grid, voxel_coords = self.voxelization(features, coords)
         if (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled()
                 and fused_ops.fusable(self.voxel_layers[0], self.voxel_layers[4], self.resolution, grid)):
-            fused = self._fused_voxel_branch(grid, voxel_coords, style)
+            fused = self._fused_voxel_branch(grid, voxel_coords, style, counts)
             if self.add_point_feat:
                 fused = fused + self.point_features(features, style)
             if self.attn is not None:

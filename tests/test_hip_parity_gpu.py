@@ -474,3 +474,27 @@ def test_se_gate_and_groupnorm_fold_match_torch():
         A2, B2 = fo.se_gate_(A.clone(), Bs.clone(), cm, se)
         assert torch.allclose(A2, A * ref_gate, rtol=1e-4, atol=1e-5)
         assert torch.allclose(B2, Bs * ref_gate, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,r,n", [(32, 32, 32, 2048), (64, 64, 32, 2048), (128, 128, 16, 512)])
+def test_conv3d_empty_tile_skip_is_bit_identical(cin, cout, r, n):
+    """conv1 of a PVConv on the voxelised (sparse) grid: skipping the K loop of tiles whose halo holds no
+    point (lion_conv3d_tile_occupancy) gives bit-identical outputs and GroupNorm sums; a flat cloud
+    leaves most tiles empty."""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(r + cin)
+    B = 3
+    coords = torch.randn(B, 3, n, device="cuda") * torch.tensor([1.0, 0.2, 0.6], device="cuda").view(1, 3, 1)
+    feat = torch.randn(B, cin, n, device="cuda")
+    out, _, _, cnt = bk_().voxelize_points_forward(feat, coords, r, True, 0.0)
+    grid = out.view(B, cin, r, r, r)
+    conv = torch.nn.Conv3d(cin, cout, 3, padding=1).cuda()
+    with torch.no_grad():
+        y0, s0 = fo.conv3d_fused(grid, conv, None, True, None)
+        y1, s1 = fo.conv3d_fused(grid, conv, None, True, cnt)
+    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+
+
+def bk_():
+    from lion_amd.functional.backend import _backend
+    return _backend
