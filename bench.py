@@ -113,7 +113,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="shapes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-sparse", action="store_true",
+                    help="run the first conv of every PVConv densely (no exact skip of all-zero input tiles)")
     args = ap.parse_args()
+    if args.no_sparse:
+        from lion_amd.models import pvcnn2_ada
+        pvcnn2_ada.SPARSE_CONV1 = False
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -237,7 +242,8 @@ def main():
                        "shapes_per_gpu": B, "points": 2048, "chain_steps": 1000,
                        "timed_steps_of_chain": K, "extrapolated": K != 1000, "decode_seconds": decode_s,
                        "parallelism": f"{world} independent rank(s), no data-path collective",
-                       "launch": "eager" if args.no_graph else "hipGraph replay of each denoiser forward"},
+                       "launch": "eager" if args.no_graph else "hipGraph replay of each denoiser forward",
+                       "conv1_empty_tile_skip": not args.no_sparse},
             "roofline": roof, "roofline_voxelize": roofv,
         }
         if not args.no_cpu_baseline:

@@ -20,6 +20,8 @@ from ..conv_ops import conv3d_module
 from .. import fused_ops
 
 FUSE_INFERENCE = True  # module-level switch (tests compare the fused and the layer-by-layer paths)
+# conv1 of a PVConv reads the voxelised grid: skip (exactly) the tiles whose halo holds no point
+SPARSE_CONV1 = True
 from .adagn import AdaGN
 
 
@@ -218,7 +220,7 @@ class PVConv(nn.Module):
         conv1, gn1, conv2, gn2 = self.voxel_layers[0], self.voxel_layers[1], self.voxel_layers[4], self.voxel_layers[5]
         se = self.voxel_layers[6] if len(self.voxel_layers) > 6 else None
         r = self.resolution
-        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, counts)  # skips tiles with an all-zero halo
+        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, counts if SPARSE_CONV1 else None)  # skips all-zero tiles
         f1, g1 = gn1.affine(style)
         a1, b1, _ = fused_ops.groupnorm_fold(st1, gn1.norm, f1, g1, r ** 3)
         y2, st2 = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True)
