@@ -155,22 +155,30 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
 /* ---- P2+P3+P4 folded into C3 / K4 (inference): PVConv.forward voxel branch, pvcnn2_ada.py:211-226 ----
  * conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize without a single stand-alone pass over
  * the grid: the conv epilogue emits per-tile channel sums (stats f32[B,Cout,T,2], T =
- * lion_conv3d_stat_tiles(r, Cout, B): the spatial tiling depends on the shape), lion_groupnorm_fold turns them into per-(batch, channel) scalars
+ * lion_conv3d_stat_tiles(r, Cout, B, sparse): the spatial tiling depends on the shape), lion_groupnorm_fold turns them into per-(batch, channel) scalars
  * A, Bs (GroupNorm(G) x adaptive affine fac/gbias, models/adagn.py:61-64; fac/gbias rows are ld_fg floats
  * apart, so the two halves of the [B,2C] style projection are consumed in place) and the channel mean,
  * the next conv applies swish(x*A+Bs) while staging its input (pro_a/pro_b f32[B,Cin]), and
  * lion_trilinear_devoxelize_affine_forward interpolates scale*feat+shift (second AdaGN x SE gate). */
-int lion_conv3d_stat_tiles(int r, int Cout, int B);
+int lion_conv3d_stat_tiles(int r, int Cout, int B, int sparse); /* sparse = 1: the call will be given an occ */
 int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
-                                 int Cout, int r, const float *pro_a, const float *pro_b, float *y,
-                                 float *stats, int32_t *occ, lionStream_t stream);
+                                 int Cout, int r, const float *pro_a, const float *pro_b, const float *pro_bias,
+                                 const float *tconst, float *y, float *stats, int32_t *occ, lionStream_t stream);
 /* The first convolution of a PVConv reads the voxelised grid (>= 94 % zeros); spatial tiles whose whole halo is
  * empty produce exactly bias.  occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] (per-tile flags: 1 = some voxel of
  * the tile's halo holds a point; a work list, occupied tiles first; a queue counter) is derived from the
  * voxelisation's cnt i32[B,r^3]; passing it to ONE fused forward (only without pro_a/pro_b) skips the K loop of
  * empty tiles and balances the occupied ones over all CUs through the queue -- bit-identical output. */
 size_t lion_conv3d_occupancy_ints(int r, int Cout, int B);
-int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ, lionStream_t stream);
+/* The second convolution sees swish(AdaGN(conv1)): a per-channel constant c = swish(A*bias1+Bs) wherever conv1 saw no
+ * point, plus a sparse delta.  lion_conv3d_const_response turns c into tconst f32[B][27][Cout], the exact response of
+ * the convolution to the constant field for each of the 27 border configurations (wsum f32[27][Cin][Cout] = weights
+ * summed over the in-grid taps); with pro_bias (= bias1) and tconst the fused forward convolves only the delta, adds
+ * tconst in the epilogue, and may take an occ built with margin 2 (within fp32 rounding of the dense evaluation). */
+int lion_conv3d_const_response(const float *wsum, const float *bias2, const float *bias1, const float *pro_a,
+                               const float *pro_b, int B, int Cin, int Cout, float *tconst, lionStream_t stream);
+int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
+                               lionStream_t stream); /* margin 1 / margin 2 lists; either may be NULL; r in {16, 32} */
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
                         const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
                         float *A, float *Bs, float *chmean, lionStream_t stream);

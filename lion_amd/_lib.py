@@ -42,10 +42,11 @@ SIGNATURES = {
     "lion_conv3d_packed_floats": (_sz, [_i, _i]),
     "lion_conv3d_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_conv3d_k3_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "lion_conv3d_stat_tiles": (_i, [_i, _i, _i]),
-    "lion_conv3d_k3_fused_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lion_conv3d_stat_tiles": (_i, [_i, _i, _i, _i]),
+    "lion_conv3d_k3_fused_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lion_conv3d_const_response": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_conv3d_occupancy_ints": (_sz, [_i, _i, _i]),
-    "lion_conv3d_tile_occupancy": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "lion_conv3d_tile_occupancy": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "lion_skinny_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "lion_se_gate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

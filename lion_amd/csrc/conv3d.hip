@@ -36,6 +36,13 @@ constexpr int KC = LION_CONV_KC;
 //        previous layer, pvcnn2_ada.py:212-218, applied on the fly; zero padding stays zero).
 // STATS: per (batch, output channel, spatial tile) sum and sum of squares of the output are written
 //        to stats[b][co][tile][2] (GroupNorm statistics of the NEXT AdaGN without another pass).
+// AdaGN affine + Swish of the previous layer, applied to staged inputs (and to the previous conv's bias for the
+// constant-response decomposition below): ONE definition, so both see the same bits.
+__device__ __forceinline__ float pro_act(float v, float pa, float pb) {
+  const float t = v * pa + pb;
+  return t * __frcp_rn(1.0f + __expf(-t)); // swish(t) = t * sigmoid(t): v_exp + v_rcp
+}
+
 template <int TD, int TH, int TW, int COT, int VB, bool PRO, bool STATS>
 __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const float *__restrict__ x,
                                                                 const float *__restrict__ wp,
@@ -44,6 +51,8 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
                                                                 int Cout, int r,
                                                                 const float *__restrict__ pro_a,
                                                                 const float *__restrict__ pro_b,
+                                                                const float *__restrict__ pro_bias,
+                                                                const float *__restrict__ tconst,
                                                                 float *__restrict__ stats,
                                                                 int32_t *__restrict__ occ, int B,
                                                                 int ntiles) {
@@ -60,7 +69,9 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
   float *sw = sx + ((KC * HALO + 3) & ~3); // [2][SWS]         weight slices, double buffered (LDS-DMA)
   float *sbias = sw + 2 * SWS;            // [COT]
   float *spa = sbias + COT, *spb = spa + 256; // prologue scalars, Cin <= 256
-  float *sred = spb + 256;                // [waves][COT][2]  per-wave channel sums (STATS)
+  float *spc = spb + 256;                 // [256]            activated constant of each input channel (delta mode)
+  float *sT = spc + 256;                  // [27][COT]        constant response per border configuration (delta mode)
+  float *sred = sT + 27 * COT;            // [waves][COT][2]  per-wave channel sums (STATS)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Dense launch: grid = (B, tiles, Cout/COT); ids run batch-fastest, i.e. round-robin over the 8 XCDs, so a sample
   // (and its halo re-reads) stays on one XCD's L2.
@@ -68,7 +79,7 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
   // items from a list -- occupied tiles first, empty ones (K loop skipped, output = bias) last -- through one atomic
   // counter.  A static grid gains nothing from skipping: workgroup ids are bound to XCDs round-robin, the occupied
   // tiles of a cloud cluster in id space (measured: 74 % empty tiles, 0 % faster), and 400-us workgroups quantise
-  // the tail; the queue balances over all CUs.  occ = [B*tiles flags][B*tiles list][queue, n_occupied, n_empty].
+  // the tail; the queue balances over all CUs.  occ = [B*tiles flags][B*tiles list (per sample)][queue].
   __shared__ int s_work;
   const bool queued = occ != nullptr;
   const int ncz = Cout / COT;
@@ -80,9 +91,9 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
     __syncthreads();
     const int work = s_work;
     if (work >= B * ntiles * ncz) break;
-    const int id = occ[B * ntiles + work / ncz];
-    b = id % B;
-    tile = id / B;
+    const int item = work / ncz; // item-th entry: sample item % B, its (item / B)-th tile, occupied tiles first
+    b = item % B;
+    tile = occ[B * ntiles + b * ntiles + item / B];
     co0 = (work % ncz) * COT;
   } else {
     if (iter) break;
@@ -95,8 +106,21 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
   const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
   const int r2 = r * r, r3 = r2 * r;
 
+  // Delta mode (tconst != NULL, PRO only).  The activated input of the second convolution of a PVConv is a per-channel
+  // CONSTANT c = swish(A*bias1+Bs) wherever the first convolution saw no point (its output is exactly bias1 there), i.e.
+  // almost everywhere: z = c*[inside the grid] + delta with delta sparse.  conv(c-field) is a per-(batch, border
+  // configuration, output channel) constant tconst[b][27][Cout] (zero padding makes it differ on faces/edges/corners);
+  // the MFMA loop convolves delta only, and tiles whose 2-voxel neighbourhood holds no point skip it (occ, margin 2).
+  const bool delta = PRO && tconst != nullptr;
   if (PRO) {
-    for (int c = tid; c < Cin; c += TM) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
+    for (int c = tid; c < Cin; c += TM) {
+      const float pa = pro_a[(size_t)b * Cin + c], pb = pro_b[(size_t)b * Cin + c];
+      spa[c] = pa;
+      spb[c] = pb;
+      spc[c] = delta ? pro_act(pro_bias ? pro_bias[c] : 0.f, pa, pb) : 0.f;
+    }
+    if (delta)
+      for (int e = tid; e < 27 * COT; e += TM) sT[e] = tconst[((size_t)b * 27 + e / COT) * Cout + co0 + e % COT];
   }
   for (int c = tid; c < COT; c += TM) sbias[c] = bias ? bias[co0 + c] : 0.f;
   // spatial offsets of the halo positions this thread stages (the same for every input channel:
@@ -173,16 +197,13 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
     __syncthreads(); // everyone is done reading the previous chunk from LDS
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-      float pa = 1.f, pb = 0.f;
-      if (PRO) { pa = spa[q * KC + c]; pb = spb[q * KC + c]; } // uniform: one broadcast read per channel
+      float pa = 1.f, pb = 0.f, pc = 0.f;
+      if (PRO) { pa = spa[q * KC + c]; pb = spb[q * KC + c]; pc = spc[q * KC + c]; } // uniform broadcast reads
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int p = tid + j * TM;
         float v = rx[c][j];
-        if (PRO) {
-          const float t = v * pa + pb;
-          v = t * __frcp_rn(1.0f + __expf(-t)); // swish(t) = t * sigmoid(t), v_exp + v_rcp
-        }
+        if (PRO) v = pro_act(v, pa, pb) - pc; // pc = 0 unless delta mode
         if (p < HALO) sx[c * HALO + p] = (!PRO || gok[j]) ? v : 0.f; // zero padding stays zero
       }
     }
@@ -229,12 +250,17 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
     const int v = (wave * VB + vb) * 32 + (lane & 31);
     const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
     const int gv = ((d0 + d) * r + (h0 + h)) * r + (w0 + w);
+    // border configuration of this voxel: 0 = on the low face, 2 = on the high face, 1 = interior, per axis
+    const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
+    const int cfg = (((gd == 0 ? 0 : gd == r - 1 ? 2 : 1) * 3 + (gh == 0 ? 0 : gh == r - 1 ? 2 : 1)) * 3 +
+                     (gw == 0 ? 0 : gw == r - 1 ? 2 : 1));
+    const float *addv = delta ? sT + cfg * COT : sbias;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        const float o = acc[cb][vb][i] + sbias[co];
+        const float o = acc[cb][vb][i] + addv[co];
         acc[cb][vb][i] = o;
         yb[(size_t)co * r3 + gv] = o;
       }
@@ -317,27 +343,62 @@ __global__ void gn_fold_kernel(const float *__restrict__ stats, int C, int T, in
   }
 }
 
-// One wave per (batch, tile): any occupied voxel (cnt > 0, from the voxelisation) in the tile's halo?  Also builds
-// the work list of the sparse convolution: occupied (b, tile) ids from the front, empty ones from the back.
-// occ = [B*tiles flags][B*tiles list][queue = 0, n_occupied = 0, n_empty = 0]  (the three counters zeroed by the host).
-__global__ __launch_bounds__(64) void conv_tile_occ_kernel(const int32_t *__restrict__ cnt, int r, int TD, int TH,
-                                                           int TW, int32_t *__restrict__ occ) {
-  const int b = blockIdx.x, t = blockIdx.y, B = gridDim.x, ntiles = gridDim.y, lane = threadIdx.x;
-  const int ntw = r / TW, nth = r / TH;
-  const int d0 = (t / (ntw * nth)) * TD - 1, h0 = ((t / ntw) % nth) * TH - 1, w0 = (t % ntw) * TW - 1;
-  const int HD = TD + 2, HH = TH + 2, HW = TW + 2;
-  const int32_t *c = cnt + (size_t)b * r * r * r;
-  int any = 0;
-  for (int p = lane; p < HD * HH * HW; p += 64) {
-    const int d = d0 + p / (HH * HW), h = h0 + (p / HW) % HH, w = w0 + p % HW;
-    if (d >= 0 && d < r && h >= 0 && h < r && w >= 0 && w < r) any |= c[(d * r + h) * r + w];
+// One workgroup per sample: (1) which (d, h) columns of the count grid hold a point (tiles span the whole w axis),
+// (2) per spatial tile: any point within `margin` voxels of the tile, for margin 1 (the conv that reads the voxelised
+// grid) and margin 2 (the delta of the second conv), (3) the sample's work list for each margin -- occupied tiles
+// first, empty ones after -- and the reset of the queue counter.  No atomics, no host memset, deterministic order.
+// occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter].
+__global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__restrict__ cnt, int r, int TD, int TH,
+                                                             int32_t *__restrict__ occ1, int32_t *__restrict__ occ2) {
+  __shared__ int col[32 * 32];
+  __shared__ int flag[2][256];
+  const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
+  const int nth = r / TH, ntiles = (r / TD) * nth, total = B * ntiles;
+  for (int i = tid; i < r * r; i += 1024) col[i] = 0;
+  __syncthreads();
+  const int4 *c4 = reinterpret_cast<const int4 *>(cnt + (size_t)b * r * r * r);
+  for (int i = tid; i < (r * r * r) >> 2; i += 1024) {
+    const int4 v = c4[i];
+    if (v.x | v.y | v.z | v.w) col[(i << 2) / r] = 1; // benign race: everybody writes 1
   }
-  const unsigned long long m = __ballot(any != 0);
-  if (lane == 0) {
-    const int total = B * ntiles, id = t * B + b;
-    occ[b * ntiles + t] = m != 0ull;
-    if (m != 0ull) occ[total + atomicAdd(occ + 2 * total + 1, 1)] = id;
-    else occ[total + total - 1 - atomicAdd(occ + 2 * total + 2, 1)] = id;
+  __syncthreads();
+  for (int e = tid; e < 2 * ntiles; e += 1024) {
+    const int t = e % ntiles, margin = 1 + e / ntiles;
+    const int d0 = (t / nth) * TD - margin, h0 = (t % nth) * TH - margin;
+    int any = 0;
+    for (int d = max(d0, 0); d < min(d0 + TD + 2 * margin, r); ++d)
+      for (int h = max(h0, 0); h < min(h0 + TH + 2 * margin, r); ++h) any |= col[d * r + h];
+    flag[margin - 1][t] = any;
+  }
+  __syncthreads();
+  if (tid < 2) { // one thread per margin: <= 256 tiles, occupied first
+    int32_t *occ = tid == 0 ? occ1 : occ2;
+    if (occ) {
+      int32_t *fl = occ + (size_t)b * ntiles, *list = occ + total + (size_t)b * ntiles;
+      int k = 0;
+      for (int t = 0; t < ntiles; ++t) { fl[t] = flag[tid][t]; if (flag[tid][t]) list[k++] = t; }
+      for (int t = 0; t < ntiles; ++t) if (!flag[tid][t]) list[k++] = t;
+      if (b == 0) occ[2 * total] = 0; // the queue of the convolution that consumes this list
+    }
+  }
+}
+
+// tconst[b][cfg][co] = bias2[co] + sum_ci wsum[cfg][ci][co] * swish(A[b,ci] * bias1[ci] + Bs[b,ci]): the response of the
+// second convolution to the constant field its input takes away from the points (double accumulation).
+__global__ __launch_bounds__(256) void conv_tconst_kernel(const float *__restrict__ wsum, const float *__restrict__ bias2,
+                                                          const float *__restrict__ bias1, const float *__restrict__ pro_a,
+                                                          const float *__restrict__ pro_b, int Cin, int Cout,
+                                                          float *__restrict__ tconst) {
+  __shared__ float sc[256];
+  const int cfg = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  for (int c = tid; c < Cin; c += 256)
+    sc[c] = pro_act(bias1 ? bias1[c] : 0.f, pro_a[(size_t)b * Cin + c], pro_b[(size_t)b * Cin + c]);
+  __syncthreads();
+  for (int co = tid; co < Cout; co += 256) {
+    double acc = bias2 ? (double)bias2[co] : 0.0;
+    const float *w = wsum + (size_t)cfg * Cin * Cout + co;
+    for (int c = 0; c < Cin; ++c) acc += (double)w[(size_t)c * Cout] * (double)sc[c];
+    tconst[((size_t)b * 27 + cfg) * Cout + co] = (float)acc;
   }
 }
 
@@ -353,8 +414,8 @@ __global__ void conv3d_pack_kernel(const float *__restrict__ w, int Cout, int Ci
 
 template <int TD, int TH, int TW, int COT, int VB>
 static int launch_conv_t(const float *x, const float *wp, const float *bias, float *y, int B, int Cin,
-                         int Cout, int r, const float *pa, const float *pb, float *stats, int32_t *occ,
-                         hipStream_t st) {
+                         int Cout, int r, const float *pa, const float *pb, const float *pbias, const float *tconst,
+                         float *stats, int32_t *occ, hipStream_t st) {
   const int tiles = (r / TD) * (r / TH) * (r / TW);
   static int n_cu = 0;
   if (!n_cu) {
@@ -368,7 +429,7 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
   constexpr int NT = 256;
   constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
   constexpr int SWS = ((KC * 27 * COT + 255) / 256) * 256 + 256;
-  constexpr size_t LDS = (size_t)(((KC * HALO + 3) & ~3) + 2 * SWS + COT + 512 + (NT / 64) * COT * 2) * 4;
+  constexpr size_t LDS = (size_t)(((KC * HALO + 3) & ~3) + 2 * SWS + COT + 768 + 27 * COT + (NT / 64) * COT * 2) * 4;
 #define LION_CONV_GO(PRO_, ST_)                                                                           \
   {                                                                                                       \
     static bool cfg = false;                                                                              \
@@ -380,7 +441,8 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
       cfg = true;                                                                                         \
     }                                                                                                     \
     conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_><<<grid, NT, LDS, st>>>(x, wp, bias, y, Cin, Cout, r, \
-                                                                            pa, pb, stats, occ, B, tiles); \
+                                                                            pa, pb, pbias, tconst, stats, occ, B, \
+                                                                            tiles);                      \
   }
   if (pa && stats) LION_CONV_GO(true, true)
   else if (pa) LION_CONV_GO(true, false)
@@ -399,11 +461,14 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
 //   small grids (r = 8)               : VB 1 x COT 32  (twice the waves: 2 per SIMD instead of 1, so that one
 //                                                        wave's staging / barriers hide under the other's MFMAs)
 struct ConvPlan { int vb, cot, tiles; };
-static ConvPlan conv_plan(int r, int Cout, int B) {
+// sparse (work-queue) launches take the smaller 2x2 tiles: more of them are empty, the tail is finer grained, and the
+// occupied ones spread over all CUs even when they are fewer than the resident workgroups.
+static ConvPlan conv_plan(int r, int Cout, int B, bool sparse) {
   const int r3 = r * r * r;
-  if (Cout % 64 == 0 && r >= 16 && (long)(r3 / 512) * (Cout / 64) * B >= 512) return {4, 64, r3 / 512};
+  if (!sparse && Cout % 64 == 0 && r >= 16 && (long)(r3 / 512) * (Cout / 64) * B >= 512) return {4, 64, r3 / 512};
   if (Cout % 64 == 0 && (long)(r3 / 256) * (Cout / 64) * B >= 512) return {2, 64, r3 / 256};
-  if (Cout % 32 == 0 && r >= 16) return {4, 32, r3 / 512};
+  if (Cout % 32 == 0 && r >= 16 && !sparse) return {4, 32, r3 / 512};
+  if (Cout % 32 == 0 && r >= 16) return {2, 32, r3 / 256};
   if (Cout % 32 == 0) return {1, 32, r3 / 128};
   return {0, 0, 0};
 }
@@ -416,15 +481,18 @@ static void conv_tile_dims(int r, int vb, int *td, int *th, int *tw) {
 }
 
 static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int B, int Cin, int Cout,
-                       int r, const float *pa, const float *pb, float *stats, int32_t *occ, hipStream_t st) {
-  const ConvPlan p = conv_plan(r, Cout, B);
+                       int r, const float *pa, const float *pb, const float *pbias, const float *tconst, float *stats,
+                       int32_t *occ, hipStream_t st) {
+  const ConvPlan p = conv_plan(r, Cout, B, occ != nullptr);
 #define LION_CONV_TILE(R_, VB_, COT_, TD_, TH_, TW_)                                                       \
   if (r == R_ && p.vb == VB_ && p.cot == COT_)                                                             \
-    return launch_conv_t<TD_, TH_, TW_, COT_, VB_>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, stats, occ, st);
+    return launch_conv_t<TD_, TH_, TW_, COT_, VB_>(x, wp, bias, y, B, Cin, Cout, r, pa, pb, pbias, tconst, stats, occ, st);
   LION_CONV_TILE(32, 2, 64, 2, 4, 32)
   LION_CONV_TILE(32, 4, 64, 4, 4, 32)
   LION_CONV_TILE(16, 4, 64, 8, 4, 16)
   LION_CONV_TILE(32, 4, 32, 4, 4, 32)
+  LION_CONV_TILE(32, 2, 32, 2, 4, 32)
+  LION_CONV_TILE(16, 2, 32, 4, 4, 16)
   LION_CONV_TILE(16, 2, 64, 4, 4, 16)
   LION_CONV_TILE(16, 4, 32, 8, 4, 16)
   LION_CONV_TILE(8, 2, 64, 4, 8, 8)
@@ -454,53 +522,68 @@ int lion_conv3d_pack_weights(const float *w, int Cout, int Cin, float *wp, lionS
 // x f32[B,Cin,r,r,r] with Cin % 4 == 0, wp from lion_conv3d_pack_weights, bias f32[Cout] or NULL
 // -> y f32[B,Cout,r,r,r].   r in {8, 16, 32}.
 // pro_a / pro_b f32[B,Cin] (both or neither): input is swish(x*a+b) (fused AdaGN + Swish prologue).
-// stats f32[B,Cout,lion_conv3d_stat_tiles(r,Cout,B),2] or NULL: per-tile channel sums of the output.
+// stats f32[B,Cout,lion_conv3d_stat_tiles(r,Cout,B,sparse),2] or NULL: per-tile channel sums of the output.
 // occ (lion_conv3d_tile_occupancy, consumed by this call; only without the prologue) or NULL: all-zero input tiles are
 // skipped and the work is balanced through a queue.
 int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
-                                 int Cout, int r, const float *pro_a, const float *pro_b, float *y,
-                                 float *stats, int32_t *occ, lionStream_t stream) {
+                                 int Cout, int r, const float *pro_a, const float *pro_b, const float *pro_bias,
+                                 const float *tconst, float *y, float *stats, int32_t *occ, lionStream_t stream) {
   if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
   if ((pro_a == nullptr) != (pro_b == nullptr)) return LION_EINVAL;
-  if (occ && pro_a) return LION_EINVAL; // swish(0*a+b) != 0: an activated input is never sparse
+  if (tconst && !pro_a) return LION_EINVAL;
+  if (occ && pro_a && !tconst) return LION_EINVAL; // an activated input is sparse only as constant + delta
   if (Cin % KC != 0 || (pro_a && Cin > 256)) return LION_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (r != 8 && r != 16 && r != 32) return LION_EUNSUPPORTED;
-  return launch_conv(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, stats, occ, st);
+  return launch_conv(x, wp, bias, y, B, Cin, Cout, r, pro_a, pro_b, pro_bias, tconst, stats, occ, st);
 }
 
 int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
                            int Cout, int r, float *y, lionStream_t stream) {
-  return lion_conv3d_k3_fused_forward(x, wp, bias, B, Cin, Cout, r, nullptr, nullptr, y, nullptr, nullptr, stream);
+  return lion_conv3d_k3_fused_forward(x, wp, bias, B, Cin, Cout, r, nullptr, nullptr, nullptr, nullptr, y, nullptr,
+                                      nullptr, stream);
 }
 
 // occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] = [B*tiles flags][B*tiles work list][3 counters], tiles =
-// lion_conv3d_stat_tiles(r,Cout,B): flag 1 if any voxel of the tile's halo holds a point (cnt i32[B,r^3] from the
+// lion_conv3d_stat_tiles(r,Cout,B,sparse): flag 1 if any voxel of the tile's halo holds a point (cnt i32[B,r^3] from the
 // voxelisation).  Feed to ONE lion_conv3d_k3_fused_forward (the convolution that reads the voxelised grid): the call
 // consumes the work queue.
-size_t lion_conv3d_occupancy_ints(int r, int Cout, int B) {
-  if (r != 8 && r != 16 && r != 32) return 0;
-  return (size_t)2 * B * conv_plan(r, Cout, B).tiles + 3;
-}
-
-int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ, lionStream_t stream) {
-  if (!cnt || !occ || B <= 0 || Cout <= 0) return LION_EINVAL;
-  if (r != 8 && r != 16 && r != 32) return LION_EUNSUPPORTED;
-  const ConvPlan p = conv_plan(r, Cout, B);
-  if (!p.vb) return LION_EUNSUPPORTED;
-  int td, th, tw;
-  conv_tile_dims(r, p.vb, &td, &th, &tw);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(occ + (size_t)2 * B * p.tiles, 0, 3 * sizeof(int32_t), st);
-  if (e != hipSuccess) return (int)e;
-  conv_tile_occ_kernel<<<dim3(B, p.tiles), 64, 0, st>>>(cnt, r, td, th, tw, occ);
+// wsum f32[27][Cin][Cout]: weights summed over the taps that stay inside the grid for each border configuration
+// cfg = (cd*3 + ch)*3 + cw (0 low face, 1 interior, 2 high face per axis); bias2 f32[Cout] or NULL (this conv),
+// bias1 f32[Cin] or NULL (the conv that produced the input), pro_a/pro_b f32[B,Cin] -> tconst f32[B][27][Cout].
+int lion_conv3d_const_response(const float *wsum, const float *bias2, const float *bias1, const float *pro_a,
+                               const float *pro_b, int B, int Cin, int Cout, float *tconst, lionStream_t stream) {
+  if (!wsum || !pro_a || !pro_b || !tconst || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
+  if (Cin > 256) return LION_EUNSUPPORTED;
+  conv_tconst_kernel<<<dim3(27, B), 256, 0, static_cast<hipStream_t>(stream)>>>(wsum, bias2, bias1, pro_a, pro_b, Cin,
+                                                                                 Cout, tconst);
   LION_LAUNCH_CHECK();
   return 0;
 }
 
-int lion_conv3d_stat_tiles(int r, int Cout, int B) {
+size_t lion_conv3d_occupancy_ints(int r, int Cout, int B) {
+  if (r != 16 && r != 32) return 0;
+  return (size_t)2 * B * conv_plan(r, Cout, B, true).tiles + 1;
+}
+
+// occ_m1 / occ_m2 (either may be NULL): the occupancy + work list for margin 1 (conv on the voxelised grid) and
+// margin 2 (delta mode of the following conv), each consumed by ONE fused forward.
+int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
+                               lionStream_t stream) {
+  if (!cnt || (!occ_m1 && !occ_m2) || B <= 0 || Cout <= 0) return LION_EINVAL;
+  if (r != 16 && r != 32) return LION_EUNSUPPORTED;
+  const ConvPlan p = conv_plan(r, Cout, B, true);
+  if (!p.vb || p.tiles > 256 || (((uintptr_t)cnt) & 15) != 0) return LION_EUNSUPPORTED;
+  int td, th, tw;
+  conv_tile_dims(r, p.vb, &td, &th, &tw);
+  conv_tile_occ_kernel<<<B, 1024, 0, static_cast<hipStream_t>(stream)>>>(cnt, r, td, th, occ_m1, occ_m2);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_conv3d_stat_tiles(int r, int Cout, int B, int sparse) {
   if (r != 8 && r != 16 && r != 32) return 0;
-  return conv_plan(r, Cout, B).tiles;
+  return conv_plan(r, Cout, B, sparse != 0).tiles;
 }
 
 // stats f32[B,C,T,2] -> A, Bs, chmean f32[B,C]   (GroupNorm(G) folded with the AdaGN affine fac/gbias f32[B,C])

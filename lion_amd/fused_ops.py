@@ -8,10 +8,47 @@ from . import _lib
 from .conv_ops import packed_weight, supported
 
 
-def conv3d_fused(x, conv, pro=None, want_stats=True, counts=None):
+_WSUM_CACHE = {}
+
+
+def border_weight_sums(weight):
+    """[Cout,Cin,3,3,3] -> [27,Cin,Cout]: the weights summed over the taps that stay inside the grid, for each of
+    the 27 border configurations (per axis: 0 = voxel on the low face, 1 = interior, 2 = on the high face); fp64
+    sums, cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _WSUM_CACHE.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    m = torch.tensor([[0., 1., 1.], [1., 1., 1.], [1., 1., 0.]], dtype=torch.float64, device=weight.device)
+    ws = torch.einsum("oidhw,ad,bh,cw->abcio", weight.detach().double(), m, m, m)
+    ws = ws.reshape(27, weight.shape[1], weight.shape[0]).float().contiguous()
+    _WSUM_CACHE[id(weight)] = (key, ws)
+    return ws
+
+
+def conv3d_occupancy(counts, r, cout, b):
+    """(occ for the conv on the voxelised grid, occ for the delta mode of the following conv), one launch; each is
+    consumed by ONE conv3d_fused call.  counts: int32 [B, r^3] from the voxelisation."""
+    lib = _lib.load()
+    n = lib.lion_conv3d_occupancy_ints(r, cout, b)
+    buf = torch.empty((2, n), device=counts.device, dtype=torch.int32)
+    cnt_c = counts.contiguous()
+    _lib.check(lib.lion_conv3d_tile_occupancy(_lib.ptr(cnt_c), b, r, cout, _lib.ptr(buf[0]), _lib.ptr(buf[1]),
+                                              _lib.stream_ptr(counts.device)), "conv3d_tile_occupancy")
+    return buf[0], buf[1]
+
+
+def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None):
     """x [B,Cin,r,r,r] -> (y [B,Cout,r,r,r], stats [B,Cout,T,2] | None).  pro = (A, Bs) applies
-    swish(x*A+Bs) to the input on the fly.  counts (int32 [B,r^3], the voxelisation's occupancy, only for
-    the conv that reads the voxelised grid): tiles with an all-zero halo skip their K loop."""
+    swish(x*A+Bs) to the input on the fly.
+    occ (from conv3d_occupancy: the first element for the conv on the voxelised grid, the second for the conv
+    after it) enables the sparse evaluation:
+      * pro is None (the conv that reads the voxelised grid): tiles whose halo holds no point skip their K loop
+        (output = bias exactly), occupied tiles are balanced over the CUs through a work queue;
+      * pro given and prev_conv = the convolution that produced x: x is bias1 wherever no point is near, so the
+        activated input is a per-channel constant + a sparse delta; the constant's response is added in the
+        epilogue (27 border configurations), the MFMA loop runs on the delta and skips tiles with no point within
+        2 voxels."""
     lib = _lib.load()
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = conv.out_channels
@@ -22,23 +59,32 @@ def conv3d_fused(x, conv, pro=None, want_stats=True, counts=None):
     x = x.contiguous()
     wp = packed_weight(conv.weight)
     y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
-    stats = None
-    if want_stats:
-        stats = torch.empty((b, cout, lib.lion_conv3d_stat_tiles(r, cout, b), 2), device=x.device, dtype=torch.float32)
-    pa = pb = None
+    st = _lib.stream_ptr(x.device)
+    pa = pb = pbias = tconst = None
     if pro is not None:
         pa, pb = pro[0].contiguous(), pro[1].contiguous()
     bias = conv.bias.detach().contiguous() if conv.bias is not None else None
-    occ = None
-    if counts is not None and pro is None and r >= 16:
-        occ = torch.empty((lib.lion_conv3d_occupancy_ints(r, cout, b),), device=x.device, dtype=torch.int32)
-        cnt_c = counts.contiguous()
-        _lib.check(lib.lion_conv3d_tile_occupancy(_lib.ptr(cnt_c), b, r, cout, _lib.ptr(occ),
-                                                  _lib.stream_ptr(x.device)), "conv3d_tile_occupancy")
+    sparse = occ is not None and r >= 16
+    if sparse and pro is not None:
+        if prev_conv is None or cin > 256:
+            sparse = False
+        else:
+            ws = border_weight_sums(conv.weight)
+            pbias = prev_conv.bias.detach().contiguous() if prev_conv.bias is not None else None
+            tconst = torch.empty((b, 27, cout), device=x.device, dtype=torch.float32)
+            _lib.check(lib.lion_conv3d_const_response(_lib.ptr(ws), _lib.ptr(bias), _lib.ptr(pbias), _lib.ptr(pa),
+                                                      _lib.ptr(pb), b, cin, cout, _lib.ptr(tconst), st),
+                       "conv3d_const_response")
+    stats = None
+    if want_stats:
+        stats = torch.empty((b, cout, lib.lion_conv3d_stat_tiles(r, cout, b, int(sparse)), 2), device=x.device,
+                            dtype=torch.float32)
+    if not sparse:
+        occ = None
     _lib.check(lib.lion_conv3d_k3_fused_forward(
         _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
-        b, cin, cout, r, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(occ),
-        _lib.stream_ptr(x.device)), "conv3d_k3_fused_forward")
+        b, cin, cout, r, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(pbias), _lib.ptr(tconst), _lib.ptr(y), _lib.ptr(stats),
+        _lib.ptr(occ), st), "conv3d_k3_fused_forward")
     return y, stats
 
 

@@ -220,10 +220,14 @@ class PVConv(nn.Module):
         conv1, gn1, conv2, gn2 = self.voxel_layers[0], self.voxel_layers[1], self.voxel_layers[4], self.voxel_layers[5]
         se = self.voxel_layers[6] if len(self.voxel_layers) > 6 else None
         r = self.resolution
-        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, counts if SPARSE_CONV1 else None)  # skips all-zero tiles
+        occ1 = occ2 = None
+        if SPARSE_CONV1 and counts is not None and r >= 16:
+            occ1, occ2 = fused_ops.conv3d_occupancy(counts, r, conv1.out_channels, grid.shape[0])
+        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, occ1)  # skips all-zero tiles
         f1, g1 = gn1.affine(style)
         a1, b1, _ = fused_ops.groupnorm_fold(st1, gn1.norm, f1, g1, r ** 3)
-        y2, st2 = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True)
+        # conv2's activated input = per-channel constant + a delta that is non-zero only near the points
+        y2, st2 = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True, occ2, prev_conv=conv1)
         f2, g2 = gn2.affine(style)
         a2, b2, m2 = fused_ops.groupnorm_fold(st2, gn2.norm, f2, g2, r ** 3)
         if se is not None:

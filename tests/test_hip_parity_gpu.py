@@ -491,10 +491,49 @@ def test_conv3d_empty_tile_skip_is_bit_identical(cin, cout, r, n):
     conv = torch.nn.Conv3d(cin, cout, 3, padding=1).cuda()
     with torch.no_grad():
         y0, s0 = fo.conv3d_fused(grid, conv, None, True, None)
-        y1, s1 = fo.conv3d_fused(grid, conv, None, True, cnt)
-    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+        occ1, _ = fo.conv3d_occupancy(cnt, r, cout, B)
+        y1, s1 = fo.conv3d_fused(grid, conv, None, True, occ1)
+        nt = occ1.numel() // 2 // B
+        assert occ1[:B * nt].float().mean().item() < 0.9  # the flat cloud leaves tiles empty
+    assert torch.equal(y0, y1)  # same K order per voxel whatever the tiling
+    t0, t1 = s0.sum(2), s1.sum(2)  # the sparse launch tiles differently: compare the totals
+    assert torch.allclose(t0, t1, rtol=1e-4, atol=1e-5 * t0.abs().max().item())
 
 
 def bk_():
     from lion_amd.functional.backend import _backend
     return _backend
+
+
+@pytest.mark.parametrize("c,r,n,flat", [(32, 32, 2048, True), (64, 32, 2048, False), (64, 16, 700, True)])
+def test_conv3d_constant_plus_delta_matches_dense(c, r, n, flat):
+    """second conv of a PVConv: swish(AdaGN(conv1)) = per-channel constant + sparse delta.  The delta-mode kernel
+    (constant response per border configuration in the epilogue, tiles with no point within 2 voxels skipped) must
+    agree with the dense evaluation of the same convolution to fp32 rounding, including faces / edges / corners."""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(r + c + n)
+    B = 3
+    sc = torch.tensor([1.0, 0.2, 0.6] if flat else [1.0, 1.0, 1.0], device="cuda").view(1, 3, 1)
+    coords = torch.randn(B, 3, n, device="cuda") * sc
+    feat = torch.randn(B, c, n, device="cuda")
+    out, _, _, cnt = bk_().voxelize_points_forward(feat, coords, r, True, 0.0)
+    grid = out.view(B, c, r, r, r)
+    conv1 = torch.nn.Conv3d(c, c, 3, padding=1).cuda()
+    conv2 = torch.nn.Conv3d(c, c, 3, padding=1).cuda()
+    A = torch.rand(B, c, device="cuda") + 0.5
+    Bs = torch.randn(B, c, device="cuda") * 0.5
+    with torch.no_grad():
+        occ1, occ2 = fo.conv3d_occupancy(cnt, r, c, B)
+        y1, _ = fo.conv3d_fused(grid, conv1, None, True, occ1)
+        dense, sd = fo.conv3d_fused(y1, conv2, (A, Bs), True, None)
+        sparse, ss = fo.conv3d_fused(y1, conv2, (A, Bs), True, occ2, prev_conv=conv1)
+        ref = torch.nn.functional.conv3d(
+            torch.nn.functional.silu(y1.double() * A.double().view(B, c, 1, 1, 1) + Bs.double().view(B, c, 1, 1, 1)),
+            conv2.weight.double(), conv2.bias.double(), padding=1)
+    scale = ref.abs().max().item()
+    assert (dense.double() - ref).abs().max().item() / scale < 1e-5
+    assert (sparse.double() - ref).abs().max().item() / scale < 1e-5
+    for sl in ((..., 0, 0, 0), (..., r - 1, r - 1, r - 1), (..., 0, r // 2, r - 1)):  # corners / edge
+        assert torch.allclose(sparse[sl].double(), ref[sl], rtol=1e-4, atol=1e-5 * scale)
+    tot_s, tot_d = ss.sum(2), sd.sum(2)
+    assert torch.allclose(tot_s, tot_d, rtol=1e-3, atol=1e-4 * tot_d.abs().max().item())
