@@ -212,7 +212,7 @@ def main():
                     break
             xin = torch.randn(B, 64, 32, 32, 32, device=dev)
             from lion_amd.conv_ops import conv3d_module
-            tconv = ev_time(lambda: conv3d_module(conv, xin), 10)
+            tconv = ev_time(lambda: conv3d_module(conv, xin), 20, warm=5)
             flops = 2.0 * 27 * 64 * 64 * 32 ** 3 * B
             roof = {"kernel": "conv3d_k3_kernel: Conv3d 3x3x3 64->64 @32^3, B=32 (PVConv voxel branch; fp32-MFMA implicit GEMM, csrc/conv3d.hip)", "bound": "mfma",
                     "achieved": flops / tconv / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -227,6 +227,16 @@ def main():
                      "bound": "hbm", "achieved": vbytes / tv / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": vbytes / tv / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_call": tv * 1e6,
                      "algorithmic_bytes": vbytes}
+            _, nc, _, _ = bk.voxelize_points_forward(None, co, r, True, 0.0)
+            gridv = torch.randn(B, C, r ** 3, device=dev)
+            td = ev_time(lambda: bk.trilinear_devoxelize_forward(r, False, nc, gridv), 20)
+            dbytes = 4.0 * B * (3 * N + C * min(r ** 3, 8 * N) + C * N)       # 8 corners per point
+            dphys = 4.0 * B * (3 * N + C * r ** 3 + C * N)                    # what moves: the grid is read once
+            roofd = {"kernel": "trilinear_devoxelize C=64 N=2048 r=32: devox_slab_kernel (LDS-DMA slabs)",
+                     "bound": "hbm", "achieved": dbytes / td / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dbytes / td / 1e9 / HBM_PEAK_GBS, "traffic": dphys, "us_per_call": td * 1e6,
+                     "algorithmic_bytes": dbytes,
+                     "note": "traffic = bytes physically moved (whole grid read once): %.0f GB/s" % (dphys / td / 1e9)}
             try:  # HBM bytes per call from the separate rocprofv3 --pmc passes (cannot be collected live)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_voxelize_traffic.json")))
                 roofv["traffic"] = tj["hbm_bytes_per_call"]
@@ -244,7 +254,7 @@ def main():
                        "parallelism": f"{world} independent rank(s), no data-path collective",
                        "launch": "eager" if args.no_graph else "hipGraph replay of each denoiser forward",
                        "conv1_empty_tile_skip": not args.no_sparse},
-            "roofline": roof, "roofline_voxelize": roofv,
+            "roofline": roof, "roofline_voxelize": roofv, "roofline_devoxelize": roofd,
         }
         if not args.no_cpu_baseline:
             try:
