@@ -68,10 +68,12 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
   float *sx = smem;                       // [KC][HALO]       input tile of the current chunk
   float *sw = sx + ((KC * HALO + 3) & ~3); // [2][SWS]         weight slices, double buffered (LDS-DMA)
   float *sbias = sw + 2 * SWS;            // [COT]
-  float *spa = sbias + COT, *spb = spa + 256; // prologue scalars, Cin <= 256
-  float *spc = spb + 256;                 // [256]            activated constant of each input channel (delta mode)
-  float *sT = spc + 256;                  // [27][COT]        constant response per border configuration (delta mode)
-  float *sred = sT + 27 * COT;            // [waves][COT][2]  per-wave channel sums (STATS)
+  const int npro = PRO ? ((Cin + 63) & ~63) : 0; // prologue scalars per input channel (Cin <= 256)
+  float *spa = sbias + COT, *spb = spa + npro;
+  float *spc = spb + npro;                // [npro]           activated constant of each input channel (delta mode)
+  float *sred = spc + npro;               // [waves][COT][2]  per-wave channel sums (STATS)
+  float *sT = sx;                         // [27][COT] constant response per border configuration (delta mode): loaded
+                                          // after the K loop, into the then idle input tile
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Dense launch: grid = (B, tiles, Cout/COT); ids run batch-fastest, i.e. round-robin over the 8 XCDs, so a sample
   // (and its halo re-reads) stays on one XCD's L2.
@@ -119,8 +121,6 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
       spb[c] = pb;
       spc[c] = delta ? pro_act(pro_bias ? pro_bias[c] : 0.f, pa, pb) : 0.f;
     }
-    if (delta)
-      for (int e = tid; e < 27 * COT; e += TM) sT[e] = tconst[((size_t)b * 27 + e / COT) * Cout + co0 + e % COT];
   }
   for (int c = tid; c < COT; c += TM) sbias[c] = bias ? bias[co0 + c] : 0.f;
   // spatial offsets of the halo positions this thread stages (the same for every input channel:
@@ -241,7 +241,13 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
     }
   }
 
-  if (empty) __syncthreads(); // sbias was written by other threads and no barrier of the K loop ran
+  if (delta) {
+    __syncthreads(); // the last chunk's LDS reads are done: the input tile buffer becomes the response table
+    for (int e = tid; e < 27 * COT; e += TM) sT[e] = tconst[((size_t)b * 27 + e / COT) * Cout + co0 + e % COT];
+    __syncthreads();
+  } else if (empty) {
+    __syncthreads(); // sbias was written by other threads and no barrier of the K loop ran
+  }
   // epilogue: + bias, NCDHW store.  acc register i of lane l: channel row (i&3) + 8*(i>>2) + 4*(l>>5),
   // voxel column l&31 -> 32 consecutive voxels per (register, half-wave).
   float *yb = y + ((size_t)b * Cout + co0) * r3;
@@ -429,16 +435,18 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
   constexpr int NT = 256;
   constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
   constexpr int SWS = ((KC * 27 * COT + 255) / 256) * 256 + 256;
-  constexpr size_t LDS = (size_t)(((KC * HALO + 3) & ~3) + 2 * SWS + COT + 768 + 27 * COT + (NT / 64) * COT * 2) * 4;
+  static_assert(KC * HALO >= 27 * COT, "the response table must fit the input tile buffer");
+  const size_t LDS = (size_t)(((KC * HALO + 3) & ~3) + 2 * SWS + COT + (pa ? 3 * ((Cin + 63) & ~63) : 0) +
+                              (NT / 64) * COT * 2) * 4;
 #define LION_CONV_GO(PRO_, ST_)                                                                           \
   {                                                                                                       \
-    static bool cfg = false;                                                                              \
-    if (!cfg) {                                                                                           \
+    static size_t cfg = 0;                                                                                \
+    if (LDS > cfg) {                                                                                      \
       hipError_t e = hipFuncSetAttribute(                                                                 \
           reinterpret_cast<const void *>(&conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_>),              \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);                                          \
       if (e != hipSuccess) return (int)e;                                                                 \
-      cfg = true;                                                                                         \
+      cfg = LDS;                                                                                          \
     }                                                                                                     \
     conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_><<<grid, NT, LDS, st>>>(x, wp, bias, y, Cin, Cout, r, \
                                                                             pa, pb, pbias, tconst, stats, occ, B, \
