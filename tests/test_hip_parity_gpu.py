@@ -537,3 +537,30 @@ def test_conv3d_constant_plus_delta_matches_dense(c, r, n, flat):
         assert torch.allclose(sparse[sl].double(), ref[sl], rtol=1e-4, atol=1e-5 * scale)
     tot_s, tot_d = ss.sum(2), sd.sum(2)
     assert torch.allclose(tot_s, tot_d, rtol=1e-3, atol=1e-4 * tot_d.abs().max().item())
+
+
+@pytest.mark.parametrize("r,cout,n", [(32, 64, 2048), (32, 32, 300), (16, 128, 1024)])
+def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
+    """lion_conv3d_tile_occupancy flags (margin 1 and 2) == max-pool dilation of the count grid reduced over
+    the tile footprint; each sample's work list is a permutation of its tiles with the occupied ones first."""
+    from lion_amd import _lib, fused_ops as fo
+    torch.manual_seed(r + n)
+    B = 5
+    coords = torch.randn(B, 3, n, device="cuda") * torch.tensor([1.0, 0.3, 0.7], device="cuda").view(1, 3, 1)
+    _, _, _, cnt = bk_().voxelize_points_forward(torch.randn(B, 4, n, device="cuda"), coords, r, True, 0.0)
+    occ1, occ2 = fo.conv3d_occupancy(cnt, r, cout, B)
+    nt = _lib.load().lion_conv3d_stat_tiles(r, cout, B, 1)
+    vb = 2  # sparse launches use the 2x2 MFMA tiles: (2,4,32) at r=32, (4,4,16) at r=16
+    td, th = (2, 4) if r == 32 else (4, 4)
+    g = (cnt.view(B, 1, r, r, r) > 0).float()
+    for occ, m in ((occ1, 1), (occ2, 2)):
+        d = torch.nn.functional.max_pool3d(g, 2 * m + 1, 1, m)[:, 0]
+        ref = d.view(B, r // td, td, r // th, th, r).amax(dim=(2, 4, 5)).reshape(B, nt).int()
+        flags = occ[:B * nt].view(B, nt)
+        assert torch.equal(flags, ref), m
+        lst = occ[B * nt:2 * B * nt].view(B, nt)
+        for b in range(B):
+            assert sorted(lst[b].tolist()) == list(range(nt))
+            k = int(ref[b].sum())
+            assert ref[b][lst[b][:k].long()].all() and not ref[b][lst[b][k:].long()].any()
+        assert int(occ[2 * B * nt]) == 0
