@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
                                                          const float *__restrict__ points, int M,
                                                          int N, float r2, int U,
                                                          int32_t *__restrict__ idx) {
+  __builtin_amdgcn_s_setprio(2); // runs on the geometry side stream next to the convolutions: see sampling.hip
   __shared__ float px[BQ_TILE], py[BQ_TILE], pz[BQ_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;

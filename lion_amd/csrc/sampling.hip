@@ -40,6 +40,10 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *sx = reinterpret_cast<float *>(smem); // [3][N] copy for the "coords[old]" lookup
   __shared__ unsigned long long wkey[2][4];
+  // 1023 dependent rounds on one workgroup per cloud: pure latency.  The sampler runs this chain on a side stream
+  // under the MFMA convolutions (lion_amd/geometry.py); raise the wave priority so that its few instructions per
+  // round issue ahead of the convolution waves sharing the SIMD instead of queueing behind them.
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
   const float *co = coords + (size_t)b * 3 * N;
   float x[PPT], y[PPT], z[PPT], td[PPT];

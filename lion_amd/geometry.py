@@ -22,7 +22,9 @@ _SIDE = {}
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        # high priority: the chain is latency bound (1356 serial FPS rounds) and must not queue behind the 400-us
+        # convolution workgroups it overlaps with
+        _SIDE[key] = torch.cuda.Stream(device=device, priority=-1)
     return _SIDE[key]
 
 
