@@ -47,8 +47,25 @@ def conv3d_k3(x, weight, bias=None):
     return y
 
 
+_DGRAD_CACHE = {}
+
+
+def dgrad_weight(weight):
+    """weights of the data-gradient convolution: grad_x = conv3d(grad_y, W'), W'[ci, co, kd, kh, kw] =
+    W[co, ci, 2-kd, 2-kh, 2-kw] (stride 1, padding 1: the transposed convolution is again a 3x3x3 / pad 1
+    convolution with the channels swapped and the taps mirrored); cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _DGRAD_CACHE.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wt = weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
+    _DGRAD_CACHE[id(weight)] = (key, wt)
+    return wt
+
+
 class _Conv3dK3(torch.autograd.Function):
-    """forward on the fp32 MFMA kernel; backward through ATen's convolution_backward (MIOpen)."""
+    """forward and data gradient on the fp32 MFMA kernel (the latter as the convolution with the mirrored,
+    channel-swapped weights); weight / bias gradients through ATen's convolution_backward (MIOpen)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -59,10 +76,16 @@ class _Conv3dK3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        cout, cin = weight.shape[:2]
+        own_dgrad = ctx.needs_input_grad[0] and supported(cout, cin, x.shape[2]) and cout % 4 == 0
         gx, gw, gb = torch.ops.aten.convolution_backward(
-            gy.contiguous(), x, weight, [weight.shape[0]] if ctx.has_bias else None,
+            gy, x, weight, [weight.shape[0]] if ctx.has_bias else None,
             [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+            [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1],
+             ctx.has_bias and ctx.needs_input_grad[2]])
+        if own_dgrad:
+            gx = conv3d_k3(gy, dgrad_weight(weight), None)
         return gx, gw, gb
 
 
