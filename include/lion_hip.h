@@ -183,13 +183,19 @@ int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxe
                         const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
                         float *A, float *Bs, float *chmean, lionStream_t stream);
 /* ---- D2: global denoiser, models/score_sde/resnet.py:60-90, :195-218 -----------------------------------
- * one 1x1 conv of the [B, C, 1, 1] style-latent network as a 32-row GEMM on channel-major activations
- * xT f32[nb][Cin][32] (batch padded to 32 per slab): yT[o][b] = epi(bias[o] + sum_k W[o,k] (xT[k][b] + addT[k][b])),
- * wp = lion_pwconv_pack_weights(w f32[Cout,Cin]); act 0 none / 1 relu; gate/resid f32[nb][Cout][32] (both or
- * neither): y = resid + gate * sigmoid(.)  (the squeeze-excite tail of ResBlockSEDrop).  Cout % 32 == 0. */
-int lion_skinny_gemm(const float *xT, const float *wp, const float *bias, int nb, int Cin, int Cout,
-                     const float *addT, int act, const float *gate, const float *resid, float *yT,
-                     lionStream_t stream);
+ * The 1x1 convs of the [B, C, 1, 1] style-latent network as 32-row GEMMs on channel-major activations
+ * f32[nb][C][32] (batch padded to 32 per slab), split over K into lion_skinny_splits workgroup rows that write raw
+ * partial tiles; the consumer's operand load sums the partials and applies the producer's bias / ReLU (+ an added
+ * tensor: ResBlockSEDrop's x + t), lion_skinny_finish applies the squeeze-excite tail or the last layer's bias.
+ * wp = lion_skinny_pack_weights(w f32[Cout,Cin]) (lion_skinny_packed_floats floats, tile-major, 4 k-steps per
+ * 16-byte lane load).  Cout % 32 == 0. */
+size_t lion_skinny_packed_floats(int Cout, int Cin);
+int lion_skinny_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream);
+int lion_skinny_splits(int Cin, int Cout);
+int lion_skinny_gemm(const float *pin, int ks_in, const float *bias_in, int act_in, const float *addT,
+                     const float *wp, int nb, int Cin, int Cout, float *pout, lionStream_t stream);
+int lion_skinny_finish(const float *A, int ks_a, const float *bias_a, const float *Bp, int ks_b, const float *resid,
+                       int nb, int C, int mode, float *y, lionStream_t stream);
 /* SE3d (pvcnn2_ada.py:27-41) on the folded scalars: A, Bs f32[B,C] are multiplied in place by
  * sigmoid(W2 relu(W1 (A*chmean + Bs))), w1 f32[H,C], w2 f32[C,H] (C <= 1024, H <= 128). */
 int lion_se_gate(const float *chmean, const float *w1, const float *w2, int B, int C, int H, float *A,

@@ -48,7 +48,11 @@ SIGNATURES = {
     "lion_conv3d_occupancy_ints": (_sz, [_i, _i, _i]),
     "lion_conv3d_tile_occupancy": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
-    "lion_skinny_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "lion_skinny_packed_floats": (_sz, [_i, _i]),
+    "lion_skinny_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lion_skinny_splits": (_i, [_i, _i]),
+    "lion_skinny_gemm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lion_skinny_finish": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "lion_se_gate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_trilinear_devoxelize_affine_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_row_stats": (_i, [_vp, _i, _i, _vp, _vp]),

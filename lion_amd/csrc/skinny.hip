@@ -1,61 +1,72 @@
 // skinny.hip -- D2: the 1x1 convolutions of the global (style-latent) denoiser, models/score_sde/resnet.py:60-90,
 // 124-218.  The activation is [B, C, 1, 1] with B = 32 and C = 2048: every layer is a GEMM with 32 rows
 // whose cost is streaming its weights once (16.8 MB for 2048x2048).  The library path spends ~15
-// launches per residual block (GEMM, bias, relu, SE GEMMs, sigmoid, mul, add ...), 154 per forward,
-// each a few microseconds of mostly launch latency.  Here a block is 4 launches of one kernel:
-//
-//   yT[o][b] = epi( bias[o] + sum_k Wt[k][o] * (xT[k][b] (+ addT[k][b])) )
+// launches per residual block (GEMM, bias, relu, SE GEMMs, sigmoid, mul, add ...), 154 per forward.
 //
 // * activations are kept channel-major, [C][32] with the batch on the fast axis, for the whole
 //   network: both MFMA operands of v_mfma_f32_32x32x2_f32 are then plain 128-byte row reads (A = 32
-//   output channels of the k-major packed weights, B = the 32 batch columns of xT) and the
-//   accumulator tile [32 outputs x 32 batch] is written back with coalesced rows;
-// * one workgroup of 16 waves owns a tile of 32 output channels and splits K over its waves (the
-//   partial tiles are reduced through LDS in a fixed order), so the weight stream of a layer is
-//   spread over Cout/32 CUs with >= 256 KB in flight each.  (Splitting K across workgroups with a
-//   last-arriver reduction was measured 2-3x slower: a device-scope fence writes back / invalidates
-//   the XCD's L2 on this multi-die part.);
-// * prologue: + time embedding (ResBlockSEDrop: conv1(x + t)); epilogue: bias, ReLU, or the whole
-//   squeeze-excite tail x + h * sigmoid(acc).
+//   output channels of the tile-major packed weights, B = the 32 batch columns) and the accumulator
+//   tile [32 outputs x 32 batch] is written back with coalesced rows;
+// * split-K WITHOUT in-kernel synchronisation: a layer is cut into (output tile, k-split) workgroups
+//   of 16 waves (one round of loads per wave, all in flight at once, then 16 MFMAs) that write RAW
+//   partial tiles P[ks][Cout][32]; the consumer sums the partials -- with the producer's bias and
+//   ReLU -- while it loads its operand, so the hand-over is the kernel boundary.  (A last-arriver
+//   reduction inside one launch was measured 2-3x slower: a device-scope fence writes back /
+//   invalidates the XCD's L2 on this multi-die part; 64 workgroups without split-K are MFMA bound
+//   at 17 us per layer.)
+// * the squeeze-excite tail x + h * sigmoid(.) and the last layer's bias go through one small
+//   element-wise kernel on the partials.
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// act: 0 none, 1 relu.  gate != NULL: y = resid + gate * sigmoid(acc + bias).
-__global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restrict__ xT, const float *__restrict__ wp,
-                                                           const float *__restrict__ bias, int Cin, int Cout,
-                                                           const float *__restrict__ addT, int act,
-                                                           const float *__restrict__ gate,
-                                                           const float *__restrict__ resid, float *__restrict__ yT) {
-  __shared__ float part[16][1024]; // per-wave partial tiles (64 KiB); row writes / column sums are conflict-free
+// operand element k of batch column b: act_in( sum_q Pin[q][k][b] + bias_in[k] ) + addT[k][b]
+__global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restrict__ pin, int ks_in,
+                                                           const float *__restrict__ bias_in, int act_in,
+                                                           const float *__restrict__ addT,
+                                                           const float *__restrict__ wp, int Cin, int Cout,
+                                                           float *__restrict__ pout) {
+  extern __shared__ __attribute__((aligned(16))) float smem[]; // [16][1024] per-wave partial tiles
+  float(*part)[1024] = reinterpret_cast<float(*)[1024]>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int o0 = blockIdx.x * 32, nb = blockIdx.y;
+  const int o0 = blockIdx.x * 32, ks = blockIdx.y, KS = gridDim.y, nb = blockIdx.z, NB = gridDim.z;
   const int cl = lane & 31, kh = lane >> 5;
-  const float *xb = xT + (size_t)nb * Cin * 32;
-  const float *ab = addT ? addT + (size_t)nb * Cin * 32 : nullptr;
   const int ksteps = (Cin + 1) >> 1;
-  const int per = (ksteps + 15) >> 4, s_lo = wave * per, s_hi = min(ksteps, s_lo + per);
+  const int ksteps4 = (ksteps + 3) >> 2; // k-steps padded to a multiple of 4
+  const float *wt = wp + (size_t)blockIdx.x * (ksteps4 * 8) * 32;
+  const size_t in_stride = (size_t)NB * Cin * 32; // one k-split slab of the input partials
+  const float *xb = pin + (size_t)nb * Cin * 32;
+  const float *ab = addT ? addT + (size_t)nb * Cin * 32 : nullptr;
+  const int per = ((ksteps + KS * 16 - 1) / (KS * 16) + 3) & ~3; // multiple of 4 k-steps per wave
+  const int s_lo = min(ksteps, (ks * 16 + wave) * per), s_hi = min(ksteps, s_lo + per);
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  constexpr int UN = 16; // k-steps whose loads are all issued before the first MFMA (4 / 8 / 16 measure the same)
+  // weights: packed [tile][k-step / 4][k-half][32 channels][4 k-steps] -> one 16-byte load per lane covers 4 k-steps
+  // (2 KiB per wave instruction); per-wave slices start on multiples of 4 k-steps.
+  constexpr int UN = 8;
+  const float4 *wt4 = reinterpret_cast<const float4 *>(wt);
   for (int s0 = s_lo; s0 < s_hi; s0 += UN) {
-    float av[UN], bv[UN], cv[UN];
+    float4 a4[UN / 4];
+    float bv[UN];
+#pragma unroll
+    for (int g = 0; g < UN / 4; ++g) a4[g] = wt4[((size_t)(min(s0 + 4 * g, ksteps4 * 4 - 4) >> 2) * 2 + kh) * 32 + cl];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int k = 2 * min(s0 + u, ksteps - 1) + kh; // packed weights have 2*ksteps rows (zero padded)
-      const int kc = min(k, Cin - 1);
-      av[u] = wp[(size_t)k * Cout + o0 + cl];
-      bv[u] = xb[(size_t)kc * 32 + cl];
-      cv[u] = ab ? ab[(size_t)kc * 32 + cl] : 0.f;
+      const int kc = min(2 * (s0 + u) + kh, Cin - 1);
+      float v = bias_in ? bias_in[kc] : 0.f;
+      for (int q = 0; q < ks_in; ++q) v += xb[q * in_stride + (size_t)kc * 32 + cl]; // fixed order
+      if (act_in == 1) v = v > 0.f ? v : 0.f;
+      if (ab) v += ab[(size_t)kc * 32 + cl];
+      bv[u] = v;
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int k = 2 * (s0 + u) + kh;
-      const float v = (s0 + u < s_hi && k < Cin) ? bv[u] + cv[u] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], v, acc, 0, 0, 0);
+      const float a = (u & 3) == 0 ? a4[u >> 2].x : (u & 3) == 1 ? a4[u >> 2].y : (u & 3) == 2 ? a4[u >> 2].z : a4[u >> 2].w;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, (s0 + u < s_hi && k < Cin) ? bv[u] : 0.f, acc, 0, 0, 0);
     }
   }
   // acc register i of lane l: output row (i&3) + 8*(i>>2) + 4*(l>>5), batch column l&31
@@ -65,30 +76,96 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restri
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < 16; ++w) s += part[w][tid]; // element (o = tid / 32, b = tid % 32), fixed order
-  const int o = o0 + (tid >> 5);
-  s += bias ? bias[o] : 0.f;
-  const size_t at = ((size_t)nb * Cout + o) * 32 + (tid & 31);
-  if (gate) s = resid[at] + gate[at] * (1.0f / (1.0f + expf(-s)));
-  else if (act == 1) s = s > 0.f ? s : 0.f;
-  yT[at] = s;
+  pout[((size_t)(ks * NB + nb) * Cout + o0 + (tid >> 5)) * 32 + (tid & 31)] = s;
+}
+
+// mode 0: y = sum_q A[q] + bias_a                               (last layer)
+// mode 1: y = resid + relu(sum_q A[q] + bias_a) * sigmoid(sum_q Bp[q])   (ResBlockSEDrop tail, resnet.py:77-86)
+__global__ __launch_bounds__(256) void skinny_finish_kernel(const float *__restrict__ A, int ks_a,
+                                                            const float *__restrict__ bias_a,
+                                                            const float *__restrict__ Bp, int ks_b,
+                                                            const float *__restrict__ resid, int n, int C,
+                                                            int mode, float *__restrict__ y) {
+  const int i = blockIdx.x * 256 + threadIdx.x; // element of [nb][C][32]
+  if (i >= n) return;
+  const int c = (i >> 5) % C;
+  float a = bias_a ? bias_a[c] : 0.f;
+  for (int q = 0; q < ks_a; ++q) a += A[(size_t)q * n + i];
+  if (mode == 1) {
+    float g = 0.f;
+    for (int q = 0; q < ks_b; ++q) g += Bp[(size_t)q * n + i];
+    a = resid[i] + (a > 0.f ? a : 0.f) * (1.0f / (1.0f + expf(-g)));
+  }
+  y[i] = a;
+}
+
+// element i of wp = [tile][s4][kh][j][e]: channel tile*32 + j, input k = 2*(4*s4 + e) + kh
+__global__ void skinny_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int ksteps4,
+                                   float *__restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * ksteps4 * 8) return;
+  const int e = i & 3, j = (i >> 2) & 31, kh = (i >> 7) & 1, s4 = (i >> 8) % ksteps4, t = i / (256 * ksteps4);
+  const int k = 2 * (4 * s4 + e) + kh;
+  wp[i] = k < Cin ? w[(size_t)(t * 32 + j) * Cin + k] : 0.f;
 }
 
 } // namespace
 
 extern "C" {
 
-// xT f32[nb][Cin][32] (channel-major activations, batch padded to 32 per slab), wp = lion_pwconv_pack_weights
-// of w f32[Cout,Cin] (k-major [ceil2(Cin)][Cout]), bias f32[Cout] or NULL, addT f32[nb][Cin][32] or NULL
-// (added to the input), act 0 none / 1 relu; gate/resid f32[nb][Cout][32] (both or neither):
-// y = resid + gate * sigmoid(acc + bias).  Cout % 32 == 0.  -> yT f32[nb][Cout][32].
-int lion_skinny_gemm(const float *xT, const float *wp, const float *bias, int nb, int Cin, int Cout,
-                     const float *addT, int act, const float *gate, const float *resid, float *yT,
-                     lionStream_t stream) {
-  if (!xT || !wp || !yT || nb <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
-  if ((gate == nullptr) != (resid == nullptr) || act < 0 || act > 1) return LION_EINVAL;
+// floats of the packed copy: Cout * 8 * ceil(ceil(Cin / 2) / 4)
+size_t lion_skinny_packed_floats(int Cout, int Cin) { return (size_t)Cout * 8 * (((Cin + 1) / 2 + 3) / 4); }
+
+// w f32[Cout,Cin] -> wp f32[Cout/32][ceil(ksteps/4)][2][32][4] (zero padded k), Cout % 32 == 0
+int lion_skinny_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream) {
+  if (!w || !wp || Cout <= 0 || Cin <= 0) return LION_EINVAL;
   if (Cout % 32 != 0) return LION_EUNSUPPORTED;
-  skinny_gemm_kernel<<<dim3(Cout / 32, nb), 1024, 0, static_cast<hipStream_t>(stream)>>>(
-      xT, wp, bias, Cin, Cout, addT, act, gate, resid, yT);
+  const int ksteps4 = ((Cin + 1) / 2 + 3) / 4, total = Cout * ksteps4 * 8;
+  skinny_pack_kernel<<<lion_cdiv(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cout, Cin, ksteps4, wp);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// k-splits of a layer: ~256 workgroups, at least 8 k-steps per wave
+int lion_skinny_splits(int Cin, int Cout) {
+  if (Cout <= 0 || Cout % 32 != 0 || Cin <= 0) return 0;
+  const int tiles = Cout / 32, ksteps = (Cin + 1) / 2;
+  int ks = 1;
+  while (ks < 8 && tiles * ks * 2 <= 256 && ksteps / (ks * 2 * 16) >= 8) ks *= 2; // >= 8 k-steps per wave
+  return ks;
+}
+
+// One layer: pout f32[lion_skinny_splits(Cin,Cout)][nb][Cout][32] (raw partial sums, no bias) from the operand
+// act_in(sum_q pin[q] + bias_in) + addT, pin f32[ks_in][nb][Cin][32] (ks_in = 1 for a plain activation),
+// bias_in f32[Cin] or NULL, act_in 0 none / 1 relu, addT f32[nb][Cin][32] or NULL; wp = lion_skinny_pack_weights.
+int lion_skinny_gemm(const float *pin, int ks_in, const float *bias_in, int act_in, const float *addT,
+                     const float *wp, int nb, int Cin, int Cout, float *pout, lionStream_t stream) {
+  if (!pin || !wp || !pout || nb <= 0 || Cin <= 0 || Cout <= 0 || ks_in < 1 || act_in < 0 || act_in > 1)
+    return LION_EINVAL;
+  if (Cout % 32 != 0) return LION_EUNSUPPORTED;
+  const size_t lds = (size_t)16 * 1024 * 4;
+  static bool cfg = false;
+  if (!cfg) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_gemm_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    cfg = true;
+  }
+  skinny_gemm_kernel<<<dim3(Cout / 32, lion_skinny_splits(Cin, Cout), nb), 1024, lds, static_cast<hipStream_t>(stream)>>>(
+      pin, ks_in, bias_in, act_in, addT, wp, Cin, Cout, pout);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// y f32[nb][C][32] from partials: mode 0: sum_q A[q] + bias_a; mode 1: resid + relu(sum_q A[q] + bias_a) *
+// sigmoid(sum_q Bp[q]).  A f32[ks_a][nb][C][32], Bp f32[ks_b][nb][C][32].
+int lion_skinny_finish(const float *A, int ks_a, const float *bias_a, const float *Bp, int ks_b, const float *resid,
+                       int nb, int C, int mode, float *y, lionStream_t stream) {
+  if (!A || !y || nb <= 0 || C <= 0 || ks_a < 1 || (mode != 0 && mode != 1)) return LION_EINVAL;
+  if (mode == 1 && (!Bp || !resid || ks_b < 1)) return LION_EINVAL;
+  const int n = nb * C * 32;
+  skinny_finish_kernel<<<lion_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(A, ks_a, bias_a, Bp, ks_b,
+                                                                                        resid, n, C, mode, y);
   LION_LAUNCH_CHECK();
   return 0;
 }

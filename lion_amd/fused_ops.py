@@ -275,14 +275,46 @@ def from_channel_major(xt, b):
     return xt.transpose(1, 2).reshape(nb * 32, c)[:b].reshape(b, c, 1, 1).contiguous()
 
 
-def skinny_conv(xt, conv, add=None, act=0, gate=None, resid=None):
-    """one 1x1 conv of the global denoiser on [nb, Cin, 32] activations (see lion_skinny_gemm)."""
-    nb, cin, _ = xt.shape
+_SK_CACHE = {}
+
+
+def skinny_packed_weight(weight):
+    """[Cout,Cin,1,1] -> tile-major packed copy (lion_skinny_pack_weights); cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _SK_CACHE.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    cout, cin = weight.shape[:2]
+    wp = torch.empty((_lib.load().lion_skinny_packed_floats(cout, cin),), device=weight.device, dtype=torch.float32)
+    w_c = weight.detach().reshape(cout, cin).contiguous()
+    _lib.check(_lib.load().lion_skinny_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
+                                                    _lib.stream_ptr(weight.device)), "skinny_pack_weights")
+    _SK_CACHE[id(weight)] = (key, wp)
+    return wp
+
+
+def skinny_conv(pin, conv, bias_in=None, act_in=0, add=None):
+    """one 1x1 conv of the global denoiser: pin [ks_in, nb, Cin, 32] partials (or [nb, Cin, 32]) -> raw partial
+    sums [ks, nb, Cout, 32] of conv.weight @ (act_in(sum pin + bias_in) + add); conv.bias is applied by the
+    consumer (see lion_skinny_gemm)."""
+    lib = _lib.load()
+    if pin.dim() == 3:
+        pin = pin.unsqueeze(0)
+    ks_in, nb, cin, _ = pin.shape
     cout = conv.out_channels
-    wp = pw_packed_weight(conv.weight)
-    y = torch.empty((nb, cout, 32), device=xt.device, dtype=torch.float32)
-    bias = conv.bias.detach() if conv.bias is not None else None
-    _lib.check(_lib.load().lion_skinny_gemm(_lib.ptr(xt), _lib.ptr(wp), _lib.ptr(bias), nb, cin, cout,
-                                            _lib.ptr(add), int(act), _lib.ptr(gate), _lib.ptr(resid), _lib.ptr(y),
-                                            _lib.stream_ptr(xt.device)), "skinny_gemm")
+    wp = skinny_packed_weight(conv.weight)
+    out = torch.empty((lib.lion_skinny_splits(cin, cout), nb, cout, 32), device=pin.device, dtype=torch.float32)
+    _lib.check(lib.lion_skinny_gemm(_lib.ptr(pin), ks_in, _lib.ptr(bias_in), int(act_in), _lib.ptr(add), _lib.ptr(wp),
+                                    nb, cin, cout, _lib.ptr(out), _lib.stream_ptr(pin.device)), "skinny_gemm")
+    return out
+
+
+def skinny_finish(A, bias_a, Bp=None, resid=None):
+    """[nb, C, 32] from partials: sum A + bias_a (Bp None) or resid + relu(sum A + bias_a) * sigmoid(sum Bp)."""
+    ks_a, nb, c, _ = A.shape
+    y = torch.empty((nb, c, 32), device=A.device, dtype=torch.float32)
+    _lib.check(_lib.load().lion_skinny_finish(_lib.ptr(A), ks_a, _lib.ptr(bias_a), _lib.ptr(Bp),
+                                              0 if Bp is None else Bp.shape[0], _lib.ptr(resid), nb, c,
+                                              0 if Bp is None else 1, _lib.ptr(y), _lib.stream_ptr(A.device)),
+               "skinny_finish")
     return y

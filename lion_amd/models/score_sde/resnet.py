@@ -160,13 +160,16 @@ class Prior(nn.Module):
         if temb.shape[0] == 1 and b > 1:
             temb = temb.expand(b, -1, -1, -1)
         tt = fo.to_channel_major(temb)
-        h = fo.skinny_conv(fo.to_channel_major(x), self.input_layer)
+        bias = lambda conv: conv.bias.detach() if conv.bias is not None else None  # noqa: E731
+        h = fo.skinny_finish(fo.skinny_conv(fo.to_channel_major(x), self.input_layer), bias(self.input_layer))
         for blk in self.all_modules:
-            h1 = fo.skinny_conv(h, blk.conv1, add=tt, act=1)
-            h2 = fo.skinny_conv(h1, blk.conv2, act=1)
-            s = fo.skinny_conv(h2, blk.SE.fc[0], act=1)
-            h = fo.skinny_conv(s, blk.SE.fc[2], gate=h2, resid=h)
-        return fo.from_channel_major(fo.skinny_conv(h, self.output_layer), b)
+            p1 = fo.skinny_conv(h, blk.conv1, add=tt)                               # conv1(x + t)
+            p2 = fo.skinny_conv(p1, blk.conv2, bias_in=bias(blk.conv1), act_in=1)   # conv2(relu(. + b1))
+            p3 = fo.skinny_conv(p2, blk.SE.fc[0], bias_in=bias(blk.conv2), act_in=1)  # fc1(h2), h2 = relu(. + b2)
+            p4 = fo.skinny_conv(p3, blk.SE.fc[2], act_in=1)                         # fc2(relu(.))
+            h = fo.skinny_finish(p2, bias(blk.conv2), p4, h)                        # x + h2 * sigmoid(.)
+        out = fo.skinny_finish(fo.skinny_conv(h, self.output_layer), bias(self.output_layer))
+        return fo.from_channel_major(out, b)
 
 
 class PriorSEDrop(Prior):

@@ -427,24 +427,32 @@ def test_pwconv_matches_fp64_reference(cin, cout, L, pro):
     assert _lib.load().lion_pwconv_stat_tiles(cout, L) == st.shape[2]
 
 
-@pytest.mark.parametrize("cin,cout,B", [(2048, 2048, 32), (2048, 256, 32), (128, 2048, 5), (256, 128, 40)])
-def test_skinny_gemm_matches_fp64_reference(cin, cout, B):
-    """D2: 32-row GEMM on channel-major activations (lion_skinny_gemm): add prologue, ReLU epilogue and
-    the squeeze-excite tail x + h * sigmoid(.), batch padding (B = 5) and two slabs (B = 40)."""
+@pytest.mark.parametrize("cin,cmid,cout,B", [(2048, 2048, 256, 32), (128, 2048, 2048, 5), (256, 128, 64, 40)])
+def test_skinny_gemm_chain_matches_fp64_reference(cin, cmid, cout, B):
+    """D2: split-K 32-row GEMMs on channel-major activations with the deferred epilogue (lion_skinny_gemm /
+    lion_skinny_finish): conv(x + t), then conv(relu(. + b1)) consuming the raw partials, the plain finish and the
+    squeeze-excite tail; batch padding (B = 5) and two slabs (B = 40)."""
     from lion_amd import fused_ops as fo
     torch.manual_seed(cin + B)
-    conv = torch.nn.Conv2d(cin, cout, 1).cuda()
+    c1 = torch.nn.Conv2d(cin, cmid, 1).cuda()
+    c2 = torch.nn.Conv2d(cmid, cout, 1).cuda()
     x = torch.randn(B, cin, 1, 1, device="cuda")
     t = torch.randn(B, cin, 1, 1, device="cuda")
-    w, bias = conv.weight.double()[:, :, 0, 0], conv.bias.double()
-    ref = torch.relu((x + t).double()[:, :, 0, 0] @ w.t() + bias)
-    got = fo.from_channel_major(fo.skinny_conv(fo.to_channel_major(x), conv, add=fo.to_channel_major(t), act=1), B)
+    w1, b1 = c1.weight.double()[:, :, 0, 0], c1.bias.double()
+    w2, b2 = c2.weight.double()[:, :, 0, 0], c2.bias.double()
+    h1 = (x + t).double()[:, :, 0, 0] @ w1.t() + b1
+    ref = torch.relu(h1) @ w2.t() + b2
+    p1 = fo.skinny_conv(fo.to_channel_major(x), c1, add=fo.to_channel_major(t))
+    got1 = fo.from_channel_major(fo.skinny_finish(p1, c1.bias.detach()), B)
+    assert (got1.double()[:, :, 0, 0] - h1).abs().max().item() / h1.abs().max().item() < 1e-5
+    p2 = fo.skinny_conv(p1, c2, bias_in=c1.bias.detach(), act_in=1)
+    got = fo.from_channel_major(fo.skinny_finish(p2, c2.bias.detach()), B)
     assert (got.double()[:, :, 0, 0] - ref).abs().max().item() / ref.abs().max().item() < 1e-5
-    h = torch.randn(B, cout, 1, 1, device="cuda")
     res = torch.randn(B, cout, 1, 1, device="cuda")
-    ref2 = res.double()[:, :, 0, 0] + h.double()[:, :, 0, 0] * torch.sigmoid(x.double()[:, :, 0, 0] @ w.t() + bias)
-    got2 = fo.from_channel_major(fo.skinny_conv(fo.to_channel_major(x), conv, gate=fo.to_channel_major(h),
-                                                resid=fo.to_channel_major(res)), B)
+    gate = torch.randn(1, *p2.shape[1:], device="cuda")  # a one-split "partial" as the gate pre-activation
+    gate_b = fo.from_channel_major(gate[0], B).double()[:, :, 0, 0]
+    ref2 = res.double()[:, :, 0, 0] + torch.relu(ref) * torch.sigmoid(gate_b)
+    got2 = fo.from_channel_major(fo.skinny_finish(p2, c2.bias.detach(), gate, fo.to_channel_major(res)), B)
     assert (got2.double()[:, :, 0, 0] - ref2).abs().max().item() / ref2.abs().max().item() < 1e-5
 
 
