@@ -2,33 +2,13 @@
 third_party/pvcnn/functional/sampling.py:11-100."""
 import numpy as np
 import torch
-from torch.autograd import Function
-
 from . import backend as _bk
+from ._indexed import indexed_op
 
 __all__ = ["gather", "furthest_point_sample", "logits_mask"]
 
 
-class Gather(Function):
-    """features f32[B,C,N], indices int[B,M] -> f32[B,C,M]."""
-
-    @staticmethod
-    def forward(ctx, features, indices):
-        features = features.contiguous()
-        indices = indices.int().contiguous()
-        ctx.save_for_backward(indices)
-        ctx.num_points = features.size(-1)
-        return _bk._backend.gather_features_forward(features, indices)
-
-    @staticmethod
-    def backward(ctx, grad_output):
-        indices, = ctx.saved_tensors
-        grad_features = _bk._backend.gather_features_backward(grad_output.contiguous(), indices,
-                                                              ctx.num_points)
-        return grad_features, None
-
-
-gather = Gather.apply
+gather = indexed_op("gather_features")  # features f32[B,C,N], indices int[B,M] -> f32[B,C,M]
 
 
 def furthest_point_sample(coords, num_samples, normals=None):
