@@ -35,65 +35,55 @@ class PVCNN2Unet(nn.Module):
                  verbose=True, condition_input=False, point_as_feat=1, cfg={}, sa_blocks={},
                  fp_blocks={}, clip_forge_enable=0, clip_forge_dim=512):
         super().__init__()
-        self.input_dim = input_dim
-        self.clip_forge_enable = clip_forge_enable
-        self.sa_blocks = sa_blocks
-        self.fp_blocks = fp_blocks
-        self.point_as_feat = point_as_feat
-        self.condition_input = condition_input
-        assert extra_feature_channels >= 0
-        self.time_emb_scales = time_emb_scales
-        self.embed_dim = embed_dim
-        if self.embed_dim > 0:  # priors have a time embedding, the VAE networks do not
-            self.embedf = nn.Sequential(
-                nn.Linear(embed_dim, embed_dim),
-                nn.LeakyReLU(0.1, inplace=True),
-                nn.Linear(embed_dim, embed_dim))
-        if self.clip_forge_enable:
+        if extra_feature_channels < 0:
+            raise AssertionError("extra_feature_channels must be >= 0")
+        for name, value in (("input_dim", input_dim), ("clip_forge_enable", clip_forge_enable),
+                            ("sa_blocks", sa_blocks), ("fp_blocks", fp_blocks), ("point_as_feat", point_as_feat),
+                            ("condition_input", condition_input), ("time_emb_scales", time_emb_scales),
+                            ("embed_dim", embed_dim), ("in_channels", extra_feature_channels + 3)):
+            setattr(self, name, value)
+        # registration order below == the reference's (state_dict key order is part of the checkpoint format)
+        if embed_dim > 0:  # the priors carry a time embedding, the VAE networks do not
+            self.embedf = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.LeakyReLU(0.1, inplace=True),
+                                        nn.Linear(embed_dim, embed_dim))
+        if clip_forge_enable:
+            d_style = cfg.latent_pts.style_dim
             self.clip_forge_mapping = nn.Linear(clip_forge_dim, embed_dim)
-            style_dim = cfg.latent_pts.style_dim
-            self.style_clip = nn.Linear(style_dim + embed_dim, style_dim)
-        self.in_channels = extra_feature_channels + 3
+            self.style_clip = nn.Linear(d_style + embed_dim, d_style)
 
-        sa_layers, sa_in_channels, channels_sa_features, _ = create_pointnet2_sa_components(
-            input_dim=input_dim, sa_blocks=self.sa_blocks,
-            extra_feature_channels=extra_feature_channels, with_se=True, embed_dim=embed_dim,
-            use_att=use_att, dropout=dropout, width_multiplier=width_multiplier,
-            voxel_resolution_multiplier=voxel_resolution_multiplier, verbose=verbose, cfg=cfg)
-        self.sa_layers = nn.ModuleList(sa_layers)
-        self.global_att = None if not use_att else LinearAttention(channels_sa_features, 8, verbose=verbose)
-
-        sa_in_channels[0] = extra_feature_channels + input_dim - 3  # extra features only in the last FP
-        fp_layers, channels_fp_features = create_pointnet2_fp_modules(
-            fp_blocks=self.fp_blocks, in_channels=channels_sa_features,
-            sa_in_channels=sa_in_channels, with_se=True, embed_dim=embed_dim, use_att=use_att,
-            dropout=dropout, width_multiplier=width_multiplier,
-            voxel_resolution_multiplier=voxel_resolution_multiplier, verbose=verbose, cfg=cfg)
-        self.fp_layers = nn.ModuleList(fp_layers)
-
-        layers, _ = create_mlp_components(
-            in_channels=channels_fp_features, out_channels=[128, dropout, num_classes],
-            classifier=True, dim=2, width_multiplier=width_multiplier, cfg=cfg)
-        self.classifier = nn.ModuleList(layers)
+        shared = dict(with_se=True, embed_dim=embed_dim, use_att=use_att, dropout=dropout, cfg=cfg,
+                      width_multiplier=width_multiplier, voxel_resolution_multiplier=voxel_resolution_multiplier,
+                      verbose=verbose)
+        down, skip_channels, c_bottom, _ = create_pointnet2_sa_components(
+            sa_blocks=sa_blocks, extra_feature_channels=extra_feature_channels, input_dim=input_dim, **shared)
+        self.sa_layers = nn.ModuleList(down)
+        self.global_att = LinearAttention(c_bottom, 8, verbose=verbose) if use_att else None
+        skip_channels[0] = extra_feature_channels + input_dim - 3  # the raw xyz is not fed back to the last FP stage
+        up, c_top = create_pointnet2_fp_modules(fp_blocks=fp_blocks, in_channels=c_bottom,
+                                                sa_in_channels=skip_channels, **shared)
+        self.fp_layers = nn.ModuleList(up)
+        head, _ = create_mlp_components(in_channels=c_top, out_channels=[128, dropout, num_classes], classifier=True,
+                                        dim=2, width_multiplier=width_multiplier, cfg=cfg)
+        self.classifier = nn.ModuleList(head)
 
     def get_timestep_embedding(self, timesteps, device):
-        """sinusoidal embedding, frequencies built in float64 numpy then cast (reference :101-115)."""
-        if len(timesteps.shape) == 2 and timesteps.shape[1] == 1:
-            timesteps = timesteps[:, 0]
-        assert len(timesteps.shape) == 1, f'get shape: {timesteps.shape}'
-        timesteps = timesteps * self.time_emb_scales
-        half_dim = self.embed_dim // 2
-        cache = self.__dict__.setdefault('_freq_cache', {})  # per device; a per-call H2D copy is not graph-capturable
-        freq = cache.get(device)
-        if freq is None:
-            scale = np.log(10000) / (half_dim - 1)
-            freq = torch.from_numpy(np.exp(np.arange(0, half_dim) * -scale)).float().to(device)
-            cache[device] = freq
-        emb = timesteps[:, None] * freq[None, :]
-        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
-        if self.embed_dim % 2 == 1:
+        """[sin, cos] of t * time_emb_scales * 10000^(-i/(half-1)); the frequency row is built in float64 numpy and
+        cast, as in the reference (:101-115), but once per device (a per-call host->device copy is not
+        graph-capturable); odd embed_dim is zero-padded by one column."""
+        if timesteps.dim() == 2 and timesteps.shape[1] == 1:
+            timesteps = timesteps.squeeze(1)
+        if timesteps.dim() != 1:
+            raise AssertionError(f"get shape: {timesteps.shape}")
+        rows = self.__dict__.setdefault("_freq_cache", {})
+        row = rows.get(device)
+        if row is None:
+            half = self.embed_dim // 2
+            row = torch.from_numpy(np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))).float().to(device)
+            rows[device] = row
+        ang = (timesteps * self.time_emb_scales).unsqueeze(1) * row.unsqueeze(0)
+        emb = torch.cat((ang.sin(), ang.cos()), dim=1)
+        if self.embed_dim % 2:
             emb = nn.functional.pad(emb, (0, 1), "constant", 0)
-        assert emb.shape == torch.Size([timesteps.shape[0], self.embed_dim])
         return emb
 
     def forward(self, inputs, **kwargs):
