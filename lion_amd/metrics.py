@@ -140,3 +140,61 @@ def compute_all_metrics(sample_pcs, ref_pcs, batch_size=256, verbose=False, acce
         one_nn = knn(M_rr, M_rs, M_ss, 1, sqrt=False)
         results.update({"1-NN-%s-%s" % (metric, k): v.item() for k, v in one_nn.items() if 'acc' in k})
     return results
+
+
+# ---- JSD between the occupancy histograms of two point-cloud sets ------------------------------------------
+# (utils/evaluation_metrics_fast.py:563-647, after latent_3d_points; the reference runs a CPU sklearn nearest-
+# neighbour search per cloud -- here the whole set is assigned on the device in one batched distance + argmin)
+
+def unit_cube_grid_point_cloud(resolution, clip_sphere=False, device=None):
+    """centres of the resolution^3 cells of the unit cube [-0.5, 0.5]^3 (x slowest), optionally only those inside
+    the unit-diameter sphere; returns (grid [G,3], spacing)."""
+    spacing = 1.0 / float(resolution - 1)
+    axis = torch.arange(resolution, dtype=torch.float32, device=device) * spacing - 0.5
+    grid = torch.stack(torch.meshgrid(axis, axis, axis, indexing="ij"), dim=-1).reshape(-1, 3)
+    if clip_sphere:
+        grid = grid[grid.norm(dim=1) <= 0.5]
+    return grid, spacing
+
+
+def occupancy_histogram(pclouds, resolution=28, in_sphere=True, chunk=64):
+    """(entropy of the per-cell Bernoulli occupancy, per-cell point counts [G]) of a set of clouds [S,N,3]:
+    every point votes for its nearest grid cell (reference :601-640)."""
+    pclouds = torch.as_tensor(pclouds, dtype=torch.float32)
+    grid, _ = unit_cube_grid_point_cloud(resolution, in_sphere, device=pclouds.device)
+    counts = torch.zeros(grid.shape[0], dtype=torch.float64, device=pclouds.device)
+    hits = torch.zeros_like(counts)
+    g2 = (grid * grid).sum(1)
+    for s0 in range(0, pclouds.shape[0], chunk):
+        pc = pclouds[s0:s0 + chunk]
+        # argmin_g |p - g|^2 = argmin_g (|g|^2 - 2 p.g)
+        idx = (g2[None, None, :] - 2.0 * pc @ grid.t()).argmin(dim=-1)          # [s, N]
+        counts += torch.bincount(idx.reshape(-1), minlength=grid.shape[0]).double()
+        onehot = torch.zeros(pc.shape[0], grid.shape[0], dtype=torch.bool, device=pc.device)
+        onehot.scatter_(1, idx, True)
+        hits += onehot.sum(0).double()
+    p = hits / float(pclouds.shape[0])
+    nz = p[(p > 0) & (p < 1)]
+    ent = -(nz * nz.log() + (1 - nz) * (1 - nz).log()).sum() / grid.shape[0]
+    return float(ent), counts
+
+
+def jensen_shannon_divergence(P, Q):
+    """base-2 JSD of two non-negative histograms (normalised here), reference :643-660."""
+    P, Q = torch.as_tensor(P, dtype=torch.float64), torch.as_tensor(Q, dtype=torch.float64)
+    if (P < 0).any() or (Q < 0).any():
+        raise ValueError("Negative values.")
+    if P.numel() != Q.numel():
+        raise ValueError("Non equal size.")
+    P, Q = P / P.sum(), Q / Q.sum()
+
+    def h(x):
+        x = x[x > 0]
+        return -(x * x.log2()).sum()
+    return float(h(0.5 * (P + Q)) - 0.5 * (h(P) + h(Q)))
+
+
+def jsd_between_point_cloud_sets(sample_pcs, ref_pcs, resolution=28):
+    """JSD between the voxel-occupancy histograms of two sets of clouds in the unit sphere (reference :587-598)."""
+    return jensen_shannon_divergence(occupancy_histogram(sample_pcs, resolution, True)[1],
+                                     occupancy_histogram(ref_pcs, resolution, True)[1])
