@@ -172,8 +172,14 @@ def main():
             # local-prior forward are replayed without host launch overhead
             from lion_amd.graph import GraphedDenoiser
             t0_ = torch.full((B,), 1000.0, device=dev)
-            glob = GraphedDenoiser(glob, xg, t0_, None)
-            local = GraphedDenoiser(local, xl, t0_, style)
+            try:
+                glob_g = GraphedDenoiser(glob, xg, t0_, None)
+                local_g = GraphedDenoiser(local, xl, t0_, style)
+                glob, local = glob_g, local_g
+            except Exception as e:  # a failed capture must not cost the measurement: run eagerly and say so
+                print(f"bench: hipGraph capture failed ({e!r}); falling back to eager launches", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                args.no_graph = True
         # warm-up (untimed): W steps of each prior
         ddim_steps(glob, xg, None, 0, W)
         ddim_steps(local, xl, style, 0, W)
