@@ -124,6 +124,9 @@ int lion_chamfer_backward(const float *xyz1, const float *xyz2, const float *gdi
 size_t lion_emd_workspace_bytes(int B, int N, int M);
 int lion_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int N, int M,
                          float *match, void *ws, size_t ws_bytes, lionStream_t stream);
+/* evaluation path (emd_nograd.py:19-44): approxmatch + matchcost without the [B,N,M] match matrix -> cost f32[B] */
+int lion_emd_cost(const float *xyz1, const float *xyz2, int B, int N, int M, float *cost, void *ws,
+                  size_t ws_bytes, lionStream_t stream);
 int lion_emd_matchcost(const float *xyz1, const float *xyz2, const float *match, int B, int N,
                        int M, float *cost, void *ws, size_t ws_bytes, lionStream_t stream);
 int lion_emd_matchcost_backward(const float *grad_cost, const float *xyz1, const float *xyz2,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "lion_chamfer_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_emd_workspace_bytes": (_sz, [_i, _i, _i]),
     "lion_emd_approxmatch": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lion_emd_cost": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lion_emd_matchcost": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lion_emd_matchcost_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_conv3d_packed_floats": (_sz, [_i, _i]),

@@ -133,6 +133,58 @@ __global__ __launch_bounds__(256) void emd_pass3_kernel(const float *__restrict_
   if (k < n) remainL[(size_t)b * n + k] = fmaxf(0.0f, sub_rn(remainL[(size_t)b * n + k], suml));
 }
 
+// pass 3 without the match matrix (evaluation path, emd_nograd.py:19-44 only needs the cost): the reference builds
+// match[b][l][k] (16.8 MB per pair at 2048^2, read and rewritten at each of the 10 levels) and then sums
+// match * d^2; the sum over levels commutes with that product, so row k accumulates sum_l w * d^2 on the fly
+// (ascending l, levels in order) and nothing of size N*M ever reaches memory.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void emd_pass3_cost_kernel(const float *__restrict__ xyz1,
+                                                             const float *__restrict__ xyz2, int n, int m,
+                                                             float level, const float *__restrict__ ratioL,
+                                                             const float *__restrict__ ratioR,
+                                                             float *__restrict__ remainL,
+                                                             float *__restrict__ costrow) {
+  __shared__ float4 tile[EMD_TILE];
+  const int tid = threadIdx.x, b = blockIdx.y, k = blockIdx.x * 256 + tid;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  float x1 = 0, y1 = 0, z1 = 0, rl = 0;
+  if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; rl = ratioL[(size_t)b * n + k]; }
+  float suml = 0, crow = 0;
+  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, m - l0);
+    __syncthreads();
+    for (int l = tid; l < ln; l += 256)
+      tile[l] = make_float4(p2[(size_t)(l0 + l) * 3], p2[(size_t)(l0 + l) * 3 + 1],
+                            p2[(size_t)(l0 + l) * 3 + 2], ratioR[(size_t)b * m + l0 + l]);
+    __syncthreads();
+#pragma unroll 4
+    for (int l = 0; l < ln; ++l) {
+      const float4 v = tile[l];
+      const float d2 = sqdist3(v.x, v.y, v.z, x1, y1, z1);
+      const float w = mul_rn(mul_rn(__expf(mul_rn(level, d2)), rl), v.w);
+      suml = add_rn(suml, w);
+      crow = add_rn(crow, mul_rn(d2, w));
+    }
+  }
+  if (k < n) {
+    remainL[(size_t)b * n + k] = fmaxf(0.0f, sub_rn(remainL[(size_t)b * n + k], suml));
+    costrow[(size_t)b * n + k] = FIRST ? crow : add_rn(costrow[(size_t)b * n + k], crow);
+  }
+}
+
+// cost[b] = sum_k costrow[b][k]: 256 strided partials, then a fixed tree (deterministic)
+__global__ __launch_bounds__(256) void emd_costrow_sum_kernel(const float *__restrict__ costrow, int n,
+                                                              float *__restrict__ cost) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0;
+  for (int k = tid; k < n; k += 256) s = add_rn(s, costrow[(size_t)b * n + k]);
+  for (int q = 32; q >= 1; q >>= 1) s = add_rn(s, __shfl_xor(s, q, 64));
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) cost[b] = add_rn(add_rn(red[0], red[1]), add_rn(red[2], red[3]));
+}
+
 // matchcost (emd_kernel.cu:199-241): per-k partial sums over l, reduced per block into
 // partial[b][block]; a second tiny kernel sums the partials in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void emd_cost_partial_kernel(const float *__restrict__ xyz1,
@@ -250,8 +302,8 @@ __global__ __launch_bounds__(256) void emd_grad2_kernel(const float *__restrict_
 
 static size_t emd_ws_floats(int B, int N, int M) {
   const size_t nb = (size_t)lion_cdiv(N, 256);
-  // remainL[B,N] remainR[B,M] ratioL[B,N] ratioR[B,M] partial[B,nb]
-  return (size_t)B * (2 * (size_t)N + 2 * (size_t)M + nb) + 64;
+  // remainL[B,N] remainR[B,M] ratioL[B,N] ratioR[B,M] partial[B,nb] costrow[B,N]
+  return (size_t)B * (3 * (size_t)N + 2 * (size_t)M + nb) + 64;
 }
 
 } // namespace
@@ -288,6 +340,38 @@ int lion_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int N, int
     else
       emd_pass3_kernel<false><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, ratioR, remainL, match);
   }
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// approxmatch + matchcost in one call without materialising match (no-grad evaluation path): cost f32[B].
+int lion_emd_cost(const float *xyz1, const float *xyz2, int B, int N, int M, float *cost, void *ws,
+                  size_t ws_bytes, lionStream_t stream) {
+  if (!xyz1 || !xyz2 || !cost || B <= 0 || N <= 0 || M <= 0) return LION_EINVAL;
+  if (!ws || ws_bytes < lion_emd_workspace_bytes(B, N, M)) return LION_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float *remainL = static_cast<float *>(ws);
+  float *remainR = remainL + (size_t)B * N;
+  float *ratioL = remainR + (size_t)B * M;
+  float *ratioR = ratioL + (size_t)B * N;
+  float *costrow = ratioR + (size_t)B * M + (size_t)B * lion_cdiv(N, 256);
+  float multiL, multiR; // emd_kernel.cu:27-33 (integer division)
+  if (N >= M) { multiL = 1.f; multiR = (float)(N / M); }
+  else { multiL = (float)(M / N); multiR = 1.f; }
+  const int nmax = N > M ? N : M;
+  emd_init_kernel<<<dim3(lion_cdiv(nmax, 256), B), 256, 0, st>>>(N, M, multiL, multiR, remainL, remainR);
+  const dim3 gn(lion_cdiv(N, 256), B), gm(lion_cdiv(M, 256), B);
+  for (int j = 7; j >= -2; --j) {
+    float level = -powf(4.0f, (float)j); // :45-48
+    if (j == -2) level = 0.f;
+    emd_pass1_kernel<<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, remainL, remainR, ratioL);
+    emd_pass2_kernel<<<gm, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, remainR, ratioR);
+    if (j == 7)
+      emd_pass3_cost_kernel<true><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, ratioR, remainL, costrow);
+    else
+      emd_pass3_cost_kernel<false><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, ratioR, remainL, costrow);
+  }
+  emd_costrow_sum_kernel<<<B, 256, 0, st>>>(costrow, N, cost);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -83,8 +83,14 @@ class EarthMoverDistanceFunctionNoGrad(torch.autograd.Function):
         xyz1 = xyz1.contiguous()
         xyz2 = xyz2.contiguous()
         assert xyz1.is_cuda and xyz2.is_cuda, "Only support cuda currently."
-        match = emd_ext.approxmatch_forward(xyz1, xyz2)
-        return emd_ext.matchcost_forward(xyz1, xyz2, match)
+        # no gradient needed: the fused path never materialises the [B,N,M] match matrix
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        cost = torch.empty((b,), device=xyz1.device, dtype=torch.float32)
+        ws, nbytes = _ws(b, n, m, xyz1.device)
+        _lib.check(_lib.load().lion_emd_cost(_lib.ptr(xyz1), _lib.ptr(xyz2), b, n, m, _lib.ptr(cost), _lib.ptr(ws),
+                                             nbytes, _lib.stream_ptr(xyz1.device)), "emd_cost")
+        return cost
 
 
 def _prep(xyz1, xyz2, transpose):

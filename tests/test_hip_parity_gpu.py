@@ -572,3 +572,16 @@ def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
             k = int(ref[b].sum())
             assert ref[b][lst[b][:k].long()].all() and not ref[b][lst[b][k:].long()].any()
         assert int(occ[2 * B * nt]) == 0
+
+
+@pytest.mark.parametrize("B,N,M", [(3, 512, 512), (2, 300, 1024), (4, 2048, 2048)])
+def test_emd_fused_cost_matches_materialised_path(B, N, M):
+    """lion_emd_cost (no [B,N,M] match matrix: row sums of w * d^2 accumulated over the levels) == matchcost of the
+    materialised approxmatch, to fp32 summation-order noise."""
+    from lion_amd.emd import emd_ext, earth_mover_distance_nograd
+    torch.manual_seed(N + M)
+    x1 = torch.rand(B, N, 3, device="cuda")
+    x2 = torch.rand(B, M, 3, device="cuda")
+    ref = emd_ext.matchcost_forward(x1, x2, emd_ext.approxmatch_forward(x1, x2)) / float(N)
+    got = earth_mover_distance_nograd(x1, x2, transpose=False)
+    assert torch.allclose(got, ref, rtol=2e-5, atol=1e-7), (got, ref)
