@@ -215,7 +215,7 @@ int lion_pwconv_stat_tiles(int Cout, int L) {
 }
 
 // x f32[B,Cin,L], wp from lion_pwconv_pack_weights, bias f32[Cout] or NULL -> y f32[B,Cout,L];
-// Cout in {32,64,128,256}, weight slice <= ~100 KiB of LDS.  pro_a / pro_b f32[B,Cin] (both or neither):
+// Cout in {32,64,128,256}, weight slice <= 150 KiB of LDS.  pro_a / pro_b f32[B,Cin] (both or neither):
 // the input is swish(x*a+b).  stats f32[B,Cout,lion_pwconv_stat_tiles(Cout,L),2] or NULL.
 // Meant for the large activations (set-abstraction MLPs, L = M*U); short ones are latency bound and
 // better served by the library GEMM.
@@ -224,7 +224,7 @@ int lion_pwconv_forward(const float *x, const float *wp, const float *bias, int 
   if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0) return LION_EINVAL;
   if ((pro_a == nullptr) != (pro_b == nullptr)) return LION_EINVAL;
   const PwPlan p = pw_plan(Cout);
-  if (!p.cb || pw_lds(p.cb, Cin, pro_a != nullptr) > 100 * 1024) return LION_EUNSUPPORTED;
+  if (!p.cb || pw_lds(p.cb, Cin, pro_a != nullptr) > 150 * 1024) return LION_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (p.cb) {
   case 1: return launch_pw<1, 4>(x, wp, bias, y, B, Cin, Cout, L, pro_a, pro_b, stats, st);

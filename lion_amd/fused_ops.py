@@ -166,7 +166,7 @@ def pw_supported(conv, x):
     cout, cin = conv.out_channels, conv.in_channels
     L = x[0, 0].numel()
     lds = (2 * ((cin + 1) // 2) * cout + 2 * cin + 8 * cout) * 4
-    return (cout in (32, 64, 128, 256) and lds <= 100 * 1024 and L >= 1024
+    return (cout in (32, 64, 128, 256) and lds <= 150 * 1024 and L >= 1024
             and x.shape[0] * L * cout >= (1 << 22) and conv.groups == 1
             and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
             and all(p == 0 for p in conv.padding))
