@@ -154,6 +154,12 @@ size_t lion_conv3d_packed_floats(int Cout, int Cin);
 int lion_conv3d_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream);
 int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, int B, int Cin,
                            int Cout, int r, float *y, lionStream_t stream);
+/* training: the data gradient is lion_conv3d_k3_forward(gy, pack(mirrored, channel-swapped w)); the weight gradient
+ * gw f32[Cout,Cin,3,3,3] = sum_{b,v} gy * shifted x runs on the same MFMA instruction with the voxels on the k axis
+ * (ws: lion_conv3d_wgrad_workspace_floats floats of partial sums, reduced in a fixed order). */
+size_t lion_conv3d_wgrad_workspace_floats(int B, int Cin, int Cout, int r);
+int lion_conv3d_k3_wgrad(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
+                         size_t ws_floats, lionStream_t stream);
 
 /* ---- P2+P3+P4 folded into C3 / K4 (inference): PVConv.forward voxel branch, pvcnn2_ada.py:211-226 ----
  * conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize without a single stand-alone pass over

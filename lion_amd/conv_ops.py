@@ -63,9 +63,24 @@ def dgrad_weight(weight):
     return wt
 
 
+def conv3d_k3_wgrad(x, gy, weight_shape):
+    """weight gradient [Cout,Cin,3,3,3] of the 3x3x3 / pad 1 conv on the MFMA kernel (x [B,Cin,r,r,r], Cin % 4 == 0)."""
+    lib = _lib.load()
+    b, cin, r = x.shape[0], x.shape[1], x.shape[2]
+    cout = gy.shape[1]
+    gw = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
+    n = lib.lion_conv3d_wgrad_workspace_floats(b, cin, cout, r)
+    ws = torch.empty((n,), device=x.device, dtype=torch.float32)
+    x_c, gy_c = x.contiguous(), gy.contiguous()
+    _lib.check(lib.lion_conv3d_k3_wgrad(_lib.ptr(x_c), _lib.ptr(gy_c), b, cin, cout, r, _lib.ptr(gw), _lib.ptr(ws), n,
+                                        _lib.stream_ptr(x.device)), "conv3d_k3_wgrad")
+    return gw
+
+
 class _Conv3dK3(torch.autograd.Function):
-    """forward and data gradient on the fp32 MFMA kernel (the latter as the convolution with the mirrored,
-    channel-swapped weights); weight / bias gradients through ATen's convolution_backward (MIOpen)."""
+    """forward, data gradient (the convolution with the mirrored, channel-swapped weights) and weight gradient
+    (voxels on the MFMA k axis) on the fp32 MFMA kernels; shapes they do not cover (Cin % 4 != 0) fall back to
+    ATen's convolution_backward (MIOpen)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -78,14 +93,23 @@ class _Conv3dK3(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         cout, cin = weight.shape[:2]
-        own_dgrad = ctx.needs_input_grad[0] and supported(cout, cin, x.shape[2]) and cout % 4 == 0
-        gx, gw, gb = torch.ops.aten.convolution_backward(
-            gy, x, weight, [weight.shape[0]] if ctx.has_bias else None,
-            [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1,
-            [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1],
-             ctx.has_bias and ctx.needs_input_grad[2]])
+        r = x.shape[2]
+        own_dgrad = ctx.needs_input_grad[0] and supported(cout, cin, r) and cout % 4 == 0
+        own_wgrad = ctx.needs_input_grad[1] and supported(cin, cout, r) and cin % 4 == 0
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        gx = gw = gb = None
+        lib_mask = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1] and not own_wgrad,
+                    want_gb and not own_wgrad]
+        if any(lib_mask):
+            gx, gw, gb = torch.ops.aten.convolution_backward(
+                gy, x, weight, [weight.shape[0]] if ctx.has_bias else None,
+                [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, lib_mask)
         if own_dgrad:
             gx = conv3d_k3(gy, dgrad_weight(weight), None)
+        if own_wgrad:
+            gw = conv3d_k3_wgrad(x, gy, weight.shape)
+            if want_gb:
+                gb = gy.sum(dim=(0, 2, 3, 4))
         return gx, gw, gb
 
 

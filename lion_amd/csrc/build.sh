@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
 OBJS=()
-for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d pointwise pwconv skinny "$@"; do
+for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_wgrad pointwise pwconv skinny "$@"; do
   [ -f "$f.hip" ] || continue
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &

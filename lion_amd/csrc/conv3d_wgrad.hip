@@ -1,0 +1,175 @@
+// conv3d_wgrad.hip -- weight gradient of the 3x3x3 / pad 1 / stride 1 Conv3d (training path of C3,
+// models/pvcnn2_ada.py:211-222; the reference reaches cuDNN's backward-filter through autograd).
+//
+//   gw[co][ci][tap] = sum_{b, v} gy[b][co][v] * xpad[b][ci][v + tap]          (xpad: zero padded input)
+//
+// As a GEMM this is M = Cout, N = Cin * 27, K = B * r^3 (one million for 32 x 32^3): K is the long axis.  On
+// v_mfma_f32_32x32x2_f32 the voxels therefore sit on the MFMA k axis: A = gy (32 output channels x 2 voxels, from an
+// LDS tile [co][voxel] with an odd row stride -> conflict free), B = the haloed input tile shifted by the tap of the
+// column (2 voxels x 32 (ci, tap) columns; the column order ci*27 + tap is exactly the memory order of a gw row, so
+// the accumulator tile is written straight into the [Cout][Cin][27] layout).  A workgroup owns 32 output channels x
+// CIT input channels (CIT*27 columns = 7 column blocks at CIT = 8) and walks the spatial tiles of ONE sample; its 4
+// waves split each 256-voxel tile, so there are B * 4 partial results per (co, ci) tile, summed in a fixed order by a
+// second kernel (deterministic, no atomics).  Exact fp32 products, like the forward.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TD, int TH, int TW, int CIT>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                              int Cin, int Cout, int r, int TS,
+                                                              float *__restrict__ partial) {
+  constexpr int TV = TD * TH * TW; // 256 voxels per tile
+  static_assert(TV == 256, "4 waves x 64 voxels");
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
+  constexpr int NCOL = CIT * 27, NB = (NCOL + 31) / 32;
+  constexpr int GS = TV + 1; // row stride of the gy tile: odd -> the 32 channels of an A operand hit 32 banks
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sgy = smem;            // [32][GS]
+  float *sx = sgy + 32 * GS;    // [CIT][HALO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / TS, ts = blockIdx.x % TS, cit = blockIdx.y, cot = blockIdx.z; // ts: every TS-th tile
+  const int ci0 = cit * CIT, co0 = cot * 32;
+  const int r2 = r * r, r3 = r2 * r;
+  const int ntw = r / TW, nth = r / TH, ntiles = (r / TD) * nth * ntw;
+  const int cl = lane & 31, kh = lane >> 5;
+
+  // per-lane column constants: column c = nb*32 + cl -> (ci, tap) -> LDS offset of the shifted input
+  int cofs[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int c = min(nb * 32 + cl, NCOL - 1); // padded columns recompute the last one; never stored
+    const int ci = c / 27, tap = c - ci * 27;
+    cofs[nb] = ci * HALO + ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+  }
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(x + ((size_t)b * Cin + ci0) * r3), 0, CIT * r3 * 4, 0x00020000);
+  const float *gyb = gy + ((size_t)b * Cout + co0) * r3;
+
+  for (int t = ts; t < ntiles; t += TS) {
+    const int tw_i = t % ntw, th_i = (t / ntw) % nth, td_i = t / (ntw * nth);
+    const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+    __syncthreads(); // the previous tile's LDS reads are done
+    // gy tile: 32 channels x 256 voxels; thread = voxel, loop over channels (coalesced rows of TW voxels)
+    {
+      const int v = tid, d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+      const int gv = ((d0 + d) * r + (h0 + h)) * r + (w0 + w);
+#pragma unroll 8
+      for (int c = 0; c < 32; ++c) sgy[c * GS + v] = gyb[(size_t)c * r3 + gv];
+    }
+    // input halo tile (zero padding through out-of-range buffer offsets)
+    for (int p = tid; p < HALO; p += 256) {
+      const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+      const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+      const bool ok = gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+      const int off = ok ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
+#pragma unroll
+      for (int c = 0; c < CIT; ++c)
+        sx[c * HALO + p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, c * r3 * 4, 0));
+    }
+    __syncthreads();
+    // 32 k-steps of 2 voxels over this wave's 64 voxels
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {
+      const int v = wave * 64 + 2 * s + kh;
+      const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+      const int vb = (d * HH + h) * HW + w;
+      const float a = sgy[cl * GS + v];
+      float bq[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bq[nb] = sx[cofs[nb] + vb];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[nb], acc[nb], 0, 0, 0);
+    }
+  }
+  // partial[(b*4 + wave)][co][ci*27 + tap]; acc register i of lane l: row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31
+  float *pt = partial + (size_t)(blockIdx.x * 4 + wave) * Cout * Cin * 27;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int c = nb * 32 + cl;
+    if (c < NCOL) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        pt[((size_t)co * Cin + ci0) * 27 + c] = acc[nb][i];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *__restrict__ partial, int nparts,
+                                                                  size_t n, float *__restrict__ gw) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0; // the partials are sums of ~8k products each; their sum (up to 1024 of them) is taken in double
+  for (int p = 0; p < nparts; ++p) s += (double)partial[(size_t)p * n + i]; // fixed order
+  gw[i] = (float)s;
+}
+
+template <int TD, int TH, int TW, int CIT>
+static int launch_wgrad(const float *x, const float *gy, int B, int Cin, int Cout, int r, int TS, float *partial,
+                        hipStream_t st) {
+  constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
+  const size_t lds = (size_t)(32 * 257 + CIT * HALO) * 4;
+  static size_t cfg = 0;
+  if (lds > cfg) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<TD, TH, TW, CIT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    cfg = lds;
+  }
+  conv3d_wgrad_kernel<TD, TH, TW, CIT><<<dim3(B * TS, Cin / CIT, Cout / 32), 256, lds, st>>>(x, gy, Cin, Cout, r, TS,
+                                                                                           partial);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+// spatial splits per sample: enough workgroups for ~2 per CU when the channel tiles alone are too few
+static int wgrad_splits(int B, int Cin, int Cout, int r) {
+  const int cit = Cin % 8 == 0 ? 8 : 4;
+  const long wg = (long)B * (Cin / cit) * (Cout / 32);
+  const int ntiles = r * r * r / 256;
+  int ts = 1;
+  while (ts < ntiles && ts < 8 && wg * ts < 512) ts *= 2;
+  return ts;
+}
+
+// floats of scratch: B * splits * 4 partial copies of the [Cout,Cin,27] gradient
+size_t lion_conv3d_wgrad_workspace_floats(int B, int Cin, int Cout, int r) {
+  if (Cin % 4 != 0 || Cout % 32 != 0 || (r != 8 && r != 16 && r != 32)) return 0;
+  return (size_t)B * wgrad_splits(B, Cin, Cout, r) * 4 * Cout * Cin * 27;
+}
+
+// x f32[B,Cin,r,r,r] (Cin % 4 == 0), gy f32[B,Cout,r,r,r] (Cout % 32 == 0), r in {8,16,32} -> gw f32[Cout,Cin,3,3,3]
+int lion_conv3d_k3_wgrad(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
+                         size_t ws_floats, lionStream_t stream) {
+  if (!x || !gy || !gw || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
+  if (Cin % 4 != 0 || Cout % 32 != 0 || (r != 8 && r != 16 && r != 32)) return LION_EUNSUPPORTED;
+  if (!ws || ws_floats < lion_conv3d_wgrad_workspace_floats(B, Cin, Cout, r)) return LION_EWORKSPACE;
+  const int TS = wgrad_splits(B, Cin, Cout, r);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool c8 = Cin % 8 == 0;
+  int rc;
+  if (r == 32) rc = c8 ? launch_wgrad<2, 4, 32, 8>(x, gy, B, Cin, Cout, r, TS, ws, st) : launch_wgrad<2, 4, 32, 4>(x, gy, B, Cin, Cout, r, TS, ws, st);
+  else if (r == 16) rc = c8 ? launch_wgrad<4, 4, 16, 8>(x, gy, B, Cin, Cout, r, TS, ws, st) : launch_wgrad<4, 4, 16, 4>(x, gy, B, Cin, Cout, r, TS, ws, st);
+  else rc = c8 ? launch_wgrad<4, 8, 8, 8>(x, gy, B, Cin, Cout, r, TS, ws, st) : launch_wgrad<4, 8, 8, 4>(x, gy, B, Cin, Cout, r, TS, ws, st);
+  if (rc) return rc;
+  const size_t n = (size_t)Cout * Cin * 27;
+  conv3d_wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ws, B * TS * 4, n, gw);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+} // extern "C"
