@@ -53,12 +53,17 @@ _DGRAD_CACHE = {}
 def dgrad_weight(weight):
     """weights of the data-gradient convolution: grad_x = conv3d(grad_y, W'), W'[ci, co, kd, kh, kw] =
     W[co, ci, 2-kd, 2-kh, 2-kw] (stride 1, padding 1: the transposed convolution is again a 3x3x3 / pad 1
-    convolution with the channels swapped and the taps mirrored); cached per (storage, version)."""
+    convolution with the channels swapped and the taps mirrored); its output channels (= Cin) are zero-padded to a
+    multiple of 32, the kernel's channel tile (callers slice); cached per (storage, version)."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape))
     hit = _DGRAD_CACHE.get(id(weight))
     if hit is not None and hit[0] == key:
         return hit[1]
-    wt = weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
+    wt = weight.detach().flip(2, 3, 4).transpose(0, 1)
+    pad = (-wt.shape[0]) % 32
+    if pad:
+        wt = torch.cat([wt, wt.new_zeros((pad,) + tuple(wt.shape[1:]))], 0)
+    wt = wt.contiguous()
     _DGRAD_CACHE[id(weight)] = (key, wt)
     return wt
 
@@ -94,7 +99,7 @@ class _Conv3dK3(torch.autograd.Function):
         gy = gy.contiguous()
         cout, cin = weight.shape[:2]
         r = x.shape[2]
-        own_dgrad = ctx.needs_input_grad[0] and supported(cout, cin, r) and cout % 4 == 0
+        own_dgrad = ctx.needs_input_grad[0] and r in (8, 16, 32) and cout % 4 == 0
         own_wgrad = ctx.needs_input_grad[1] and supported(cin, cout, r) and cin % 4 == 0
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         gx = gw = gb = None
@@ -106,6 +111,8 @@ class _Conv3dK3(torch.autograd.Function):
                 [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, lib_mask)
         if own_dgrad:
             gx = conv3d_k3(gy, dgrad_weight(weight), None)
+            if gx.shape[1] != cin:
+                gx = gx[:, :cin].contiguous()
         if own_wgrad:
             gw = conv3d_k3_wgrad(x, gy, weight.shape)
             if want_gb:
@@ -124,5 +131,10 @@ def conv3d_module(conv: torch.nn.Conv3d, x):
     if not ok:
         return conv(x)
     if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
-        return _Conv3dK3.apply(x, conv.weight, conv.bias)
+        w = conv.weight
+        if x.shape[1] % 4:  # zero input channels: autograd slices the gradients of the two pads away again
+            pad = 4 - x.shape[1] % 4
+            x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, 0, pad))
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, pad))
+        return _Conv3dK3.apply(x, w, conv.bias)
     return conv3d_k3(x, conv.weight, conv.bias)
