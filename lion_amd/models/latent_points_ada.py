@@ -65,6 +65,7 @@ class PVCNN2Unet(nn.Module):
         head, _ = create_mlp_components(in_channels=c_top, out_channels=[128, dropout, num_classes], classifier=True,
                                         dim=2, width_multiplier=width_multiplier, cfg=cfg)
         self.classifier = nn.ModuleList(head)
+        pvcnn2_ada.route_1x1_convs(self)
 
     def get_timestep_embedding(self, timesteps, device):
         """[sin, cos] of t * time_emb_scales * 10000^(-i/(half-1)); the frequency row is built in float64 numpy and

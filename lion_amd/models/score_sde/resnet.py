@@ -124,6 +124,8 @@ class Prior(nn.Module):
         blocks = [self.building_block(nf, nf) for _ in range(args.num_cell_per_scale_dae)]
         self.output_layer = nn.Conv2d(nf, num_input_channels, 1, 1)  # registered before the blocks,
         self.all_modules = nn.ModuleList(blocks)                       # as in the reference (:188-191)
+        from ..pvcnn2_ada import route_1x1_convs
+        route_1x1_convs(self)
 
     def forward(self, x, t, **kwargs):
         if t.dim() == 0:

@@ -41,6 +41,8 @@ class Model(nn.Module):
             zdim=self.latent_dim, input_dim=self.input_dim, args=args)
         self.decoder = import_model(args.shapelatent.decoder_type)(
             context_dim=self.latent_dim, point_dim=args.ddpm.input_dim, args=args)
+        from .pvcnn2_ada import route_1x1_convs
+        route_1x1_convs(self)  # 1x1 convs as matrix products: GEMM backward instead of the conv library's
 
     # ---- latent bookkeeping ------------------------------------------------------------------
     def compose_eps(self, all_eps):
