@@ -12,8 +12,10 @@
 // round (double-buffered 4-entry LDS exchange).  The low word reproduces the reference's tie-break
 // exactly: its strided per-thread scan + left-biased tree picks the lowest (k mod 512, k) among
 // equal distances (sampling.cu:141-159), so the indices are bit-exact, ties included.
-// Clouds with N > 256*32 use the same kernel with distances in a caller-provided global scratch?
-// No: they take the generic strided variant below (distances in LDS up to 32K points).
+// Clouds with N > 256*8 take the generic strided variant below (distances in LDS, up to 32 K points).
+// The per-wave arg-max runs on DPP row operations + v_readlane (two 32-bit reductions: the distance bits, then the
+// tie-break word among the lanes that hold the maximum) instead of 64-bit xor-shuffles, which go through the LDS
+// crossbar (ds_bpermute, ~12 dependent LDS round trips per round).
 #include "common.h"
 
 namespace {
@@ -24,6 +26,22 @@ __device__ __forceinline__ unsigned long long fps_key(float d2, int k) {
 }
 __device__ __forceinline__ int fps_key_index(unsigned long long key) {
   return (int)((0xffffffffu - (unsigned)(key & 0xffffffffull)) & 0xfffffu);
+}
+// max over the 64 lanes, result uniform: xor-1 / xor-2 inside quads, half-mirror (8), mirror (16), then the 4 rows
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+  v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true); // row_half_mirror
+  v = o > v ? o : v;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true); // row_mirror
+  v = o > v ? o : v;
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
@@ -38,7 +56,7 @@ template <int PPT>
 __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ coords, int N, int M,
                                                       int32_t *__restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *sx = reinterpret_cast<float *>(smem); // [3][N] copy for the "coords[old]" lookup
+  float4 *sx = reinterpret_cast<float4 *>(smem); // [N] {x, y, z, -} copy for the "coords[old]" lookup (one 16-byte read)
   __shared__ unsigned long long wkey[2][4];
   // 1023 dependent rounds on one workgroup per cloud: pure latency.  The sampler runs this chain on a side stream
   // under the MFMA convolutions (lion_amd/geometry.py); raise the wave priority so that its few instructions per
@@ -47,14 +65,17 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
   const float *co = coords + (size_t)b * 3 * N;
   float x[PPT], y[PPT], z[PPT], td[PPT];
+  unsigned tb[PPT]; // tie-break word of point k: larger wins, 0 for lanes past N (see fps_key)
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
     const int k = tid + p * 256;
     x[p] = y[p] = z[p] = 0.f;
     td[p] = 1e38f; // sampling.cpp:53-54
+    tb[p] = 0u;
     if (k < N) {
       x[p] = co[k]; y[p] = co[k + N]; z[p] = co[k + 2 * N];
-      sx[k] = x[p]; sx[N + k] = y[p]; sx[2 * N + k] = z[p];
+      sx[k] = make_float4(x[p], y[p], z[p], 0.f);
+      tb[p] = 0xffffffffu - (((unsigned)(k & 511) << 20) | (unsigned)k);
     }
   }
   int32_t *out = idx + (size_t)b * M;
@@ -62,21 +83,25 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
   __syncthreads();
   int old = 0;
   for (int j = 1; j < M; ++j) {
-    const float x1 = sx[old], y1 = sx[N + old], z1 = sx[2 * N + old];
-    unsigned long long best = 0ull;
+    const float4 c1 = sx[old];
+    unsigned md = 0u;
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
-      const int k = tid + p * 256;
-      if (k < N) {
-        const float d = sqdist3(x[p], y[p], z[p], x1, y1, z1); // sampling.cu:133-134
-        const float d2 = d < td[p] ? d : td[p];
-        td[p] = d2;
-        const unsigned long long key = fps_key(d2, k);
-        best = key > best ? key : best;
-      }
+      const float d = sqdist3(x[p], y[p], z[p], c1.x, c1.y, c1.z); // sampling.cu:133-134
+      const float d2 = d < td[p] ? d : td[p];
+      td[p] = tb[p] ? d2 : 0.f; // lanes past N never compete (distance bits 0, tie-break word 0)
+      const unsigned db = __float_as_uint(td[p]); // d2 >= 0: the bit pattern is monotone
+      md = db > md ? db : md;
     }
-    best = wave_max_u64(best);
-    if (lane == 0) wkey[j & 1][wave] = best;
+    const unsigned wmax = wave_max_u32(md);
+    unsigned mt = 0u;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+      const unsigned cand = __float_as_uint(td[p]) == wmax ? tb[p] : 0u;
+      mt = cand > mt ? cand : mt;
+    }
+    const unsigned wtb = wave_max_u32(mt);
+    if (lane == 0) wkey[j & 1][wave] = ((unsigned long long)wmax << 32) | wtb;
     __syncthreads();
     unsigned long long k0 = wkey[j & 1][0], k1 = wkey[j & 1][1], k2 = wkey[j & 1][2],
                        k3 = wkey[j & 1][3];
@@ -128,7 +153,7 @@ __global__ __launch_bounds__(1024) void fps_lds_kernel(const float *__restrict__
 
 template <int PPT>
 static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx, hipStream_t st) {
-  const size_t lds = (size_t)3 * N * 4;
+  const size_t lds = (size_t)N * 16;
   fps_reg_kernel<PPT><<<B, 256, lds, st>>>(coords, N, M, idx);
   LION_LAUNCH_CHECK();
   return 0;
