@@ -35,6 +35,28 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 }
 
 // Inclusive wave prefix sum (wave64) with shuffles.
+// ---- butterfly steps on DPP row operations --------------------------------------------------------------------
+// A commutative xor-butterfly reduction over 16 consecutive lanes (x ^= 1, 2, 4, 8) without the LDS crossbar that
+// __shfl_xor / ds_bpermute go through: quad_perm does the true xor-1 / xor-2 exchanges; after them the 4 lanes of a
+// quad hold the same value, so pairing lane i with lane 7-i (row_half_mirror) combines the same two quad results as
+// xor-4 would -- and likewise row_mirror for xor-8.  Bit-identical to the butterfly for any commutative op.
+#define LION_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float row16_sum_rn(float v) { // exact same tree as v += shfl_xor(v, 1|2|4|8) with add_rn
+  v = __fadd_rn(v, LION_DPP_F32(v, 0xB1));  // quad_perm [1,0,3,2]
+  v = __fadd_rn(v, LION_DPP_F32(v, 0x4E));  // quad_perm [2,3,0,1]
+  v = __fadd_rn(v, LION_DPP_F32(v, 0x141)); // row_half_mirror
+  v = __fadd_rn(v, LION_DPP_F32(v, 0x140)); // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  float o;
+  o = LION_DPP_F32(v, 0xB1); v = o > v ? o : v;
+  o = LION_DPP_F32(v, 0x4E); v = o > v ? o : v;
+  o = LION_DPP_F32(v, 0x141); v = o > v ? o : v;
+  o = LION_DPP_F32(v, 0x140); v = o > v ? o : v;
+  return v;
+}
+
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
   for (int d = 1; d < LION_WAVE; d <<= 1) {

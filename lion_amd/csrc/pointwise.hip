@@ -27,8 +27,9 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
   } else {
     for (int i = tid; i < L; i += 256) { const float v = p[i]; s1 += v; s2 += v * v; }
   }
+  s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  for (int m = 16; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
   if (lane == 0) { r1[wave] = s1; r2[wave] = s2; }
   __syncthreads();
   if (tid == 0) {

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int vb = 0; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
         if (cl == 0) {
           const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
           sred[(wave * COUT + co) * 2] = s1;

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
+      part[a] = row16_sum_rn(part[a]); // s = 1, 2, 4, 8 (same tree, DPP); then across the 4 rows
 #pragma unroll
-      for (int s = 1; s < 64; s <<= 1) part[a] = add_rn(part[a], __shfl_xor(part[a], s, 64));
+      for (int s = 16; s < 64; s <<= 1) part[a] = add_rn(part[a], __shfl_xor(part[a], s, 64));
       if (lane == 0) fscr[a * 16 + wave] = part[a];
     }
     __syncthreads();
@@ -98,8 +99,7 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       float v = fscr[a * 16 + (lane & 15)];
-#pragma unroll
-      for (int s = 1; s < 16; s <<= 1) v = add_rn(v, __shfl_xor(v, s, 64));
+      v = row16_sum_rn(v);
       mean[a] = div_rn(v, (float)N);
     }
     float denom = 1.0f;
@@ -115,13 +115,13 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
           mx = nr > mx ? nr : mx;
         }
       }
+      mx = row16_max(mx);
 #pragma unroll
-      for (int s = 1; s < 64; s <<= 1) { const float o = __shfl_xor(mx, s, 64); mx = o > mx ? o : mx; }
+      for (int s = 16; s < 64; s <<= 1) { const float o = __shfl_xor(mx, s, 64); mx = o > mx ? o : mx; }
       if (lane == 0) fscr[48 + wave] = mx;
       __syncthreads();
       float m2 = fscr[48 + (lane & 15)];
-#pragma unroll
-      for (int s = 1; s < 16; s <<= 1) { const float o = __shfl_xor(m2, s, 64); m2 = o > m2 ? o : m2; }
+      m2 = row16_max(m2);
       denom = add_rn(mul_rn(m2, 2.0f), eps);
     }
     float *nc = norm_coords + (size_t)b * 3 * N;
