@@ -311,29 +311,42 @@ __global__ void gn_fold_kernel(const float *__restrict__ stats, int C, int T, in
                                const float *__restrict__ gamma, const float *__restrict__ beta,
                                const float *__restrict__ fac, const float *__restrict__ gbias, int ld_fg, float eps,
                                float *__restrict__ A, float *__restrict__ Bs, float *__restrict__ chmean) {
-  // one wave per (batch, group); C/G <= 64 channels per group, one lane each: lane c walks its T tile sums in
-  // order (double accumulation), the group total is an xor-butterfly over the 64 lanes (a fixed tree):
-  // deterministic, and no barrier chain.
+  // one 256-thread workgroup per (batch, group); C/G <= 64 channels per group.  LPC = 256 / pow2ceil(C/G) lanes share
+  // a channel: lane `sub` accumulates tiles sub, sub + LPC, ... in double, the LPC partials are combined with an
+  // xor-butterfly (consecutive lanes of one wave), the channel totals with a fixed-order loop: deterministic.
+  __shared__ double cs[64][2];
   __shared__ double gs[2];
   const int b = blockIdx.y, g = blockIdx.x, cpg = C / G, tid = threadIdx.x;
+  int cp2 = 1;
+  while (cp2 < cpg) cp2 <<= 1;
+  const int LPC = 256 / cp2, ch = tid / LPC, sub = tid % LPC; // LPC in {4, ..., 256}, a power of two
   double s1 = 0.0, s2 = 0.0;
-  if (tid < cpg) {
-    const float2 *p = reinterpret_cast<const float2 *>(stats + (((size_t)b * C + g * cpg + tid) * T) * 2);
-    int t = 0;
-    for (; t + 4 <= T; t += 4) { // 4 independent loads in flight
-      const float2 v0 = p[t], v1 = p[t + 1], v2 = p[t + 2], v3 = p[t + 3];
-      s1 += (double)v0.x; s2 += (double)v0.y;
-      s1 += (double)v1.x; s2 += (double)v1.y;
-      s1 += (double)v2.x; s2 += (double)v2.y;
-      s1 += (double)v3.x; s2 += (double)v3.y;
-    }
-    for (; t < T; ++t) { const float2 v = p[t]; s1 += (double)v.x; s2 += (double)v.y; }
-    chmean[(size_t)b * C + g * cpg + tid] = (float)(s1 / count);
+  if (ch < cpg) {
+    const float2 *p = reinterpret_cast<const float2 *>(stats + (((size_t)b * C + g * cpg + ch) * T) * 2);
+    for (int t = sub; t < T; t += LPC) { const float2 v = p[t]; s1 += (double)v.x; s2 += (double)v.y; }
   }
-  double g1 = s1, g2 = s2;
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { g1 += __shfl_xor(g1, m, 64); g2 += __shfl_xor(g2, m, 64); }
-  if (tid == 0) { gs[0] = g1; gs[1] = g2; }
+  for (int m = 1; m < LPC && m < 64; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (LPC > 64) { // a channel spans several waves (C/G <= 2): combine through LDS
+    __shared__ double ws[4][2];
+    if ((tid & 63) == 0) { ws[tid >> 6][0] = s1; ws[tid >> 6][1] = s2; }
+    __syncthreads();
+    if (sub == 0) {
+      s1 = 0.0; s2 = 0.0;
+      for (int w = 0; w < LPC / 64; ++w) { s1 += ws[(tid >> 6) + w][0]; s2 += ws[(tid >> 6) + w][1]; }
+    }
+  }
+  if (ch < cpg && sub == 0) {
+    cs[ch][0] = s1;
+    cs[ch][1] = s2;
+    chmean[(size_t)b * C + g * cpg + ch] = (float)(s1 / count);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double g1 = 0.0, g2 = 0.0;
+    for (int c = 0; c < cpg; ++c) { g1 += cs[c][0]; g2 += cs[c][1]; }
+    gs[0] = g1;
+    gs[1] = g2;
+  }
   __syncthreads();
   if (tid < cpg) {
     const double n = (double)count * cpg;
@@ -600,7 +613,7 @@ int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxe
                         float *A, float *Bs, float *chmean, lionStream_t stream) {
   if (!stats || !gamma || !beta || !fac || !gbias || !A || !Bs || !chmean) return LION_EINVAL;
   if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G != 0 || C / G > 64 || ld_fg < C) return LION_EINVAL;
-  gn_fold_kernel<<<dim3(G, B), 64, 0, static_cast<hipStream_t>(stream)>>>(stats, C, T, G, (float)voxels, gamma,
+  gn_fold_kernel<<<dim3(G, B), 256, 0, static_cast<hipStream_t>(stream)>>>(stats, C, T, G, (float)voxels, gamma,
                                                                          beta, fac, gbias, ld_fg, eps, A, Bs, chmean);
   LION_LAUNCH_CHECK();
   return 0;
