@@ -1,0 +1,31 @@
+"""Cache of tensors derived from a weight (packed / mirrored / summed copies).
+
+Keyed by the weight's storage address and shape, validated by its version counter (in-place optimizer steps bump
+it).  Every entry holds a STRONG reference to the weight tensor it was built from: while the entry lives the storage
+cannot be freed, so its address cannot be handed to a different tensor -- an id()- or address-keyed cache without
+that reference returns the previous owner's packed copy when a freed parameter's block is reused by a new parameter
+of the same shape (seen as a flaky parity test).  Least-recently-used entries are dropped beyond `capacity`."""
+from collections import OrderedDict
+
+
+class WeightCache:
+    def __init__(self, build, capacity=256):
+        self._build = build
+        self._entries = OrderedDict()
+        self._capacity = capacity
+
+    def get(self, weight):
+        key = (weight.data_ptr(), tuple(weight.shape), weight.dtype, weight.device)
+        hit = self._entries.get(key)
+        if hit is not None and hit[0] == weight._version:
+            self._entries.move_to_end(key)
+            return hit[2]
+        value = self._build(weight)
+        self._entries[key] = (weight._version, weight, value)
+        self._entries.move_to_end(key)
+        while len(self._entries) > self._capacity:
+            self._entries.popitem(last=False)
+        return value
+
+    def clear(self):
+        self._entries.clear()

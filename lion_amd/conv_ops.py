@@ -2,28 +2,28 @@
 import torch
 
 from . import _lib
-
-_PACK_CACHE = {}
-
+from ._wcache import WeightCache
 
 def supported(cin, cout, r):
     return r in (8, 16, 32) and cout % 32 == 0 and cin >= 1
 
 
-def packed_weight(weight):
-    """[Cout,Cin,3,3,3] -> packed [ceil4(Cin),27,Cout]; cached per (storage, version)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    hit = _PACK_CACHE.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return hit[1]
+def _pack(weight):
     cout, cin = weight.shape[:2]
     lib = _lib.load()
     wp = torch.empty((lib.lion_conv3d_packed_floats(cout, cin),), device=weight.device, dtype=torch.float32)
     w_c = weight.detach().contiguous()  # local reference: see fused_ops.groupnorm_fold
     _lib.check(lib.lion_conv3d_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
                                             _lib.stream_ptr(weight.device)), "conv3d_pack_weights")
-    _PACK_CACHE[id(weight)] = (key, wp)
     return wp
+
+
+_PACK_CACHE = WeightCache(_pack)
+
+
+def packed_weight(weight):
+    """[Cout,Cin,3,3,3] -> packed [ceil4(Cin),27,Cout]; cached per (storage, version), see _wcache.py."""
+    return _PACK_CACHE.get(weight)
 
 
 def conv3d_k3(x, weight, bias=None):
@@ -47,7 +47,15 @@ def conv3d_k3(x, weight, bias=None):
     return y
 
 
-_DGRAD_CACHE = {}
+def _mirror(weight):
+    wt = weight.detach().flip(2, 3, 4).transpose(0, 1)
+    pad = (-wt.shape[0]) % 32
+    if pad:
+        wt = torch.cat([wt, wt.new_zeros((pad,) + tuple(wt.shape[1:]))], 0)
+    return wt.contiguous()
+
+
+_DGRAD_CACHE = WeightCache(_mirror)
 
 
 def dgrad_weight(weight):
@@ -55,17 +63,7 @@ def dgrad_weight(weight):
     W[co, ci, 2-kd, 2-kh, 2-kw] (stride 1, padding 1: the transposed convolution is again a 3x3x3 / pad 1
     convolution with the channels swapped and the taps mirrored); its output channels (= Cin) are zero-padded to a
     multiple of 32, the kernel's channel tile (callers slice); cached per (storage, version)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    hit = _DGRAD_CACHE.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    wt = weight.detach().flip(2, 3, 4).transpose(0, 1)
-    pad = (-wt.shape[0]) % 32
-    if pad:
-        wt = torch.cat([wt, wt.new_zeros((pad,) + tuple(wt.shape[1:]))], 0)
-    wt = wt.contiguous()
-    _DGRAD_CACHE[id(weight)] = (key, wt)
-    return wt
+    return _DGRAD_CACHE.get(weight)
 
 
 def conv3d_k3_wgrad(x, gy, weight_shape):

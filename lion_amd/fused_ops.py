@@ -5,25 +5,24 @@ lion_trilinear_devoxelize_affine_forward (include/lion_hip.h)."""
 import torch
 
 from . import _lib
+from ._wcache import WeightCache
 from .conv_ops import packed_weight, supported
 
 
-_WSUM_CACHE = {}
+def _border_sums(weight):
+    m = torch.tensor([[0., 1., 1.], [1., 1., 1.], [1., 1., 0.]], dtype=torch.float64, device=weight.device)
+    ws = torch.einsum("oidhw,ad,bh,cw->abcio", weight.detach().double(), m, m, m)
+    return ws.reshape(27, weight.shape[1], weight.shape[0]).float().contiguous()
+
+
+_WSUM_CACHE = WeightCache(_border_sums)
 
 
 def border_weight_sums(weight):
     """[Cout,Cin,3,3,3] -> [27,Cin,Cout]: the weights summed over the taps that stay inside the grid, for each of
     the 27 border configurations (per axis: 0 = voxel on the low face, 1 = interior, 2 = on the high face); fp64
     sums, cached per (storage, version)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    hit = _WSUM_CACHE.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    m = torch.tensor([[0., 1., 1.], [1., 1., 1.], [1., 1., 0.]], dtype=torch.float64, device=weight.device)
-    ws = torch.einsum("oidhw,ad,bh,cw->abcio", weight.detach().double(), m, m, m)
-    ws = ws.reshape(27, weight.shape[1], weight.shape[0]).float().contiguous()
-    _WSUM_CACHE[id(weight)] = (key, ws)
-    return ws
+    return _WSUM_CACHE.get(weight)
 
 
 def conv3d_occupancy(counts, r, cout, b):
@@ -141,23 +140,22 @@ def fusable(conv1, conv2, r, x):
             and conv2.in_channels % 4 == 0 and conv2.in_channels <= 256)
 
 
-_PW_CACHE = {}
-
-
-def pw_packed_weight(weight):
-    """[Cout,Cin,1(,1)] -> k-major [ceil2(Cin),Cout]; cached per (storage, version)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    hit = _PW_CACHE.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return hit[1]
+def _pw_pack(weight):
     cout, cin = weight.shape[:2]
     lib = _lib.load()
     wp = torch.empty((lib.lion_pwconv_packed_floats(cout, cin),), device=weight.device, dtype=torch.float32)
     w_c = weight.detach().reshape(cout, cin).contiguous()
     _lib.check(lib.lion_pwconv_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
                                             _lib.stream_ptr(weight.device)), "pwconv_pack_weights")
-    _PW_CACHE[id(weight)] = (key, wp)
     return wp
+
+
+_PW_CACHE = WeightCache(_pw_pack)
+
+
+def pw_packed_weight(weight):
+    """[Cout,Cin,1(,1)] -> k-major [ceil2(Cin),Cout]; cached per (storage, version)."""
+    return _PW_CACHE.get(weight)
 
 
 def pw_supported(conv, x):
@@ -275,22 +273,21 @@ def from_channel_major(xt, b):
     return xt.transpose(1, 2).reshape(nb * 32, c)[:b].reshape(b, c, 1, 1).contiguous()
 
 
-_SK_CACHE = {}
-
-
-def skinny_packed_weight(weight):
-    """[Cout,Cin,1,1] -> tile-major packed copy (lion_skinny_pack_weights); cached per (storage, version)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    hit = _SK_CACHE.get(id(weight))
-    if hit is not None and hit[0] == key:
-        return hit[1]
+def _sk_pack(weight):
     cout, cin = weight.shape[:2]
     wp = torch.empty((_lib.load().lion_skinny_packed_floats(cout, cin),), device=weight.device, dtype=torch.float32)
     w_c = weight.detach().reshape(cout, cin).contiguous()
     _lib.check(_lib.load().lion_skinny_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
                                                     _lib.stream_ptr(weight.device)), "skinny_pack_weights")
-    _SK_CACHE[id(weight)] = (key, wp)
     return wp
+
+
+_SK_CACHE = WeightCache(_sk_pack)
+
+
+def skinny_packed_weight(weight):
+    """[Cout,Cin,1,1] -> tile-major packed copy (lion_skinny_pack_weights); cached per (storage, version)."""
+    return _SK_CACHE.get(weight)
 
 
 def skinny_conv(pin, conv, bias_in=None, act_in=0, add=None):
