@@ -58,3 +58,33 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "liboracle" in src:
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_weight_cache_never_serves_a_freed_tensors_copy():
+    """lion_amd._wcache.WeightCache: entries are keyed by storage address, validated by the version counter and hold a
+    strong reference to their source tensor -- a new tensor can therefore never inherit the derived copy of a freed
+    one that happened to live at the same address (the failure mode of an id()-keyed cache)."""
+    import gc
+    import torch
+    from lion_amd._wcache import WeightCache
+    builds = []
+
+    def build(w):
+        builds.append(w.data_ptr())
+        return w.detach().clone() * 2
+
+    cache = WeightCache(build, capacity=4)
+    a = torch.arange(6.0).reshape(2, 3)
+    assert torch.equal(cache.get(a), a * 2) and len(builds) == 1
+    assert cache.get(a) is cache.get(a) and len(builds) == 1          # hit
+    a.add_(1.0)                                                         # in-place update bumps the version
+    assert torch.equal(cache.get(a), a * 2) and len(builds) == 2
+    ptr = a.data_ptr()
+    del a
+    gc.collect()
+    b = torch.full((2, 3), 7.0)                                         # may or may not reuse a's block ...
+    assert torch.equal(cache.get(b), b * 2)                             # ... the result is right either way
+    assert b.data_ptr() != ptr or len(builds) >= 3                      # and a reused address would have rebuilt
+    for i in range(8):                                                  # capacity bound (LRU)
+        cache.get(torch.zeros(1 + i))
+    assert len(cache._entries) <= 4
