@@ -22,6 +22,16 @@ from .. import fused_ops
 FUSE_INFERENCE = True  # module-level switch (tests compare the fused and the layer-by-layer paths)
 # conv1 of a PVConv reads the voxelised grid: skip (exactly) the tiles whose halo holds no point
 SPARSE_CONV1 = True
+# run the point branch of a PVConv on a second stream, concurrently with its voxel branch (inference)
+OVERLAP_POINT_BRANCH = True
+_POINT_STREAMS = {}
+
+
+def _point_stream(device):
+    key = (device.type, device.index)
+    if key not in _POINT_STREAMS:
+        _POINT_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _POINT_STREAMS[key]
 from .adagn import AdaGN
 
 
@@ -279,8 +289,21 @@ class PVConv(nn.Module):
             grid, voxel_coords = self.voxelization(features, coords)
         if (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled()
                 and fused_ops.fusable(self.voxel_layers[0], self.voxel_layers[4], self.resolution, grid)):
+            pf = None
+            if self.add_point_feat and OVERLAP_POINT_BRANCH:
+                # the point branch (1x1 conv + AdaGN + Swish: a handful of short, latency-bound launches) does not
+                # depend on the voxel branch: issue it on a second stream (a parallel branch under graph capture),
+                # where it runs in the shadow of the MFMA convolutions
+                main, side = torch.cuda.current_stream(features.device), _point_stream(features.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    pf = self.point_features(features, style)
             fused = self._fused_voxel_branch(grid, voxel_coords, style, counts)
-            if self.add_point_feat:
+            if pf is not None:
+                main.wait_stream(side)
+                pf.record_stream(main)
+                fused = fused + pf
+            elif self.add_point_feat:
                 fused = fused + self.point_features(features, style)
             if self.attn is not None:
                 fused = self.attn(fused)
