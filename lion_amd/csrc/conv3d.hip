@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
   // occ (optional): 0 = every input voxel of this tile's halo is zero in ALL channels (conv1 of a PVConv reads the
   // voxelised grid, >= 94 % zeros, and whole tiles far from the cloud are empty).  The K loop is skipped and the
   // epilogue writes bias -- bit-identical to accumulating the zeros.
-  const bool empty = queued && occ[b * ntiles + tile] == 0;
+  const int wmask = queued ? occ[b * ntiles + tile] : 0xf; // bit w: wave w's 64 voxels see a point (sparse launches)
+  const bool empty = wmask == 0;
+  const bool wave_on = (wmask >> wave) & 1;
   const int nchunks = empty ? 0 : Cin / KC;
   if (!empty) load_chunk(0);
   for (int q = 0; q < nchunks; ++q) {
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) av[buf][cb] = ap[cb * 32];
     };
+    if (wave_on) { // a wave whose block is empty only takes part in the staging and the barriers
     lds_step(0, 0);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
         for (int vb = 0; vb < VB; ++vb)
           acc[cb][vb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][cb], bv[st & 1][vb], acc[cb][vb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
   }
 
@@ -381,13 +385,21 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
     if (v.x | v.y | v.z | v.w) col[(i << 2) / r] = 1; // benign race: everybody writes 1
   }
   __syncthreads();
+  // per tile and margin: a 4-bit mask, bit w = wave w's 64-voxel block (64 / r rows of one d-plane) has a point within
+  // `margin`; 0 = the whole tile is empty
+  const int RW = 64 / r; // rows per wave (tiles are r voxels wide)
   for (int e = tid; e < 2 * ntiles; e += 1024) {
     const int t = e % ntiles, margin = 1 + e / ntiles;
-    const int d0 = (t / nth) * TD - margin, h0 = (t % nth) * TH - margin;
-    int any = 0;
-    for (int d = max(d0, 0); d < min(d0 + TD + 2 * margin, r); ++d)
-      for (int h = max(h0, 0); h < min(h0 + TH + 2 * margin, r); ++h) any |= col[d * r + h];
-    flag[margin - 1][t] = any;
+    const int dt = (t / nth) * TD, ht = (t % nth) * TH;
+    int mask = 0;
+    for (int w = 0; w < 4; ++w) {
+      const int dl = dt + (w * RW) / TH, hl = ht + (w * RW) % TH;
+      int any = 0;
+      for (int d = max(dl - margin, 0); d <= min(dl + margin, r - 1); ++d)
+        for (int h = max(hl - margin, 0); h <= min(hl + RW - 1 + margin, r - 1); ++h) any |= col[d * r + h];
+      mask |= (any ? 1 : 0) << w;
+    }
+    flag[margin - 1][t] = mask;
   }
   __syncthreads();
   if (tid < 2) { // one thread per margin: <= 256 tiles, occupied first

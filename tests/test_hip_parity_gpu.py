@@ -502,7 +502,7 @@ def test_conv3d_empty_tile_skip_is_bit_identical(cin, cout, r, n):
         occ1, _ = fo.conv3d_occupancy(cnt, r, cout, B)
         y1, s1 = fo.conv3d_fused(grid, conv, None, True, occ1)
         nt = occ1.numel() // 2 // B
-        assert occ1[:B * nt].float().mean().item() < 0.9  # the flat cloud leaves tiles empty
+        assert (occ1[:B * nt] != 0).float().mean().item() < 0.9  # the flat cloud leaves tiles empty
     assert torch.equal(y0, y1)  # same K order per voxel whatever the tiling
     t0, t1 = s0.sum(2), s1.sum(2)  # the sparse launch tiles differently: compare the totals
     assert torch.allclose(t0, t1, rtol=1e-4, atol=1e-5 * t0.abs().max().item())
@@ -564,8 +564,9 @@ def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
     for occ, m in ((occ1, 1), (occ2, 2)):
         d = torch.nn.functional.max_pool3d(g, 2 * m + 1, 1, m)[:, 0]
         ref = d.view(B, r // td, td, r // th, th, r).amax(dim=(2, 4, 5)).reshape(B, nt).int()
-        flags = occ[:B * nt].view(B, nt)
-        assert torch.equal(flags, ref), m
+        flags = occ[:B * nt].view(B, nt)  # 4-bit masks: bit w = wave w's 64-voxel block sees a point; 0 = empty tile
+        assert torch.equal((flags != 0).int(), ref), m
+        assert int(flags.max()) <= 15
         lst = occ[B * nt:2 * B * nt].view(B, nt)
         for b in range(B):
             assert sorted(lst[b].tolist()) == list(range(nt))

@@ -21,7 +21,7 @@ for c, r, n in ((64, 32, 2048), (32, 32, 2048), (128, 16, 1024)):
         grid = out.view(B, c, r, r, r)
         nt = lib.lion_conv3d_stat_tiles(r, c, B, 1)
         o1, o2 = fo.conv3d_occupancy(cnt, r, c, B)
-        fr = [1 - o1[:B * nt].float().mean().item(), 1 - o2[:B * nt].float().mean().item()]
+        fr = [1 - (o1[:B * nt] != 0).float().mean().item(), 1 - (o2[:B * nt] != 0).float().mean().item()]
         with torch.no_grad():
             y1, _ = fo.conv3d_fused(grid, conv1, None, True, None)
             print(f"C={c} r={r} {name:5s} empty tiles m1 {fr[0]:.2f} m2 {fr[1]:.2f} | conv1 dense "
