@@ -88,3 +88,33 @@ def test_weight_cache_never_serves_a_freed_tensors_copy():
     for i in range(8):                                                  # capacity bound (LRU)
         cache.get(torch.zeros(1 + i))
     assert len(cache._entries) <= 4
+
+
+def test_host_side_plan_functions():
+    """size / plan helpers of the C ABI are pure host code: pin the values the Python shim relies on."""
+    from lion_amd import _lib
+    lib = _lib.load()
+    # Conv3d tile plans: dense 4x2 MFMA tiles where >= 512 workgroups remain, 2x2 tiles for sparse launches
+    assert lib.lion_conv3d_stat_tiles(32, 64, 32, 0) == 32768 // 512
+    assert lib.lion_conv3d_stat_tiles(32, 64, 32, 1) == 32768 // 256
+    assert lib.lion_conv3d_stat_tiles(16, 64, 32, 0) == 4096 // 256      # 8 x 1 x 32 = 256 < 512 -> 2x2 tiles
+    assert lib.lion_conv3d_stat_tiles(16, 128, 32, 0) == 4096 // 512
+    assert lib.lion_conv3d_stat_tiles(8, 128, 32, 0) == 512 // 128        # r = 8: one MFMA column block per wave
+    assert lib.lion_conv3d_stat_tiles(7, 64, 32, 0) == 0
+    assert lib.lion_conv3d_occupancy_ints(32, 64, 32) == 2 * 32 * 128 + 1
+    assert lib.lion_conv3d_occupancy_ints(8, 64, 32) == 0                  # never sparse at r = 8
+    assert lib.lion_conv3d_packed_floats(64, 3) == 4 * 27 * 64             # Cin padded to 4
+    assert lib.lion_conv3d_wgrad_workspace_floats(32, 64, 64, 32) == 32 * 1 * 4 * 64 * 64 * 27
+    assert lib.lion_conv3d_wgrad_workspace_floats(32, 32, 32, 32) == 32 * 4 * 4 * 32 * 32 * 27  # 4 spatial splits
+    assert lib.lion_conv3d_wgrad_workspace_floats(32, 3, 32, 32) == 0      # Cin % 4 != 0: library fallback
+    # pointwise conv: column tiles of 4 waves x VB x 32 columns
+    assert lib.lion_pwconv_stat_tiles(64, 32768) == 32768 // 512
+    assert lib.lion_pwconv_stat_tiles(128, 1000) == -(-1000 // 256)
+    assert lib.lion_pwconv_stat_tiles(48, 1000) == 0
+    assert lib.lion_pwconv_packed_floats(64, 35) == 36 * 64
+    # skinny GEMM: split K until ~256 workgroups, >= 8 k-steps per wave
+    assert lib.lion_skinny_splits(2048, 2048) == 4
+    assert lib.lion_skinny_splits(2048, 256) == 8                        # 8 output tiles only: split K further
+    assert lib.lion_skinny_splits(256, 2048) == 1
+    assert lib.lion_skinny_splits(128, 48) == 0
+    assert lib.lion_skinny_packed_floats(2048, 2048) == 2048 * 8 * 256
