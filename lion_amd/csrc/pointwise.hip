@@ -102,8 +102,11 @@ __global__ __launch_bounds__(256) void affine_swish_max_coop_kernel(const float 
   for (int i = 0; i < IT; ++i) {
     float best = fmaxf(fmaxf(swishf(v[i].x * a + b), swishf(v[i].y * a + b)),
                        fmaxf(swishf(v[i].z * a + b), swishf(v[i].w * a + b)));
-#pragma unroll
-    for (int s = 1; s < LPM; s <<= 1) best = fmaxf(best, __shfl_xor(best, s, 64));
+    // max over the LPM lanes of a centre: the same butterfly on DPP row operations (see common.h)
+    if (LPM >= 2) best = fmaxf(best, LION_DPP_F32(best, 0xB1));
+    if (LPM >= 4) best = fmaxf(best, LION_DPP_F32(best, 0x4E));
+    if (LPM >= 8) best = fmaxf(best, LION_DPP_F32(best, 0x141));
+    if (LPM >= 16) best = fmaxf(best, LION_DPP_F32(best, 0x140));
     const int m = m0 + i * MPW + lane / LPM;
     if ((lane % LPM) == 0 && m < M) y[(size_t)row * M + m] = best;
   }
