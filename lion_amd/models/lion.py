@@ -15,6 +15,7 @@ import torch
 from . import import_model
 from .latent_points_ada_localprior import PVCNN2Prior as LocalPrior
 from .vae_adain import Model as VAE
+from ..checkpoint import load_prior_checkpoint
 from ..diffusion import DiffusionDiscretized
 from .. import diffusion_ops
 
@@ -51,9 +52,7 @@ class LION(object):
         self.scheduler = DDPMSchedulerShim(self.diffusion)
 
     def load_model(self, model_path):
-        ckpt = torch.load(model_path, map_location=self.device)
-        self.priors.load_state_dict(ckpt['dae_state_dict'])
-        self.vae.load_state_dict(ckpt['vae_state_dict'])
+        load_prior_checkpoint(model_path, self.priors, self.vae, map_location=self.device)
         print(f'INFO finish loading from {model_path}')
 
     @torch.no_grad()
