@@ -64,7 +64,11 @@ _RELEASED_PRIOR = {
                        weight_kl_pt=1.0, weight_kl_feat=1.0, weight_kl_glb=1.0, latent_dim_ext=[64]),
     "clipforge": dict(enable=0, feat_dim=512),
     "data": dict(tr_max_sample_points=2048, te_max_sample_points=2048, cond_on_cat=0, cates="airplane",
-                 batch_size=20),
+                 batch_size=20, batch_size_test=10, num_workers=4, train_drop_last=1, dataset_scale=1,
+                 normalize_global=True, normalize_per_shape=False, normalize_shape_box=False,
+                 normalize_std_per_axis=False, recenter_per_shape=False, random_subsample=1,
+                 sample_with_replacement=1, clip_forge_enable=0, clip_model="ViT-B/32",
+                 type="datasets.pointflow_datasets"),
     "trainer": dict(type="trainers.train_2prior", seed=1, anneal_kl=1,
                     opt=dict(type="adam", lr=1e-3, beta1=0.9, beta2=0.99, weight_decay=0.0,
                              ema_decay=0.9999, grad_clip=-1.0)),

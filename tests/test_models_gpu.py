@@ -229,3 +229,30 @@ def test_geometry_prefetch_and_style_plan_do_not_change_the_local_prior():
         adagn.StylePlan.projected = real_projected
     err = (full - per_layer).abs().max().item() / per_layer.abs().max().item()
     assert err < 1e-5, err
+
+
+def test_graph_replay_equals_eager_denoisers():
+    """lion_amd/graph.py: one captured forward per denoiser, replayed with new inputs copied into the static buffers,
+    reproduces the eager forward (same kernels, same order; side-stream branches become parallel graph branches)."""
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.graph import GraphedDenoiser
+    from lion_amd.models.lion import LION
+    torch.manual_seed(5)
+    lion = LION(released_prior_cfg())
+    lion.priors.eval()
+    sh = lion.vae.latent_shape()
+    B = 2
+    zg = [torch.randn([B] + sh[0], device="cuda") for _ in range(3)]
+    zl = [torch.randn([B] + sh[1], device="cuda") for _ in range(3)]
+    ts = [torch.full((B,), v, device="cuda") for v in (999.0, 500.0, 1.0)]
+    with torch.no_grad():
+        style = lion.vae.global2style(zg[0])
+        for prior, zs, cond in ((lion.priors[0], zg, None), (lion.priors[1], zl, style)):
+            graphed = GraphedDenoiser(prior, zs[0], ts[0], condition_input=cond)
+            for x, t in zip(zs[1:], ts[1:]):  # inputs the capture never saw
+                want = prior(x=x, t=t, condition_input=cond, clip_feat=None).float()
+                got = graphed(x=x, t=t, condition_input=cond, clip_feat=None).float()
+                assert got.shape == want.shape
+                err = (got - want).abs().max().item() / want.abs().max().item()
+                assert err <= 1e-6, err
+            assert graphed.eval() is graphed and graphed.mixed_prediction == prior.mixed_prediction

@@ -130,3 +130,29 @@ def test_clip_conditioned_prior_step():
         out = lion.priors[1](x=torch.randn(2, 4096, 1, 1, device="cuda"), t=torch.tensor([5.0, 900.0], device="cuda"),
                              condition_input=torch.randn(2, 128, 1, 1, device="cuda"), clip_feat=clip)
     assert tuple(out.shape) == (2, 4096, 1, 1) and torch.isfinite(out).all()
+
+
+def test_resident_point_clouds_cut_batches_on_the_device(tmp_path):
+    """lion_amd/data.py::ResidentPointClouds on the GPU: batches are gathers of the HBM-resident pool (equal to the
+    host arrays at the reported indices), shards of two ranks are disjoint, draws without replacement are sets."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from synthetic_shapenet import write_tree
+    from lion_amd import data as D
+    tree = write_tree(str(tmp_path))
+    ds = D.ShapeNet15kPointClouds(categories=["airplane", "chair"], split="train", tr_sample_size=32,
+                                  normalize_global=True, random_subsample=True, root_dir=tree)
+    pool = torch.from_numpy(ds.train_points).float()
+    seen = []
+    for rank in (0, 1):
+        res = D.ResidentPointClouds(ds, "cuda", batch_size=4, rank=rank, world_size=2, seed=1, drop_last=False)
+        for b in res.epoch(2):
+            assert b["tr_points"].is_cuda and b["tr_points"].dtype == torch.float32
+            idx, pick = b["idx"].cpu(), b["select_idx"].cpu()
+            assert torch.equal(b["tr_points"].cpu(), pool[idx.unsqueeze(1), pick])
+            seen += idx.tolist()
+    assert sorted(seen) == list(range(len(ds)))
+    ds.sample_with_replacement = 0
+    pick = D.ResidentPointClouds(ds, "cuda", 4).pick_points(5).cpu()
+    assert all(len(set(r.tolist())) == 32 for r in pick)
