@@ -5,7 +5,11 @@
  * Every entry point replaces one function of the reference's pybind/ATen operator modules
  * (cited per function as file:line under /root/reference).  Conventions:
  *   - plain device pointers + sizes, no torch types; all tensors C-contiguous, fp32 / int32;
- *   - no allocation, no synchronisation, no global state inside: safe under hipGraph capture;
+ *   - no allocation, no synchronisation, no global state that results depend on: safe under hipGraph
+ *     capture and callable from any host thread, for any device of the process (the device is the
+ *     calling thread's current one; the only state kept is a per-device note of which kernels already
+ *     had their dynamic-LDS limit raised -- the first call of a kernel on a device makes one
+ *     hipFuncSetAttribute call, so run one call outside a capture first);
  *     scratch memory is passed in (`ws`, size from the matching lion_*_workspace_bytes());
  *   - every launch goes to the caller's `stream` (the reference mixes the legacy default stream
  *     and the current stream; here it is always the caller's stream);

@@ -16,6 +16,30 @@
 
 static inline int lion_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Dynamic-LDS limit of a kernel.  HIP keeps the attribute per device, so what has already been configured is
+// remembered per device (one slot per kernel instantiation at its launch site); the attribute call itself is
+// idempotent and the slot only grows, which makes concurrent first calls from several host threads harmless.
+#define LION_MAX_DEVICES 32
+struct LionLdsLimit {
+  size_t bytes[LION_MAX_DEVICES];
+};
+static inline int lion_current_device(int *dev) {
+  if (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev >= LION_MAX_DEVICES) return LION_EINVAL;
+  return 0;
+}
+template <typename K>
+static inline int lion_dynamic_lds(K kernel, size_t bytes, LionLdsLimit &limit) {
+  int dev = 0;
+  if (int e = lion_current_device(&dev)) return e;
+  if (bytes > limit.bytes[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    limit.bytes[dev] = bytes;
+  }
+  return 0;
+}
+
 // Parity-critical float arithmetic: one IEEE rounding per operation, never contracted into
 // an FMA, exactly like the -ffp-contract=off oracle.  (The whole library is also compiled with
 // -ffp-contract=off; the intrinsics make the intent explicit at the call sites that matter.)

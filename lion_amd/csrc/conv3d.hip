@@ -448,13 +448,15 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
                          int Cout, int r, const float *pa, const float *pb, const float *pbias, const float *tconst,
                          float *stats, int32_t *occ, hipStream_t st) {
   const int tiles = (r / TD) * (r / TH) * (r / TW);
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
+  static int cu_count[LION_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (int e = lion_current_device(&dev)) return e;
+  if (!cu_count[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LION_EINVAL;
-    n_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LION_EINVAL;
+    cu_count[dev] = prop.multiProcessorCount;
   }
+  const int n_cu = cu_count[dev];
   const long items = (long)B * tiles * (Cout / COT);
   const dim3 grid = occ ? dim3((unsigned)(items < 2L * n_cu ? items : 2L * n_cu)) : dim3(B, tiles, Cout / COT);
   constexpr int NT = 256;
@@ -465,14 +467,8 @@ static int launch_conv_t(const float *x, const float *wp, const float *bias, flo
                               (NT / 64) * COT * 2) * 4;
 #define LION_CONV_GO(PRO_, ST_)                                                                           \
   {                                                                                                       \
-    static size_t cfg = 0;                                                                                \
-    if (LDS > cfg) {                                                                                      \
-      hipError_t e = hipFuncSetAttribute(                                                                 \
-          reinterpret_cast<const void *>(&conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_>),              \
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);                                          \
-      if (e != hipSuccess) return (int)e;                                                                 \
-      cfg = LDS;                                                                                          \
-    }                                                                                                     \
+    static LionLdsLimit cfg = {};                                                                         \
+    if (int e = lion_dynamic_lds(&conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_>, LDS, cfg)) return e;  \
     conv3d_k3_kernel<TD, TH, TW, COT, VB, PRO_, ST_><<<grid, NT, LDS, st>>>(x, wp, bias, y, Cin, Cout, r, \
                                                                             pa, pb, pbias, tconst, stats, occ, B, \
                                                                             tiles);                      \

@@ -119,13 +119,8 @@ static int launch_wgrad(const float *x, const float *gy, int B, int Cin, int Cou
                         hipStream_t st) {
   constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
   const size_t lds = (size_t)(32 * 257 + CIT * HALO) * 4;
-  static size_t cfg = 0;
-  if (lds > cfg) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<TD, TH, TW, CIT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    cfg = lds;
-  }
+  static LionLdsLimit cfg = {};
+  if (int e = lion_dynamic_lds(&conv3d_wgrad_kernel<TD, TH, TW, CIT>, lds, cfg)) return e;
   conv3d_wgrad_kernel<TD, TH, TW, CIT><<<dim3(B * TS, Cin / CIT, Cout / 32), 256, lds, st>>>(x, gy, Cin, Cout, r, TS,
                                                                                            partial);
   LION_LAUNCH_CHECK();

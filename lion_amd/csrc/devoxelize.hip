@@ -341,23 +341,13 @@ static int devox_launch(const float *coords, const float *feat, int B, int C, in
     dim3 grid(lion_cdiv(C, CT), B);
 #define DEVOX_SLAB(LD_)                                                                                    \
   {                                                                                                        \
-    static size_t cfg0 = 0, cfg1 = 0;                                                                      \
+    static LionLdsLimit cfg0 = {}, cfg1 = {};                                                              \
     if (scale) {                                                                                           \
-      if (lds > cfg1) {                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&devox_slab_kernel<LD_, true>),  \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-        if (e != hipSuccess) return (int)e;                                                                \
-        cfg1 = lds;                                                                                        \
-      }                                                                                                    \
+      if (int e = lion_dynamic_lds(&devox_slab_kernel<LD_, true>, lds, cfg1)) return e;                    \
       devox_slab_kernel<LD_, true><<<grid, 256, lds, st>>>(coords, feat, C, N, r, PX, XS, CT, CI, slab_floats, \
                                                            training, out, inds, wgts, scale, shift);       \
     } else {                                                                                               \
-      if (lds > cfg0) {                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&devox_slab_kernel<LD_, false>), \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-        if (e != hipSuccess) return (int)e;                                                                \
-        cfg0 = lds;                                                                                        \
-      }                                                                                                    \
+      if (int e = lion_dynamic_lds(&devox_slab_kernel<LD_, false>, lds, cfg0)) return e;                   \
       devox_slab_kernel<LD_, false><<<grid, 256, lds, st>>>(coords, feat, C, N, r, PX, XS, CT, CI, slab_floats, \
                                                             training, out, inds, wgts, scale, shift);      \
     }                                                                                                      \
@@ -414,13 +404,8 @@ int lion_trilinear_devoxelize_backward(const float *gy, const int32_t *inds, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)r3 * 4;
   if (lds <= 128 * 1024 && (r3 % 4) == 0) {
-    static size_t configured = 0;
-    if (lds > configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&devox_bwd_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      configured = lds;
-    }
+    static LionLdsLimit configured = {};
+    if (int e = lion_dynamic_lds(&devox_bwd_lds_kernel, lds, configured)) return e;
     const int nt = r3 >= 16384 ? 1024 : 256;
     devox_bwd_lds_kernel<<<dim3(C, B), nt, lds, st>>>(gy, inds, wgts, C, N, r3, gx);
     LION_LAUNCH_CHECK();

@@ -176,13 +176,8 @@ static int launch_pw(const float *x, const float *wp, const float *bias, float *
   const size_t lds = pw_lds(CB, Cin, pa != nullptr);
 #define LION_PW_GO(PRO_, ST_)                                                                              \
   {                                                                                                        \
-    static size_t cfg = 0;                                                                                 \
-    if (lds > cfg) {                                                                                       \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pwconv_kernel<CB, VB, PRO_, ST_>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-      if (e != hipSuccess) return (int)e;                                                                  \
-      cfg = lds;                                                                                           \
-    }                                                                                                      \
+    static LionLdsLimit cfg = {};                                                                          \
+    if (int e = lion_dynamic_lds(&pwconv_kernel<CB, VB, PRO_, ST_>, lds, cfg)) return e;                   \
     pwconv_kernel<CB, VB, PRO_, ST_><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, Cout, L, pa, pb, stats); \
   }
   if (pa && stats) LION_PW_GO(true, true)

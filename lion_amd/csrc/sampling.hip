@@ -174,13 +174,8 @@ extern "C" int lion_furthest_point_sampling(const float *coords, int B, int N, i
   if (N <= 4096) return launch_fps_reg<16>(coords, B, N, M, idx, st);
   if (N <= 32768) {
     const size_t lds = (size_t)N * 4;
-    static size_t configured = 0;
-    if (lds > configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      configured = lds;
-    }
+    static LionLdsLimit configured = {};
+    if (int e = lion_dynamic_lds(&fps_lds_kernel, lds, configured)) return e;
     fps_lds_kernel<<<B, 1024, lds, st>>>(coords, N, M, idx);
     LION_LAUNCH_CHECK();
     return 0;

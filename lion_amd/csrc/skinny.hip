@@ -144,13 +144,8 @@ int lion_skinny_gemm(const float *pin, int ks_in, const float *bias_in, int act_
     return LION_EINVAL;
   if (Cout % 32 != 0) return LION_EUNSUPPORTED;
   const size_t lds = (size_t)16 * 1024 * 4;
-  static bool cfg = false;
-  if (!cfg) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_gemm_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    cfg = true;
-  }
+  static LionLdsLimit cfg = {};
+  if (int e = lion_dynamic_lds(&skinny_gemm_kernel, lds, cfg)) return e;
   skinny_gemm_kernel<<<dim3(Cout / 32, lion_skinny_splits(Cin, Cout), nb), 1024, lds, static_cast<hipStream_t>(stream)>>>(
       pin, ks_in, bias_in, act_in, addT, wp, Cin, Cout, pout);
   LION_LAUNCH_CHECK();

@@ -431,17 +431,6 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
   return p;
 }
 
-template <typename K>
-static int set_dyn_lds(K kernel, size_t bytes, size_t *configured) {
-  if (bytes > *configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
-    *configured = bytes;
-  }
-  return 0;
-}
-
 static int voxelize_impl(const float *feat, const int32_t *coords_i, const float *coords_f, int B,
                          int C, int N, int r, int normalize, float eps, float *out,
                          float *norm_coords, int32_t *ind, int32_t *cnt, void *ws, size_t ws_bytes,
@@ -461,9 +450,8 @@ static int voxelize_impl(const float *feat, const int32_t *coords_i, const float
     const int ch_cap = 16; // channel chunk: the next chunk's row loads overlap the previous chunk's store drain
 #define LION_VOX_LAUNCH(P1, NPV)                                                                       \
   {                                                                                                    \
-    static size_t cfg = 0;                                                                             \
-    int e = set_dyn_lds(&vox_fused_kernel<P1, NPV>, p.lds, &cfg);                                      \
-    if (e) return e;                                                                                   \
+    static LionLdsLimit cfg = {};                                                                      \
+    if (int e = lion_dynamic_lds(&vox_fused_kernel<P1, NPV>, p.lds, cfg)) return e;                    \
     vox_fused_kernel<P1, NPV><<<grid, VT, p.lds, st>>>(feat, coords_i, coords_f, B, C, N, r, p.S, p.CS, p.SV, \
                                                        p.n_words, p.arena_words, ch_cap, normalize, eps, out, \
                                                        norm_coords, ind, cnt);                         \
