@@ -50,6 +50,13 @@ __device__ __forceinline__ void cut(float v, unsigned short &hi, unsigned short 
   lo = __builtin_bit_cast(unsigned short, l);
 }
 
+// __syncthreads() is fence + barrier: hipcc puts s_waitcnt vmcnt(0) in front of it, i.e. the weight load issued in a
+// tap is waited for at the next tap's barrier, and the scheduler sinks that load to just before its use: L2 latency
+// is exposed 27 times per chunk (seen in the ISA of the first version, 856 us).  TUNED: barrier = this wave's LDS
+// writes have landed + s_barrier (register loads are tracked by the compiler's own waits), and the weight load is
+// pinned right behind the barrier with a scheduling fence so that it has a whole tap of MFMAs to arrive.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // w f32[Cout][Cin][27] -> wp u16[chunk][tap][piece][g][Cout][8]   (channel ci = chunk*16 + g*8 + j)
 __global__ void split_weights(const float *w, int Cin, int Cout, unsigned short *wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -61,7 +68,7 @@ __global__ void split_weights(const float *w, int Cin, int Cout, unsigned short 
   wp[(((((size_t)chunk * 27 + t) * 2 + 1) * 2 + g) * Cout + co) * 8 + j] = lo;
 }
 
-template <bool PRO>
+template <bool PRO, bool TUNED>
 __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
                                                             const float *__restrict__ bias,
                                                             const float *__restrict__ pro_a,
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
   const int chunks = Cin / KC;
   u4 wreg = wp[we_g];
   for (int q = 0; q < chunks; ++q) {
-    __syncthreads(); // everyone is done with the previous chunk's planes (and spa/spb are visible)
+    if (TUNED && q) lds_barrier(); else __syncthreads(); // the previous chunk's planes are no longer read (spa/spb visible)
     // all loads of the chunk first (56 per thread in flight; items past the planes carry an out-of-range offset and
     // read 0), then activate + split + write: one memory round trip per chunk instead of one per item
     float v[NI][8];
@@ -156,8 +163,9 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
       const int s = q * 27 + tap;
       u4 *swb = sw + (s & 1) * WPL;
       swb[tid] = wreg;
-      __syncthreads(); // weight slice s (and, for tap 0, the planes) are in LDS
+      if (TUNED) lds_barrier(); else __syncthreads(); // weight slice s (and, for tap 0, the planes) are in LDS
       if (s + 1 < chunks * 27) wreg = wp[(size_t)(s + 1) * 4 * Cout + we_g];
+      if (TUNED) __builtin_amdgcn_sched_barrier(0); // the load stays here, a whole tap ahead of its use
       const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
       u4 wf[2][2], xf[2][2];
 #pragma unroll
@@ -178,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
           cor[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, wf[m][1]),
                                                              __builtin_bit_cast(h8, xf[n][0]), cor[m][n], 0, 0, 0);
         }
+      if (TUNED) __builtin_amdgcn_sched_barrier(0); // the next tap's LDS write + barrier stay behind these MFMAs
     }
   }
   // epilogue: D[row = channel][col = voxel], col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
@@ -196,14 +205,14 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
   }
 }
 
-template <bool PRO>
+template <bool PRO, bool TUNED>
 static void run(const char *name, int B, int Cin, int Cout, int r, const std::vector<float> &hx,
                 const std::vector<float> &hw, const std::vector<float> &hb, const std::vector<float> &hpa,
                 const std::vector<float> &hpb, float *dx, unsigned short *dwp, float *db, float *dpa, float *dpb,
                 float *dy) {
   const int r3 = r * r * r, tiles = (r / TD) * (r / TH) * (r / TW);
   const size_t lds = (size_t)(2 * 2 * HP + 2 * 2 * 2 * COT) * 16 + 2 * 256 * 4;
-  auto kern = &conv_layer_kernel<PRO>;
+  auto kern = &conv_layer_kernel<PRO, TUNED>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid(B, tiles, Cout / COT);
   const u4 *wp = reinterpret_cast<const u4 *>(dwp);
@@ -260,7 +269,7 @@ static void run(const char *name, int B, int Cin, int Cout, int r, const std::ve
   float ms = 0;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double flop = 2.0 * 27 * Cin * Cout * (double)r3 * B;
-  printf("%-22s B=%d %d->%d r=%d  rms err %.2e  max err %.2e  |  %7.1f us/launch  %6.1f TFLOP/s fp32-equivalent\n", name,
+  printf("%-26s B=%d %d->%d r=%d  rms err %.2e  max err %.2e  |  %7.1f us/launch  %6.1f TFLOP/s fp32-equivalent\n", name,
          B, Cin, Cout, r, sqrt(e2 / want.size()), emax, ms * 1e3 / launches, flop / (ms * 1e-3 / launches) / 1e12);
   fflush(stdout);
 }
@@ -301,7 +310,9 @@ int main() {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   printf("%s, %d CUs; whole layer, fp16x2 split at staging time\n", prop.name, prop.multiProcessorCount);
-  run<false>("plain", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
-  run<true>("AdaGN+Swish prologue", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<false, false>("plain", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<false, true>("plain, tuned barriers", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<true, false>("prologue", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<true, true>("prologue, tuned barriers", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
   return 0;
 }
