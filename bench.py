@@ -262,7 +262,10 @@ def main():
                        "conv1_empty_tile_skip": not args.no_sparse},
             "roofline": roof, "roofline_voxelize": roofv, "roofline_devoxelize": roofd,
         }
-        if not args.no_cpu_baseline:
+        if world > 1:  # the host baseline belongs to the 1-GPU line (other ranks would idle behind it)
+            out["cpu_baseline"] = {"value": None, "unit": "shapes/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "not timed at --gpus > 1; see the --gpus 1 line"}
+        elif not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:  # the baseline must never take the benchmark down
