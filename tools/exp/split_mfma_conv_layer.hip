@@ -68,7 +68,7 @@ __global__ void split_weights(const float *w, int Cin, int Cout, unsigned short 
   wp[(((((size_t)chunk * 27 + t) * 2 + 1) * 2 + g) * Cout + co) * 8 + j] = lo;
 }
 
-template <bool PRO, bool TUNED>
+template <bool PRO, int VAR>
 __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
                                                             const float *__restrict__ bias,
                                                             const float *__restrict__ pro_a,
@@ -122,8 +122,23 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
   // this thread's u4 of a weight slice: slice element e = (piece*2 + g)*COT + co -> global (piece*2 + g)*Cout + co0 + co
   const int we_g = (tid / COT) * Cout + co0 + (tid % COT);
 
+  // VAR 0: first version.  VAR 1 (TUNED): LDS-only barriers + pinned weight prefetch.  VAR 2 (WREG): every wave loads
+  // its weight fragments straight from L2 in operand order, one tap ahead -- no weight LDS, no per-tap barrier: the 4
+  // waves (and the 2 workgroups of the CU) drift apart, so one's staging overlaps the others' MFMAs.
+  constexpr bool TUNED = VAR == 1, WREG = VAR == 2;
   const int chunks = Cin / KC;
   u4 wreg = wp[we_g];
+  u4 wfr[3][2][2]; // WREG: ring of weight fragments, slot = tap % 3 (27 taps per chunk keep the phase), 2 taps ahead
+  const int wf_g = g * Cout + co0 + l32;
+  if (WREG) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          wfr[a][m][pc] = wp[(size_t)min(a, chunks * 27 - 1) * 4 * Cout + pc * 2 * Cout + wf_g + m * 32];
+  }
   for (int q = 0; q < chunks; ++q) {
     if (TUNED && q) lds_barrier(); else __syncthreads(); // the previous chunk's planes are no longer read (spa/spb visible)
     // all loads of the chunk first (56 per thread in flight; items past the planes carry an out-of-range offset and
@@ -162,16 +177,31 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
     for (int tap = 0; tap < 27; ++tap) {
       const int s = q * 27 + tap;
       u4 *swb = sw + (s & 1) * WPL;
-      swb[tid] = wreg;
-      if (TUNED) lds_barrier(); else __syncthreads(); // weight slice s (and, for tap 0, the planes) are in LDS
-      if (s + 1 < chunks * 27) wreg = wp[(size_t)(s + 1) * 4 * Cout + we_g];
-      if (TUNED) __builtin_amdgcn_sched_barrier(0); // the load stays here, a whole tap ahead of its use
-      const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
       u4 wf[2][2], xf[2][2];
+      if (WREG) {
+        if (tap == 0) __syncthreads(); // the planes of this chunk are written
+        const int sn = min(s + 2, chunks * 27 - 1); // the last two requests repeat the last slice (never used)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            wfr[(tap + 2) % 3][m][pc] = wp[(size_t)sn * 4 * Cout + pc * 2 * Cout + wf_g + m * 32];
+            wf[m][pc] = wfr[tap % 3][m][pc];
+          }
+        __builtin_amdgcn_sched_barrier(0); // the requests stay in front of this tap's MFMAs
+      } else {
+        swb[tid] = wreg;
+        if (TUNED) lds_barrier(); else __syncthreads(); // weight slice s (and, for tap 0, the planes) are in LDS
+        if (s + 1 < chunks * 27) wreg = wp[(size_t)(s + 1) * 4 * Cout + we_g];
+        if (TUNED) __builtin_amdgcn_sched_barrier(0); // the load stays here, a whole tap ahead of its use
+      }
+      const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
 #pragma unroll
       for (int pc = 0; pc < 2; ++pc) {
+        if (!WREG) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) wf[m][pc] = swb[(pc * 2 + g) * COT + m * 32 + l32];
+          for (int m = 0; m < 2; ++m) wf[m][pc] = swb[(pc * 2 + g) * COT + m * 32 + l32];
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) xf[n][pc] = sx[(pc * 2 + g) * HP + xbase[n] + toff];
       }
@@ -186,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
           cor[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, wf[m][1]),
                                                              __builtin_bit_cast(h8, xf[n][0]), cor[m][n], 0, 0, 0);
         }
-      if (TUNED) __builtin_amdgcn_sched_barrier(0); // the next tap's LDS write + barrier stay behind these MFMAs
+      if (TUNED || WREG) __builtin_amdgcn_sched_barrier(0); // the next tap's LDS write + barrier / loads stay behind these MFMAs
     }
   }
   // epilogue: D[row = channel][col = voxel], col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
@@ -205,14 +235,14 @@ __global__ __launch_bounds__(256, 2) void conv_layer_kernel(const float *__restr
   }
 }
 
-template <bool PRO, bool TUNED>
+template <bool PRO, int VAR>
 static void run(const char *name, int B, int Cin, int Cout, int r, const std::vector<float> &hx,
                 const std::vector<float> &hw, const std::vector<float> &hb, const std::vector<float> &hpa,
                 const std::vector<float> &hpb, float *dx, unsigned short *dwp, float *db, float *dpa, float *dpb,
                 float *dy) {
   const int r3 = r * r * r, tiles = (r / TD) * (r / TH) * (r / TW);
   const size_t lds = (size_t)(2 * 2 * HP + 2 * 2 * 2 * COT) * 16 + 2 * 256 * 4;
-  auto kern = &conv_layer_kernel<PRO, TUNED>;
+  auto kern = &conv_layer_kernel<PRO, VAR>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid(B, tiles, Cout / COT);
   const u4 *wp = reinterpret_cast<const u4 *>(dwp);
@@ -310,9 +340,11 @@ int main() {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   printf("%s, %d CUs; whole layer, fp16x2 split at staging time\n", prop.name, prop.multiProcessorCount);
-  run<false, false>("plain", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
-  run<false, true>("plain, tuned barriers", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
-  run<true, false>("prologue", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
-  run<true, true>("prologue, tuned barriers", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<false, 0>("plain", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<false, 1>("plain, tuned barriers", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<false, 2>("plain, weights from L2", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<true, 0>("prologue", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<true, 1>("prologue, tuned barriers", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
+  run<true, 2>("prologue, weights from L2", B, Cin, Cout, r, hx, hw, hb, hpa, hpb, dx, dwp, db, dpa, dpb, dy);
   return 0;
 }
