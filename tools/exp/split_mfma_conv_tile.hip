@@ -18,7 +18,7 @@
 // AdaGN+Swish prologue, weights once at pack time).
 //
 // Build + run on an MI355X:
-//   hipcc --offload-arch=gfx950 -O3 tools/exp/split_mfma_conv_tile.hip -o /tmp/split_conv && /tmp/split_conv
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/exp/split_mfma_conv_tile.hip -o /tmp/split_conv && /tmp/split_conv
 // prints, per variant: error against a float64 host convolution (relative to the output rms) and the effective
 // fp32-equivalent TFLOP/s with every CU busy (to compare with 141 TF of conv3d_k3_kernel and the 157.3 TF fp32 peak).
 // Variants: MODE (0 fp16x2, 1 bf16x3, 2 = one fp16 piece only: NOT accurate, shows the data-movement ceiling),
@@ -248,11 +248,102 @@ __global__ __launch_bounds__(256, OCC) void conv_tile_kernel(const u4 *__restric
       }
 }
 
+// Hand-pipelined form of the fp16x2 / weights-from-L2 loop (the shape the compiler does NOT produce by itself: it sinks
+// every load to its first use).  Weight fragments travel two taps ahead in a ring of three register sets (27 taps per
+// chunk keep the ring phase), the activation fragments of tap t+1 are read from LDS into the other half of a double
+// buffer before the 12 MFMAs of tap t are issued; scheduling fences keep that order.  One bubble per 16-channel chunk
+// (the first tap's activation fragments cannot be read before the planes are staged).
+template <int TD, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_tile_pipe_kernel(const u4 *__restrict__ xp, const u4 *__restrict__ wp,
+                                                             int chunks, int rep, float *__restrict__ out) {
+  constexpr int S = 2;
+  constexpr int HALO = halo_of(TD), NVOX = nvox_of(TD);
+  constexpr int NR = TD * TH / 4;
+  constexpr int XPL = S * 2 * HALO, WPL = S * 2 * COUT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u4 *sx = reinterpret_cast<u4 *>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, l32 = lane & 31;
+  f16v acc[2][NR], cor[2][NR];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = cor[m][n][r] = 0.f;
+  int xbase[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    const int row = NR * wave + n, d = row / TH, h = row % TH;
+    xbase[n] = (d * HH + h) * HW + l32;
+  }
+  const int steps = chunks * 27;
+  const int wbase = g * COUT + l32;
+  for (int it = 0; it < rep; ++it) {
+    u4 wfr[3][2][S], xfb[2][NR][S];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wfr[a][m][s] = wp[(size_t)min(a, steps - 1) * WPL + s * 2 * COUT + wbase + m * 32];
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+      __syncthreads();
+      for (int e = tid; e < XPL; e += 256) sx[e] = xp[(size_t)chunk * XPL + e];
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) xfb[0][n][s] = sx[(s * 2 + g) * HALO + xbase[n]]; // tap 0: offset 0
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int q = chunk * 27 + tap;
+        const int qn = min(q + 2, steps - 1); // the last two requests repeat the last slice (never used)
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) wfr[(tap + 2) % 3][m][s] = wp[(size_t)qn * WPL + s * 2 * COUT + wbase + m * 32];
+        if (tap + 1 < 27) {
+          const int t1 = tap + 1, toff = ((t1 / 9) * HH + (t1 / 3) % 3) * HW + t1 % 3;
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) xfb[t1 & 1][n][s] = sx[(s * 2 + g) * HALO + xbase[n] + toff];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NR; ++n) acc[m][n] = mma<0>(wfr[tap % 3][m][0], xfb[tap & 1][n][0], acc[m][n]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NR; ++n) cor[m][n] = mma<0>(wfr[tap % 3][m][0], xfb[tap & 1][n][1], cor[m][n]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NR; ++n) cor[m][n] = mma<0>(wfr[tap % 3][m][1], xfb[tap & 1][n][0], cor[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float *o = out + (size_t)blockIdx.x * COUT * NVOX;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NR; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const int vox = (NR * wave + n) * TW + l32;
+        o[(size_t)co * NVOX + vox] = acc[m][n][r] + cor[m][n][r] * (1.f / 2048.f);
+      }
+}
+
 static std::vector<float> g_x[5], g_w; // halo inputs per TD (index = TD), weights
 static std::vector<double> g_truth[5];
 static double g_rms[5];
 
-template <int MODE, int WSRC, int TD, int OCC, int UNR>
+template <int MODE, int WSRC, int TD, int OCC, int UNR, bool PIPE = false>
 static void run(const char *name, int Cin, int n_cu) {
   constexpr int S = Split<MODE>::S;
   constexpr int HALO = halo_of(TD), NVOX = nvox_of(TD);
@@ -271,7 +362,9 @@ static void run(const char *name, int Cin, int n_cu) {
   split_activations<MODE, HALO><<<(Cin * HALO + 255) / 256, 256>>>(dx, Cin, dxp);
   split_weights<MODE><<<(COUT * Cin * 27 + 255) / 256, 256>>>(dw, Cin, dwp);
   const size_t lds = (size_t)(S * 2 * HALO + (WSRC == 0 ? 2 * S * 2 * COUT : 0)) * 16;
-  auto kern = &conv_tile_kernel<MODE, WSRC, TD, OCC, UNR>;
+  void (*kern)(const u4 *, const u4 *, int, int, float *);
+  if constexpr (PIPE) kern = &conv_tile_pipe_kernel<TD, OCC>;
+  else kern = &conv_tile_kernel<MODE, WSRC, TD, OCC, UNR>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const u4 *xp = reinterpret_cast<const u4 *>(dxp), *wp = reinterpret_cast<const u4 *>(dwp);
   // correctness: one workgroup, one pass
@@ -299,7 +392,7 @@ static void run(const char *name, int Cin, int n_cu) {
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double flop = 2.0 * COUT * NVOX * Cin * 27 * rep * G * launches;
   printf("%-7s W%s TD%d occ%d %s  lds %5.1f KB  rms err %.2e  max err %.2e  |  %7.1f us/launch  %6.1f TFLOP/s fp32-equivalent\n",
-         name, WSRC ? "reg" : "lds", TD, OCC, UNR ? "unrolled" : "loop    ", lds / 1024.0, sqrt(e2 / ho.size()), emax, ms * 1e3 / launches,
+         name, WSRC ? "reg" : "lds", TD, OCC, PIPE ? "pipelined" : UNR ? "unrolled " : "loop     ", lds / 1024.0, sqrt(e2 / ho.size()), emax, ms * 1e3 / launches,
          flop / (ms * 1e-3) / 1e12);
   fflush(stdout);
   CHECK(hipFree(dx)); CHECK(hipFree(dw)); CHECK(hipFree(dxp)); CHECK(hipFree(dwp)); CHECK(hipFree(dout));
@@ -350,6 +443,8 @@ int main() {
   printf("%s, %d CUs; tiles TDx4x32 x %d channels, Cin %d\n", prop.name, n_cu, COUT, Cin);
   run<0, 1, 2, 2, 0>("fp16x2", Cin, n_cu);
   run<0, 1, 2, 2, 1>("fp16x2", Cin, n_cu);
+  run<0, 1, 2, 2, 1, true>("fp16x2", Cin, n_cu);
+  run<0, 1, 2, 1, 1, true>("fp16x2", Cin, n_cu);
   run<0, 0, 2, 2, 1>("fp16x2", Cin, n_cu);
   run<0, 1, 4, 1, 0>("fp16x2", Cin, n_cu);
   run<0, 1, 4, 1, 1>("fp16x2", Cin, n_cu);
