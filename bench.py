@@ -160,7 +160,7 @@ def main():
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     with torch.no_grad():
@@ -273,7 +273,7 @@ def main():
                                        "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
