@@ -7,10 +7,13 @@ GPU, the 1000-step DDIM chain of generate_samples_vada_2prior (trainers/train_2p
 (PVCNN2Prior, 14 PVConv / 4 SA / 4 FP per forward) + one VAE decode.  Weights are random-init of the
 released architecture (no checkpoints offline), latents are synthetic N(0, I): data = "synthetic".
 
-A "step" = one DDIM step of BOTH priors over the batch (model forward + fused update each), taken
-from the head of the real 1000-step chain (t = 999, 998, ...).  --steps 1000 is the full chain.
-    value = n_gpus * B / (1000 * ms_per_step / 1e3 + decode_seconds)        [shapes/s]
+The timed region is ONE call of the product sampler, lion_amd.sampling.generate_samples_vada_2prior(ddim_step=K)
+-- the function a user calls; the graph replay lives in it, not here.  A "step" = one DDIM step of BOTH priors over
+the batch.  --steps 1000 (default) is the metric's real chain:  value = n_gpus * B / elapsed.  For K < 1000 the call
+runs a K-step DDIM chain (uniform skip) and the line says "extrapolated":
+    value = n_gpus * B / (1000 * ms_per_step / 1e3 + decode_seconds),  ms_per_step = (elapsed - decode) / K.
 Each rank samples its own B shapes (independent units, no data-path collective): scaling = weak.
+`python bench.py --gpus N` starts its own N ranks when no launcher set WORLD_SIZE; under torchrun it is one rank.
 
 Extra objects on the JSON line:
   roofline      dominant kernel of the step (3x3x3 Conv3d 64->64 @32^3, 97 % of the FLOPs) timed
@@ -31,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_GBS = 6290.0       # measured float4-copy ceiling (same guide)
 MFMA_F32_PEAK_TF = 157.3    # fp32-input MFMA dense peak
 
 
@@ -46,6 +50,17 @@ def ev_time(fn, iters, warm=2):
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e-3
+
+
+def hbm_roofline(kernel, algorithmic_bytes, seconds):
+    """achieved = SURVEY.md 8d algorithmic bytes / HIP-event time; frac against the 8.0 TB/s spec, frac_of_copy_ceiling
+    against the 6.29 TB/s a float4 copy reaches on this part (MI355X_MICROARCH.md).  traffic: HBM bytes per launch
+    come from separate rocprofv3 --pmc passes (tools/prof_traffic.sh -> profiles/r02_*_traffic.json), they cannot be
+    collected inside this process, hence null here."""
+    gbs = algorithmic_bytes / seconds / 1e9
+    return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / HBM_COPY_GBS, "traffic": None,
+            "us_per_call": seconds * 1e6, "algorithmic_bytes": algorithmic_bytes}
 
 
 def build_models(cfg, device):
@@ -105,112 +120,135 @@ def cpu_baseline(cfg, budget_s=25.0):
         bk._backend = saved
 
 
+def _spawn(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, rendezvous on
+    127.0.0.1) and relay rank 0's JSON line.  Under torchrun (WORLD_SIZE set) this is not used."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p_ in procs[1:]:
+        rc = rc or p_.wait()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000, help="DDIM steps timed; 1000 = the full real chain (~20 s)")
+    ap.add_argument("--steps", type=int, default=1000,
+                    help="DDIM steps per prior that are timed; 1000 = the metric's real chain (~17 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="shapes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-sparse", action="store_true",
-                    help="run the first conv of every PVConv densely (no exact skip of all-zero input tiles)")
+                    help="run the voxel convolutions densely (no exact skip of all-zero input tiles)")
+    ap.add_argument("--no-dense-check", action="store_true", help="skip the short dense (--no-sparse) side measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn(args)
+    from lion_amd.models import pvcnn2_ada
     if args.no_sparse:
-        from lion_amd.models import pvcnn2_ada
         pvcnn2_ada.SPARSE_CONV1 = False
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    backend = os.environ.get("LION_BENCH_BACKEND", "nccl")  # "gloo": ranks sharing one device (launcher tests only)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=backend, init_method="env://")
 
     from lion_amd import _lib
     _lib.load()  # fail loudly if the HIP extension is missing
     from lion_amd.config import released_prior_cfg
-    from lion_amd import diffusion_ops
-    from lion_amd.sampling import rank_seed
+    from lion_amd.sampling import generate_samples_vada_2prior, rank_seed
 
     cfg = released_prior_cfg("airplane")
     lion = build_models(cfg, dev)
     d = lion.diffusion
     B, K, W = args.batch, args.steps, args.warmup
     assert 1 <= K <= 1000
-    torch.manual_seed(rank_seed(1234, rank))
     shapes = lion.vae.latent_shape()
-    steps = d.ddim_schedule(1000, 1000, "uniform")  # 999 .. 0
-    glob, local = lion.priors[0], lion.priors[1]
-
-    def ddim_steps(model, x, cond, first, count):
-        for i in range(first, first + count):
-            t = steps[i]
-            last = i == len(steps) - 1
-            s, c, sg = d.ddim_coefficients(t, None if last else steps[i + 1], 1.0)
-            ts = torch.full((B,), float(t + 1), device=dev)
-            eps = model(x=x, t=ts, condition_input=cond, clip_feat=None).float().contiguous()
-            z = torch.randn_like(x) if sg != 0.0 else None
-            x = diffusion_ops.ddim_update(x, eps, z, s, c, sg)
-        return x
+    graph = not args.no_graph
 
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
+    def sample(n_steps, seed):
+        """the PRODUCT sampler (lion_amd/sampling.py == trainers/train_2prior.py:50-127): n_steps DDIM steps of the
+        global prior, style, n_steps of the local prior, VAE decode."""
+        torch.manual_seed(seed)
+        return generate_samples_vada_2prior(shapes, lion.priors, d, lion.vae, B, ddim_step=n_steps,
+                                            ddim_skip_type='uniform', ddim_kappa=1.0, graph=graph)[0]
+
     with torch.no_grad():
-        xg = torch.randn([B] + shapes[0], device=dev)
-        xl = torch.randn([B] + shapes[1], device=dev)
-        style = lion.vae.global2style(torch.randn([B] + shapes[0], device=dev))
-        if not args.no_graph:
-            # one hipGraph per denoiser (untimed, like any other one-off setup): ~740 launches per
-            # local-prior forward are replayed without host launch overhead
-            from lion_amd.graph import GraphedDenoiser
-            t0_ = torch.full((B,), 1000.0, device=dev)
-            try:
-                glob_g = GraphedDenoiser(glob, xg, t0_, None)
-                local_g = GraphedDenoiser(local, xl, t0_, style)
-                glob, local = glob_g, local_g
-            except Exception as e:  # a failed capture must not cost the measurement: run eagerly and say so
-                print(f"bench: hipGraph capture failed ({e!r}); falling back to eager launches", file=sys.stderr, flush=True)
-                torch.cuda.synchronize()
-                args.no_graph = True
-        # warm-up (untimed): W steps of each prior
-        ddim_steps(glob, xg, None, 0, W)
-        ddim_steps(local, xl, style, 0, W)
+        # untimed: W warm-up steps per prior through the same call (captures the two chain graphs once)
+        sample(max(W, 1), rank_seed(999, rank))
         sync_all()
         t0 = time.perf_counter()
-        xg = ddim_steps(glob, xg, None, 0, K)          # K steps of the global chain
-        style = lion.vae.global2style(xg)
-        xl = ddim_steps(local, xl, style, 0, K)        # K steps of the local chain
+        pts = sample(K, rank_seed(1234, rank))          # K steps of each chain + one decode: the timed region
         sync_all()
         elapsed = time.perf_counter() - t0
-        # decode (once per 1000 steps), timed on its own
-        lion.vae.sample(num_samples=B, decomposed_eps=[xg, xl])
+        # the decode on its own (once per 1000 steps), to extrapolate honestly when K != 1000
+        eps = [torch.randn([B] + shapes[0], device=dev), torch.randn([B] + shapes[1], device=dev)]
+        lion.vae.sample(num_samples=B, decomposed_eps=eps)
         sync_all()
         t1 = time.perf_counter()
-        pts = lion.vae.sample(num_samples=B, decomposed_eps=[xg, xl])
+        lion.vae.sample(num_samples=B, decomposed_eps=eps)
         sync_all()
         decode_s = time.perf_counter() - t1
     assert tuple(pts.shape) == (B, 2048, 3)
 
     if world > 1:
-        tt = torch.tensor([elapsed, decode_s], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed, decode_s], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, decode_s = float(tt[0]), float(tt[1])
-    ms_per_step = elapsed / K * 1e3
-    value = world * B / (1000.0 * ms_per_step / 1e3 + decode_s)
+    chain_s = max(elapsed - decode_s, 1e-9)
+    ms_per_step = chain_s / K * 1e3
+    value = world * B / elapsed if K == 1000 else world * B / (1000.0 * ms_per_step / 1e3 + decode_s)
 
     out = None
     if rank == 0:
-        # ---- roofline: dominant kernel (Conv3d 64->64, 3^3, 32^3 grid, B=32: 29 of 59.7 GFLOP/shape) --
         from lion_amd.functional.backend import _backend as bk
         with torch.no_grad():
+            # how much of the step the exact sparse evaluation saves on THIS trajectory (random-weight latents drift
+            # into concentrated clouds): a short dense chain, same call
+            ms_dense = None
+            if not args.no_sparse and not args.no_dense_check:
+                pvcnn2_ada.SPARSE_CONV1 = False
+                try:
+                    d._chains.clear()
+                    kd = min(K, 20)
+                    sample(2, 1)
+                    torch.cuda.synchronize()
+                    td = time.perf_counter()
+                    sample(kd, rank_seed(1234, rank))
+                    torch.cuda.synchronize()
+                    ms_dense = (time.perf_counter() - td - decode_s) / kd * 1e3
+                finally:
+                    pvcnn2_ada.SPARSE_CONV1 = True
+                    d._chains.clear()
+            # ---- roofline: dominant kernel (Conv3d 64->64, 3^3, 32^3 grid, B=32: 29 of 59.7 GFLOP/shape) --
             conv = None
             for m in lion.priors[1].modules():
                 if isinstance(m, torch.nn.Conv3d) and m.in_channels == 64 and m.out_channels == 64:
@@ -224,42 +262,37 @@ def main():
                     "achieved": flops / tconv / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": flops / tconv / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
                     "us_per_launch": tconv * 1e6}
+            del xin
             C, N, r = 64, 2048, 32
             co = torch.randn(B, 3, N, device=dev)
             ft = torch.randn(B, C, N, device=dev)
             tv = ev_time(lambda: bk.voxelize_points_forward(ft, co, r, True, 0.0), 20)
             vbytes = 4.0 * B * (3 * N + C * N + C * r ** 3 + N + r ** 3) + 4.0 * B * 3 * N
-            roofv = {"kernel": "voxelize_points (P1+K1+K2) C=64 N=2048 r=32: vox_fused_kernel",
-                     "bound": "hbm", "achieved": vbytes / tv / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": vbytes / tv / 1e9 / HBM_PEAK_GBS, "traffic": None, "us_per_call": tv * 1e6,
-                     "algorithmic_bytes": vbytes}
+            roofv = hbm_roofline("voxelize_points (P1+K1+K2) C=64 N=2048 r=32: vox_fused_kernel", vbytes, tv)
             _, nc, _, _ = bk.voxelize_points_forward(None, co, r, True, 0.0)
             gridv = torch.randn(B, C, r ** 3, device=dev)
             td = ev_time(lambda: bk.trilinear_devoxelize_forward(r, False, nc, gridv), 20)
             dbytes = 4.0 * B * (3 * N + C * min(r ** 3, 8 * N) + C * N)       # 8 corners per point
-            dphys = 4.0 * B * (3 * N + C * r ** 3 + C * N)                    # what moves: the grid is read once
-            roofd = {"kernel": "trilinear_devoxelize C=64 N=2048 r=32: devox_slab_kernel (LDS-DMA slabs)",
-                     "bound": "hbm", "achieved": dbytes / td / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dbytes / td / 1e9 / HBM_PEAK_GBS, "traffic": dphys, "us_per_call": td * 1e6,
-                     "algorithmic_bytes": dbytes,
-                     "note": "traffic = bytes physically moved (whole grid read once): %.0f GB/s" % (dphys / td / 1e9)}
-            try:  # HBM bytes per call from the separate rocprofv3 --pmc passes (cannot be collected live)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_voxelize_traffic.json")))
-                roofv["traffic"] = tj["hbm_bytes_per_call"]
-            except Exception:
-                pass
+            roofd = hbm_roofline("trilinear_devoxelize C=64 N=2048 r=32 (eval): devoxelize.hip", dbytes, td)
         out = {
             "metric": "shapes/sec @1000-step DDIM, Bx2048pts", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: unconditional airplane prior sampling, 1000-step DDIM chain "
-                                   "(global PriorSEDrop + local PVCNN2Prior) + VAE decode",
+                                   "(global PriorSEDrop + local PVCNN2Prior) + VAE decode, through the product "
+                                   "sampler lion_amd.sampling.generate_samples_vada_2prior",
                        "shapes_per_gpu": B, "points": 2048, "chain_steps": 1000,
-                       "timed_steps_of_chain": K, "extrapolated": K != 1000, "decode_seconds": decode_s,
+                       "timed_steps_per_prior": K, "extrapolated": K != 1000, "decode_seconds": decode_s,
+                       "timed_region_seconds": elapsed,
                        "parallelism": f"{world} independent rank(s), no data-path collective",
-                       "launch": "eager" if args.no_graph else "hipGraph replay of each denoiser forward",
-                       "conv1_empty_tile_skip": not args.no_sparse},
+                       "launch": "hipGraph replay of [step prologue, denoiser forward, update + Philox noise]" if graph
+                                 else "eager",
+                       "sparse_voxel_convs": not args.no_sparse,
+                       "ms_per_step_dense_convs": ms_dense,
+                       "note": "step = one DDIM step of BOTH priors; with random-init weights the latents drift and "
+                               "the exact empty-tile skip saves a trajectory-dependent share of the conv work: "
+                               "ms_per_step_dense_convs is the same call with every tile computed (short chain)"},
             "roofline": roof, "roofline_voxelize": roofv, "roofline_devoxelize": roofd,
         }
         if world > 1:  # the host baseline belongs to the 1-GPU line (other ranks would idle behind it)
@@ -273,7 +306,7 @@ def main():
                                        "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -148,6 +148,21 @@ int lion_ddim_update(const float *x, const float *eps, const float *z, size_t nu
 int lion_ddpm_update(const float *x, const float *eps, const float *z, size_t numel,
                      int t_is_zero, float k_outer, float k_a, float k_b, float scale,
                      float temp, float *out, lionStream_t stream);
+/* The same updates for a chain that is replayed from ONE captured graph (whole-step capture, noise
+ * on the device): the host supplies nothing per step.
+ *   table f32[n_steps][8] = {t_model, a0..a5, -} per step, counter i32[1] (device), cur f32[8] (device).
+ * lion_chain_begin_step: i = clamp(*counter); t_out[0..B) = table[i][0]; cur[0..7) = table[i][0..7),
+ *   cur[7] = bits(i); *counter = i + 1.
+ * lion_chain_update_noise: z ~ N(0,1) drawn in the kernel (Philox4x32-10, key = the 64-bit seed in device memory, counter = (element/4,
+ *   cur step, stream_id); Box-Muller) replacing the reference's per-step CPU randn + H2D copy
+ *   (diffusion_pvd.py:465-466);  mode 0 (DDIM): out = x*a0 + (a1*eps + a2*z);
+ *   mode 1 (DDPM): a5 != 0: out = a0*(x - a1*eps), else out = a0*(x - a1*eps/a2) + (a3*z)*a4.
+ *   z_out (may be NULL) receives the noise that was used (tests / trajectories).  out may alias x. */
+int lion_chain_begin_step(const float *table, int n_steps, int32_t *counter, float *t_out, int B, float *cur,
+                          lionStream_t stream);
+int lion_chain_update_noise(int mode, const float *x, const float *eps, size_t numel, const float *cur,
+                            const uint32_t *seed /* device u32[2]: lo, hi */, uint32_t stream_id, float *out,
+                            float *z_out, lionStream_t stream);
 
 /* ---- C3: nn.Conv3d(kernel 3, stride 1, padding 1) of PVConv, models/pvcnn2_ada.py:211-222 --------
  * fp32-input MFMA implicit GEMM (exact fp32).  Weights are re-packed once per weight tensor:

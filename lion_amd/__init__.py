@@ -12,3 +12,10 @@ Nothing here falls back to a CPU implementation: without the built HIP library e
 operator raises RuntimeError.
 """
 __version__ = "0.1.0"
+
+
+def invalidate_weight_caches() -> None:
+    """Call after writing model weights through ``.data`` (which hides the write from the version counter):
+    packed / mirrored weights, style plans and captured graphs are rebuilt on next use (lion_amd/_wcache.py)."""
+    from . import _wcache
+    _wcache.invalidate_all()

@@ -67,6 +67,8 @@ SIGNATURES = {
     "lion_affine_swish_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_ddim_update": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp]),
     "lion_ddpm_update": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp, _vp]),
+    "lion_chain_begin_step": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "lion_chain_update_noise": (_i, [_i, _vp, _vp, _sz, _vp, _vp, C.c_uint32, _vp, _vp, _vp]),
 }
 
 _ERR = {-1: "LION_EINVAL (bad shape / null pointer)",

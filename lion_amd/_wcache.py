@@ -4,8 +4,33 @@ Keyed by the weight's storage address and shape, validated by its version counte
 it).  Every entry holds a STRONG reference to the weight tensor it was built from: while the entry lives the storage
 cannot be freed, so its address cannot be handed to a different tensor -- an id()- or address-keyed cache without
 that reference returns the previous owner's packed copy when a freed parameter's block is reused by a new parameter
-of the same shape (seen as a flaky parity test).  Least-recently-used entries are dropped beyond `capacity`."""
+of the same shape (seen as a flaky parity test).  Least-recently-used entries are dropped beyond `capacity`.
+
+The version counter only sees writes made through the tensor itself: ``p.data.copy_()`` / ``p.data[...] = `` write
+the same storage WITHOUT bumping it.  Writers inside this package therefore use ``with torch.no_grad(): p.copy_()``
+and additionally call ``invalidate_all()``, which advances a process-wide generation every entry (and every derived
+object: ``StylePlan``, ``GraphedDenoiser``) is validated against; code outside the package that pokes ``.data`` must
+call ``lion_amd.invalidate_weight_caches()`` itself."""
 from collections import OrderedDict
+
+_GENERATION = 0
+
+
+def generation() -> int:
+    return _GENERATION
+
+
+def invalidate_all() -> None:
+    """Declare every tensor derived from a weight stale (packed / mirrored copies, style plans, captured graphs)."""
+    global _GENERATION
+    _GENERATION += 1
+
+
+def fingerprint(module) -> tuple:
+    """What a captured graph or a plan over `module`'s weights is valid for: the generation, and the identity and
+    version of every parameter and buffer."""
+    items = list(module.parameters()) + list(module.buffers())
+    return (_GENERATION, tuple((t.data_ptr(), t._version) for t in items))
 
 
 class WeightCache:
@@ -17,11 +42,11 @@ class WeightCache:
     def get(self, weight):
         key = (weight.data_ptr(), tuple(weight.shape), weight.dtype, weight.device)
         hit = self._entries.get(key)
-        if hit is not None and hit[0] == weight._version:
+        if hit is not None and hit[0] == (weight._version, _GENERATION):
             self._entries.move_to_end(key)
             return hit[2]
         value = self._build(weight)
-        self._entries[key] = (weight._version, weight, value)
+        self._entries[key] = ((weight._version, _GENERATION), weight, value)
         self._entries.move_to_end(key)
         while len(self._entries) > self._capacity:
             self._entries.popitem(last=False)

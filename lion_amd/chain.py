@@ -1,0 +1,141 @@
+"""Whole-step capture of a sampling chain -- what ``DiffusionDiscretized.run_ddim`` /
+``run_denoising_diffusion`` / ``LION.sample`` run by default on the GPU.
+
+One denoiser evaluation of the local prior is ~500 kernel launches; the reference's samplers
+(utils/diffusion_pvd.py:224-303, :390-473) additionally issue ~10 elementwise launches, a ``torch.full`` and a
+host-side ``randn`` + H2D copy per step.  Here ONE hipGraph holds
+    lion_chain_begin_step  ->  denoiser forward  ->  lion_chain_update_noise
+and a chain of S steps is S replays of it.  Everything that changes from step to step lives in device memory:
+the schedule table (timestep for the model + the update's coefficients, S x 8 floats uploaded once per chain), the
+step counter, the Philox seed, the latent ``x`` (updated in place).  The host issues one ``hipGraphLaunch`` per step
+and never synchronises inside the chain.
+
+A captured graph bakes in the packed-weight pointers of its model: it is keyed by ``_wcache.fingerprint(model)``
+and re-captured when any parameter changed (optimizer step, EMA swap, checkpoint load).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, _wcache
+
+DDIM, DDPM = 0, 1
+
+
+class GraphedChain:
+    def __init__(self, model, num_samples, shape, condition_input, clip_feat, device, mode, capacity, warmup=2,
+                 record_noise=False):
+        self.model, self.mode, self.capacity = model, mode, int(capacity)
+        self.fingerprint = _wcache.fingerprint(model)
+        dev = torch.device(device)
+        size = [num_samples] + list(shape)
+        self.x = torch.zeros(size, device=dev)
+        self.t = torch.zeros(num_samples, device=dev)
+        self.cond = None if condition_input is None else condition_input.detach().clone().contiguous()
+        self.clip = None if clip_feat is None else clip_feat.detach().clone().contiguous()
+        self.table = torch.zeros(self.capacity, 8, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.seed = torch.zeros(2, dtype=torch.int32, device=dev)   # two 32-bit words of the Philox key
+        self.cur = torch.zeros(8, device=dev)
+        self.z = torch.zeros(size, device=dev) if record_noise else None   # tests: the noise each step used
+        self.table[:, 0] = 1.0
+        lib = _lib.load()
+
+        def step():
+            st = _lib.stream_ptr(dev)
+            _lib.check(lib.lion_chain_begin_step(_lib.ptr(self.table), self.capacity, _lib.ptr(self.counter),
+                                                 _lib.ptr(self.t), num_samples, _lib.ptr(self.cur), st),
+                       "chain_begin_step")
+            pred = model(x=self.x, t=self.t, condition_input=self.cond, clip_feat=self.clip)
+            eps = pred.float().contiguous()
+            _lib.check(lib.lion_chain_update_noise(mode, _lib.ptr(self.x), _lib.ptr(eps), self.x.numel(),
+                                                   _lib.ptr(self.cur), _lib.ptr(self.seed), 0, _lib.ptr(self.x),
+                                                   _lib.ptr(self.z), _lib.stream_ptr(dev)), "chain_update_noise")
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(warmup):   # first calls pack weights, set kernel attributes, fill caches
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            step()
+
+    def matches(self, condition_input, clip_feat):
+        same = lambda buf, new: (buf is None) == (new is None) and (buf is None or buf.shape == new.shape)
+        return same(self.cond, condition_input) and same(self.clip, clip_feat) \
+            and self.fingerprint == _wcache.fingerprint(self.model)
+
+    @torch.no_grad()
+    def run(self, x_init, table: np.ndarray, seed: int, condition_input=None, clip_feat=None, trajectory=None,
+            trajectory_before_last=False, noise_trajectory=None):
+        """x_init: the chain's start; table [S, 8] float32 rows {t_model, a0..a5, 0}.  Returns the final latent
+        (a fresh tensor).  `trajectory`: list that receives a copy of x after every step (before the last
+        step's update if `trajectory_before_last`, as run_denoising_diffusion reports it)."""
+        S = int(table.shape[0])
+        assert 1 <= S <= self.capacity and table.shape[1] == 8
+        self.x.copy_(x_init)
+        if self.cond is not None:
+            self.cond.copy_(condition_input)
+        if self.clip is not None:
+            self.clip.copy_(clip_feat)
+        self.table[:S].copy_(torch.from_numpy(np.ascontiguousarray(table, dtype=np.float32)), non_blocking=False)
+        self.counter.zero_()
+        words = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)
+        self.seed.copy_(torch.from_numpy(words))
+        for i in range(S):
+            if trajectory is not None and trajectory_before_last and i == S - 1:
+                trajectory.append(self.x.clone())
+            self.graph.replay()
+            if noise_trajectory is not None and self.z is not None:
+                noise_trajectory.append(self.z.clone())
+            if trajectory is not None and not (trajectory_before_last and i == S - 1):
+                trajectory.append(self.x.clone())
+        return self.x.clone()
+
+
+class ChainCache:
+    """the captured chains of one DiffusionDiscretized: (model, mode, batch shape) -> GraphedChain; a handful of
+    entries (each holds the private memory pool of one forward pass)."""
+
+    def __init__(self, capacity=4):
+        self._entries = {}
+        self._order = []
+        self._capacity = capacity
+
+    def get(self, model, num_samples, shape, condition_input, clip_feat, device, mode, table_capacity):
+        key = (id(model), mode, int(num_samples), tuple(shape), str(device))
+        hit = self._entries.get(key)
+        if hit is not None and hit.model is model and hit.capacity >= table_capacity \
+                and hit.matches(condition_input, clip_feat):
+            self._order.remove(key)
+            self._order.append(key)
+            return hit
+        if hit is not None:
+            del self._entries[key]
+            self._order.remove(key)
+        chain = GraphedChain(model, num_samples, shape, condition_input, clip_feat, device, mode, table_capacity)
+        self._entries[key] = chain
+        self._order.append(key)
+        while len(self._order) > self._capacity:
+            del self._entries[self._order.pop(0)]
+        return chain
+
+    def clear(self):
+        self._entries.clear()
+        self._order = []
+
+
+def draw_seed() -> int:
+    """64-bit Philox key for one chain, drawn from torch's default CPU generator: torch.manual_seed() keeps
+    governing reproducibility, as it does for the reference's per-step randn."""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def graphable(model, x, enable_autocast, extra_kwargs) -> bool:
+    """the chain graph covers the plain sampling configuration of every released model; anything else (mixed
+    prediction, autocast, grid embeddings, CPU tensors) takes the eager loop."""
+    return (x.is_cuda and not enable_autocast and not extra_kwargs
+            and not getattr(model, "mixed_prediction", False) and not torch.is_grad_enabled())

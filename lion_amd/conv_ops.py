@@ -82,8 +82,8 @@ def conv3d_k3_wgrad(x, gy, weight_shape):
 
 class _Conv3dK3(torch.autograd.Function):
     """forward, data gradient (the convolution with the mirrored, channel-swapped weights) and weight gradient
-    (voxels on the MFMA k axis) on the fp32 MFMA kernels; shapes they do not cover (Cin % 4 != 0) fall back to
-    ATen's convolution_backward (MIOpen)."""
+    (voxels on the MFMA k axis) on the fp32 MFMA kernels; shapes they do not cover fall back to ATen's
+    convolution_backward (MIOpen)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -98,7 +98,7 @@ class _Conv3dK3(torch.autograd.Function):
         cout, cin = weight.shape[:2]
         r = x.shape[2]
         own_dgrad = ctx.needs_input_grad[0] and r in (8, 16, 32) and cout % 4 == 0
-        own_wgrad = ctx.needs_input_grad[1] and supported(cin, cout, r) and cin % 4 == 0
+        own_wgrad = ctx.needs_input_grad[1] and supported(cin, cout, r)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         gx = gw = gb = None
         lib_mask = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1] and not own_wgrad,
@@ -112,7 +112,12 @@ class _Conv3dK3(torch.autograd.Function):
             if gx.shape[1] != cin:
                 gx = gx[:, :cin].contiguous()
         if own_wgrad:
-            gw = conv3d_k3_wgrad(x, gy, weight.shape)
+            if cin % 4:  # the kernel wants Cin % 4 == 0: zero input channels, their gradient rows sliced away
+                pad = 4 - cin % 4
+                xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, 0, pad))
+                gw = conv3d_k3_wgrad(xp, gy, (cout, cin + pad, 3, 3, 3))[:, :cin].contiguous()
+            else:
+                gw = conv3d_k3_wgrad(x, gy, weight.shape)
             if want_gb:
                 gb = gy.sum(dim=(0, 2, 3, 4))
         return gx, gw, gb
@@ -129,10 +134,8 @@ def conv3d_module(conv: torch.nn.Conv3d, x):
     if not ok:
         return conv(x)
     if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
-        w = conv.weight
-        if x.shape[1] % 4:  # zero input channels: autograd slices the gradients of the two pads away again
-            pad = 4 - x.shape[1] % 4
-            x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, 0, pad))
-            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, pad))
-        return _Conv3dK3.apply(x, w, conv.bias)
+        # always the module's own weight tensor: the packed / mirrored copies are cached per (storage, version),
+        # a padded temporary would miss every step and pin dead copies in HBM (odd Cin is padded inside
+        # conv3d_k3 / backward instead)
+        return _Conv3dK3.apply(x, conv.weight, conv.bias)
     return conv3d_k3(x, conv.weight, conv.bias)

@@ -10,8 +10,10 @@
 // float4 tiles.  Scan order is ascending target index with strict '<', i.e. the lowest index wins
 // ties exactly as in the reference (strict '<' inside a tile, strict '>' across tiles).  Distances
 // use the reference's expression without FMA contraction -> dist and idx are bit-exact.
-// The gradient is two gather passes (own term + terms scattered back through idx of the other
-// direction) into LDS rows, so the outputs are written once and need no pre-zeroing.
+// The gradient is the reference's arithmetic in two launches per direction: the own term is written
+// once per point (plain stores), the term handed to the matched point of the other cloud goes through
+// global float atomics (chamfer3D.cu:169-171), so the gradient buffers are written by the own-term
+// pass first and need no pre-zeroing; the atomic order is free, as in the reference.
 #include "common.h"
 #include <math.h>
 

@@ -3,18 +3,22 @@
 ``run_ddim`` :390-473; ``get_q_posterior_mean`` :475-486) and ``utils/diffusion.py:28-65``
 (``make_beta_schedule``).
 
-What changes on MI355X: the per-step update is ONE fused HIP kernel (``lion_ddim_update`` /
-``lion_ddpm_update``) instead of ~10 elementwise launches, and the step noise is drawn on the device
-(the reference's DDIM draws it on the CPU and copies it every step, :465-466).  The scalar
-coefficients are computed exactly as the reference computes them -- float32 0-d tensor arithmetic on
-the same float32 schedule -- so for identical (x, eps_hat, z) the update is bit-identical.
-``noise='cpu'`` reproduces the reference's CPU noise stream for seed-for-seed comparisons.
+What changes on MI355X: by default (``graph=True``, GPU tensors, eval) a chain is S replays of ONE captured
+hipGraph [step prologue -> denoiser forward -> fused update with on-chip Philox noise], nothing per step comes
+from the host (``lion_amd/chain.py``); the reference issues ~10 elementwise launches per step on top of the
+~500 of the denoiser and draws the DDIM noise on the CPU, copying it over every step (:465-466).  The scalar
+coefficients are computed exactly as the reference computes them -- float32 0-d tensor arithmetic on the same
+float32 schedule -- so for identical (x, eps_hat, z) the update is bit-identical (``lion_ddim_update`` /
+``lion_ddpm_update`` and the chain kernel share the arithmetic).  The noise STREAM differs by construction
+(Philox on the device vs torch's CPU generator): ``graph=False, noise='cpu'`` reproduces the reference's stream
+for seed-for-seed comparisons, ``graph=False`` alone the eager per-step loop.
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 
+from . import chain as _chain
 from . import diffusion_ops
 
 
@@ -76,6 +80,7 @@ class DiffusionDiscretized(object):
         self._alphas = self._h_alphas.to(self.device)
         self._alpha_bars = self._h_alpha_bars.to(self.device)
         self._betas_post_init = f32(betas_post_init).to(self.device)
+        self._chains = _chain.ChainCache()
 
     # ---- training-side quantities (reference :45-113) ------------------------------------------
     def _iw(self, B, timestep):
@@ -156,7 +161,9 @@ class DiffusionDiscretized(object):
     @staticmethod
     def ddim_schedule(diffusion_steps, S, skip_type='uniform'):
         """descending list of the visited timesteps (reference :408-419)."""
-        if skip_type == 'uniform':
+        if S == 1:
+            tau = [0]   # (the reference's expression divides by S - 1)
+        elif skip_type == 'uniform':
             c = (diffusion_steps - 1.0) / (S - 1.0)
             tau = [int(np.floor(i * c)) for i in range(S)]
         elif skip_type == 'quad':
@@ -174,8 +181,10 @@ class DiffusionDiscretized(object):
     @torch.no_grad()
     def run_denoising_diffusion(self, model, num_samples, shape, temp=1.0, enable_autocast=False,
                                 is_image=False, prior_var=1.0, condition_input=None, given_noise=None,
-                                clip_feat=None, cls_emb=None, grid_emb=None):
-        """Ancestral DDPM sampling, T model evaluations (reference :224-303)."""
+                                clip_feat=None, cls_emb=None, grid_emb=None, graph=True, keep_trajectory=True,
+                                noise_scale=None):
+        """Ancestral DDPM sampling, T model evaluations (reference :224-303).  ``noise_scale(t)`` overrides the
+        per-step noise standard deviation sqrt(beta_t) (LION.sample's scheduler variance)."""
         model.eval()
         dev = self.device
         size = [num_samples] + list(shape)
@@ -186,6 +195,22 @@ class DiffusionDiscretized(object):
         if cls_emb is not None:
             condition_input = cls_emb if condition_input is None else torch.cat([condition_input, cls_emb], dim=1)
         x_image = None
+        if graph and given_noise is None and _chain.graphable(model, x_noisy, enable_autocast, kwargs):
+            T = self._diffusion_steps
+            table = np.zeros((T, 8), np.float32)
+            for i, t in enumerate(reversed(range(T))):
+                is0, k_outer, k_a, k_b, scale = self.ddpm_coefficients(t)
+                if noise_scale is not None and not is0:
+                    scale = float(noise_scale(t))
+                table[i] = (t + 1, k_outer, k_a, k_b, scale, temp, 1.0 if is0 else 0.0, 0.0)
+            ch = self._chains.get(model, num_samples, shape, condition_input, clip_feat, dev, _chain.DDPM, T)
+            x_image = ch.run(x_noisy, table, _chain.draw_seed(), condition_input, clip_feat,
+                             trajectory=output_list['pred_x'] if keep_trajectory else None,
+                             trajectory_before_last=True)
+            if is_image:
+                x_image = (x_image.clamp(min=-1., max=1.) + 1.0) / 2.0
+            model.train()
+            return x_image, output_list
         for t in reversed(range(0, self._diffusion_steps)):
             timestep = torch.full((num_samples,), t + 1, dtype=torch.int64, device=dev)
             mixing = self.get_mixing_component(x_noisy, timestep, enabled=getattr(model, 'mixed_prediction', False))
@@ -210,7 +235,7 @@ class DiffusionDiscretized(object):
     def run_ddim(self, model, num_samples, shape, temp=1.0, enable_autocast=False, is_image=True,
                  prior_var=1.0, condition_input=None, ddim_step=100, skip_type='uniform', kappa=1.0,
                  clip_feat=None, grid_emb=None, x_noisy=None, dae_index=-1, noise='device',
-                 keep_trajectory=True):
+                 keep_trajectory=True, graph=True):
         """DDIM sampling with ``ddim_step`` model evaluations; kappa is DDIM's eta (reference :390-473)."""
         model.eval()
         dev = self.device
@@ -220,6 +245,18 @@ class DiffusionDiscretized(object):
         steps = self.ddim_schedule(self._diffusion_steps, ddim_step, skip_type)
         kwargs = {'grid_emb': grid_emb} if grid_emb is not None else {}
         output_list = []
+        if graph and noise == 'device' and _chain.graphable(model, x_noisy, enable_autocast, kwargs):
+            table = np.zeros((len(steps), 8), np.float32)
+            for i, t in enumerate(steps):
+                last = i == len(steps) - 1
+                s_, c_, sigma_ = self.ddim_coefficients(t, None if last else steps[i + 1], kappa)
+                table[i, :4] = (t + 1, s_, c_, sigma_)
+            ch = self._chains.get(model, num_samples, shape, condition_input, clip_feat, dev, _chain.DDIM,
+                                  self._diffusion_steps)
+            x_noisy = ch.run(x_noisy, table, _chain.draw_seed(), condition_input, clip_feat,
+                             trajectory=output_list if keep_trajectory else None)
+            model.train()
+            return x_noisy, output_list
         for i, t in enumerate(steps):
             last = i == len(steps) - 1
             if last:

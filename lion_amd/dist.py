@@ -45,10 +45,13 @@ def broadcast_params(params, is_distributed=True, src=0):
     flat = torch.cat([p.data.reshape(-1) for p in params])
     dist.broadcast(flat, src)
     off = 0
-    for p in params:
-        n = p.numel()
-        p.data.copy_(flat[off:off + n].view_as(p))
-        off += n
+    with torch.no_grad():  # through the parameter: bumps p._version so derived (packed) weights are rebuilt
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+    from . import _wcache
+    _wcache.invalidate_all()
 
 
 def average_gradients(params, is_distributed=True):
@@ -72,10 +75,12 @@ class BucketedGradAverager:
     def __init__(self, params, bucket_bytes: int = 32 << 20, overlap: bool = True):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
-        self.overlap = overlap and self.world > 1
+        self.overlap = bool(overlap)   # hooks are armed at world size 1 too (same code path; nothing to reduce)
         self.buckets = []      # (flat tensor, [params])
         self._pending = {}     # bucket id -> grads still missing this step
         self._bucket_of = {}
+        self._view_of = {}     # param -> its slice of the bucket
+        self._seen = set()     # params whose gradient landed this step
         self._works = []
         self._hooks = []
         self._stream = None
@@ -103,7 +108,8 @@ class BucketedGradAverager:
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         off = 0
         for p in plist:
-            p.grad = flat[off:off + p.numel()].view_as(p)  # .grad aliases the bucket: no pack/unpack copies
+            self._view_of[p] = flat[off:off + p.numel()].view_as(p)
+            p.grad = self._view_of[p]  # .grad aliases the bucket: no pack/unpack copies
             off += p.numel()
             self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(plist)))
@@ -111,9 +117,12 @@ class BucketedGradAverager:
     def _reset(self):
         self._pending = {i: len(pl) for i, (_, pl) in enumerate(self.buckets)}
         self._works = []
+        self._seen = set()
 
     def _launch(self, i):
         flat, _ = self.buckets[i]
+        if self.world == 1:
+            return
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._stream):
@@ -124,18 +133,53 @@ class BucketedGradAverager:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         self._works.append(work)
 
+    def _realias(self, p):
+        """`p.grad` must live inside its bucket.  ``zero_grad(set_to_none=True)`` (torch.optim's default) or a
+        ``p.grad = ...`` assignment breaks the aliasing: autograd then accumulates into a fresh tensor while the
+        bucket that gets all-reduced stays zero and the ranks silently diverge.  Heal it: move the gradient into
+        the bucket and point ``.grad`` back at the view."""
+        view = self._view_of[p]
+        g = p.grad
+        if g is None or g.data_ptr() == view.data_ptr():
+            return
+        view.copy_(g)
+        p.grad = view
+
     def _on_grad(self, p):
         i = self._bucket_of[p]
+        if p in self._seen:
+            raise RuntimeError("BucketedGradAverager: a parameter received a second gradient before finish(); "
+                               "two backward passes per step (gradient accumulation) need overlap=False")
+        self._seen.add(p)
+        self._realias(p)
         self._pending[i] -= 1
         if self._pending[i] == 0:
             self._launch(i)
 
     def zero_grad(self):
+        """zero the buckets and (re-)attach every ``.grad`` to its bucket view (parameters that got no gradient
+        in the previous step were detached by ``finish``; a foreign ``zero_grad(set_to_none=True)`` detaches all)."""
         for flat, _ in self.buckets:
             flat.zero_()
+        for p, view in self._view_of.items():
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
 
     def finish(self):
-        """Wait for (or, without overlap, perform) the averaging of every bucket."""
+        """Wait for (or, without overlap, perform) the averaging of every bucket.  Afterwards parameters that
+        received no gradient in this step have ``grad = None``, like in the reference, whose averaging and
+        optimizers skip them (utils/utils.py:725-727): Adam / EMA must not step them with zeros."""
+        if not self.overlap:  # no hooks: find out who got a gradient, heal broken aliasing
+            for p, view in self._view_of.items():
+                g = p.grad
+                if g is None:
+                    continue
+                if g.data_ptr() != view.data_ptr():
+                    self._realias(p)
+                    self._seen.add(p)
+            touched = None    # without hooks "received a gradient" cannot be told from "stayed zero"
+        else:
+            touched = self._seen
         if self.world > 1:
             if not self.overlap:
                 for i in range(len(self.buckets)):
@@ -148,6 +192,10 @@ class BucketedGradAverager:
                 w.wait()
             if self._stream is not None:
                 torch.cuda.current_stream().wait_stream(self._stream)
+        if touched is not None:
+            for p in self.params:
+                if p not in touched:
+                    p.grad = None
         self._reset()
 
     def remove_hooks(self):

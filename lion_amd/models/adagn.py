@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .dense import dense
+from .. import _wcache
 
 # Inference-time batching of the style projections: every AdaGN of a network projects the SAME style
 # vector with its own Linear(style, 2C).  StylePlan concatenates those weights once and evaluates all
@@ -22,7 +23,8 @@ class StylePlan:
         self._key, self._w, self._b = None, None, None
 
     def _weights(self):
-        key = tuple((m.emd.weight.data_ptr(), m.emd.weight._version, m.emd.bias._version) for m in self.mods)
+        key = (_wcache.generation(),) + tuple((m.emd.weight.data_ptr(), m.emd.weight._version, m.emd.bias._version)
+                                              for m in self.mods)
         if key != self._key:
             self._w = torch.cat([m.emd.weight.detach() for m in self.mods], 0).contiguous()
             self._b = torch.cat([m.emd.bias.detach() for m in self.mods], 0).contiguous()
@@ -61,8 +63,9 @@ class AdaGN(nn.Module):
         self.out_dim = n_channel * 2
         self.norm = nn.GroupNorm(8, n_channel)
         self.emd = dense(style_dim, n_channel * 2, init_scale=cfg.latent_pts.ada_mlp_init_scale)
-        self.emd.bias.data[:n_channel] = 1
-        self.emd.bias.data[n_channel:] = 0
+        with torch.no_grad():  # through the parameter, not .data: the version counter must see it (_wcache.py)
+            self.emd.bias[:n_channel] = 1
+            self.emd.bias[n_channel:] = 0
 
     def __repr__(self):
         return f"AdaGN(GN(8, {self.n_channel}), Linear({self.style_dim}, {self.out_dim}))"

@@ -3,10 +3,16 @@ prior], ``load_model`` (``dae_state_dict`` / ``vae_state_dict``) and ``sample``.
 
 The reference's demo path drives ``diffusers.DDPMScheduler`` (external, not vendored, not installed
 here).  ``DDPMSchedulerShim`` provides the three members ``LION.sample`` uses
-(``set_timesteps``, ``timesteps``, ``step(...).prev_sample``) implementing the DDPM ancestral step
-with beta_t variance, i.e. exactly what the in-tree ``DiffusionDiscretized.run_denoising_diffusion``
-does (utils/diffusion_pvd.py:224-303) -- parity at this boundary is "unpinned" by the reference
-(its variance_type string 'fixedlarge' is not one diffusers knows), see DESIGN.md.
+(``set_timesteps``, ``timesteps``, ``step(...).prev_sample``) implementing the DDPM ancestral step.
+The noise variance follows what diffusers 0.11.1 (env.yaml:155) does with the string the reference
+passes: ``variance_type=cfg.ddpm.model_var_type`` = 'fixedlarge' (default_config.py:221) is NOT one of
+diffusers' names ('fixed_large', 'fixed_small', ...), so ``DDPMScheduler._get_variance`` matches no
+branch and returns the posterior variance beta_t (1-abar_{t-1})/(1-abar_t) unclamped -- i.e. the
+demo path samples with the SMALL variance although the config says large.  The shim reproduces that
+('fixed_large' -> beta_t and 'fixed_small' -> clamped posterior are available by their diffusers
+names).  The mean is the in-tree posterior mean (utils/diffusion_pvd.py:475-486), algebraically equal
+to diffusers' x0-based form; floats differ at rounding level -- parity at this boundary stays
+"unpinned" by the reference (no test, dependency not vendored), see DESIGN.md / INTEGRATION.md.
 """
 from types import SimpleNamespace
 
@@ -21,10 +27,21 @@ from .. import diffusion_ops
 
 
 class DDPMSchedulerShim:
-    def __init__(self, diffusion: DiffusionDiscretized):
+    def __init__(self, diffusion: DiffusionDiscretized, variance_type: str = 'fixedlarge'):
         self.d = diffusion
         self.timesteps = None
         self.alphas_cumprod = diffusion._h_alpha_bars
+        self.variance_type = variance_type
+        self._post = diffusion._betas_post_init.detach().cpu()  # [t] = beta_t (1-abar_{t-1})/(1-abar_t), t >= 1
+
+    def _noise_scale(self, t: int) -> float:
+        """sqrt of the variance diffusers 0.11.1 ``_get_variance`` yields for this variance_type."""
+        if self.variance_type == 'fixed_large':
+            return float(torch.sqrt(self.d._h_betas[t]))
+        var = self._post[t]
+        if self.variance_type == 'fixed_small':
+            var = torch.clamp(var, min=1e-20)
+        return float(torch.sqrt(var))   # every other string, 'fixedlarge' included: no branch matches
 
     def set_timesteps(self, n, device='cuda'):
         T = self.d._diffusion_steps
@@ -33,7 +50,8 @@ class DDPMSchedulerShim:
 
     def step(self, noise_pred, t, x, generator=None):
         t = int(t)
-        is0, k_outer, k_a, k_b, scale = self.d.ddpm_coefficients(t)
+        is0, k_outer, k_a, k_b, _ = self.d.ddpm_coefficients(t)
+        scale = 0.0 if is0 else self._noise_scale(t)
         z = None if is0 else torch.randn(x.shape, device=x.device, generator=generator)
         out = diffusion_ops.ddpm_update(x.contiguous(), noise_pred.float().contiguous(), z, is0,
                                         k_outer, k_a, k_b, scale, 1.0)
@@ -49,7 +67,7 @@ class LION(object):
         local_prior = LocalPrior(cfg.sde, cfg.shapelatent.latent_dim, cfg).to(self.device)
         self.priors = torch.nn.ModuleList([global_prior, local_prior])
         self.diffusion = DiffusionDiscretized(None, None, cfg, device=self.device)
-        self.scheduler = DDPMSchedulerShim(self.diffusion)
+        self.scheduler = DDPMSchedulerShim(self.diffusion, variance_type=cfg.ddpm.model_var_type)
 
     def load_model(self, model_path):
         load_prior_checkpoint(model_path, self.priors, self.vae, map_location=self.device)
@@ -69,11 +87,12 @@ class LION(object):
         condition_input = None
         for prior, shp, key in ((global_prior, latent_shape[0], 'z_global'),
                                 (local_prior, latent_shape[1], 'z_local')):
-            x = torch.randn(size=[num_samples] + shp, device=self.device)
-            for t in self.scheduler.timesteps:
-                t_tensor = torch.full((num_samples,), t + 1, dtype=torch.int64, device=self.device)
-                eps = prior(x=x, t=t_tensor.float(), condition_input=condition_input, clip_feat=clip_feat)
-                x = self.scheduler.step(eps, t, x).prev_sample
+            # the reference's loop (:55-70: prior forward + scheduler.step per timestep) as one graphed chain:
+            # the scheduler's mean / variance rule feeds the chain's coefficient table (lion_amd/chain.py)
+            x, _ = self.diffusion.run_denoising_diffusion(
+                prior, num_samples, shp, condition_input=condition_input, clip_feat=clip_feat,
+                keep_trajectory=False, noise_scale=self.scheduler._noise_scale)
+            prior.eval()
             sampled.append(x)
             output_dict[key] = x
             if condition_input is None:

@@ -11,8 +11,10 @@ import torch
 @torch.no_grad()
 def generate_samples_vada_2prior(shape, dae, diffusion, vae, num_samples, enable_autocast=False,
                                  temp=1.0, ddim_step=0, clip_feat=None, ddim_skip_type='uniform',
-                                 ddim_kappa=1.0, noise='device', step_callback=None):
-    """shape: vae.latent_shape(); dae: [global prior, local prior].  Returns (points [B,N,3], info)."""
+                                 ddim_kappa=1.0, noise='device', step_callback=None, graph=True):
+    """shape: vae.latent_shape(); dae: [global prior, local prior].  Returns (points [B,N,3], info).
+    graph=True (default): every chain is replayed from one captured hipGraph per prior (lion_amd/chain.py);
+    graph=False: the eager per-step loop (noise='cpu' then reproduces the reference's noise stream)."""
     condition_input = None
     all_eps = []
     for i in range(len(dae)):
@@ -21,12 +23,12 @@ def generate_samples_vada_2prior(shape, dae, diffusion, vae, num_samples, enable
                                         is_image=False, ddim_step=ddim_step,
                                         condition_input=condition_input, clip_feat=clip_feat,
                                         skip_type=ddim_skip_type, kappa=ddim_kappa, noise=noise,
-                                        keep_trajectory=False)
+                                        keep_trajectory=False, graph=graph)
         else:
             eps, _ = diffusion.run_denoising_diffusion(dae[i], num_samples, shape[i], temp,
                                                        enable_autocast, is_image=False,
                                                        condition_input=condition_input,
-                                                       clip_feat=clip_feat)
+                                                       clip_feat=clip_feat, graph=graph, keep_trajectory=False)
         condition_input = eps
         if i == 0:
             condition_input = vae.global2style(condition_input)

@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from . import _wcache
 from .dist import BucketedGradAverager, average_gradients
 
 
@@ -119,9 +120,13 @@ class EMA(torch.optim.Optimizer):
                 ema = self.optimizer.state[p].get('ema')
                 if ema is None:
                     continue
-                if store_params_in_ema:
-                    tmp = p.data.detach().clone()
-                    p.data.copy_(ema)
-                    ema.copy_(tmp)
-                else:
-                    p.data.copy_(ema)
+                # written through the parameter (bumps p._version): packed-weight caches, style plans and
+                # captured graphs key on it; `.data.copy_` would leave the HIP kernels on the old packed copies
+                with torch.no_grad():
+                    if store_params_in_ema:
+                        tmp = p.detach().clone()
+                        p.copy_(ema)
+                        ema.copy_(tmp)
+                    else:
+                        p.copy_(ema)
+        _wcache.invalidate_all()

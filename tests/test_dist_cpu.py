@@ -73,6 +73,26 @@ def _w_bucketed(rank, world):
     avg3.zero_grad()
     (m3[0](x)).sum().backward()                   # only the first layer receives gradients
     avg3.finish()
+    # ... and, like in the reference (utils/utils.py:725-727), ends the step WITHOUT a gradient, so that
+    # Adam / EMA skip it instead of stepping it with zeros (weight decay, momentum)
+    assert all(p.grad is not None for p in m3[0].parameters())
+    assert all(p.grad is None for p in list(m3[2].parameters()) + list(m3[4].parameters()))
+    # a foreign zero_grad(set_to_none=True) (torch.optim's default) breaks the .grad <-> bucket aliasing:
+    # the hook moves the fresh gradient back into the bucket, the averaged result is still right
+    opt = torch.optim.SGD(m3.parameters(), lr=0.0)
+    avg3.zero_grad()
+    opt.zero_grad(set_to_none=True)
+    (m3(x) - y).square().mean().backward()
+    avg3.finish()
+    for p, q in zip(m3.parameters(), m2.parameters()):
+        assert p.grad.data_ptr() == avg3._view_of[p].data_ptr()
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7)
+    # two backward passes before finish() would reduce a bucket after the first one: refused loudly
+    avg3.zero_grad()
+    (m3(x) - y).square().mean().backward()
+    with pytest.raises(RuntimeError, match="second gradient"):
+        (m3(x) - y).square().mean().backward()
+    avg3.finish()
     avg3.remove_hooks()
     # non-overlapped mode gives the same numbers
     m4 = _model(100)

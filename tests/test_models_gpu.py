@@ -53,6 +53,19 @@ def test_blocks_forward_backward_vs_reference():
     o_fp.square().sum().backward()
     close(o_fp, z["fp_out"])
     close(cfeat.grad, z["fp_gcfeat"], 2e-4)
+    # every parameter gradient of the three block types against the reference's (block_grads.npz): each backward
+    # kernel of the training path (Conv3d dgrad / wgrad, GroupNorm / AdaGN, SE3d, LinearAttention, 1x1 convs,
+    # voxelize / devoxelize / grouping / interpolation backward) pinned at 1e-4 of the gradient's scale
+    zg = g("block_grads.npz")
+    worst = []
+    for tag, mod in (("pv", pv), ("sa", sa), ("fp", fp)):
+        for name, p in mod.named_parameters():
+            ref = zg[f"{tag}/{name}"]
+            err = np.abs(p.grad.detach().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3)
+            worst.append((err, f"{tag}/{name}"))
+    worst.sort(reverse=True)
+    print("block parameter gradients, worst scale-relative errors:", worst[:5])
+    assert len(worst) == 47 and worst[0][0] <= 1e-4, worst[:5]
 
 
 def test_priors_and_vae_decoder_vs_reference():

@@ -111,6 +111,47 @@ def test_prior_train_step_runs_and_learns():
     opt.swap_parameters_with_ema(store_params_in_ema=True)       # swapping twice restores the weights
 
 
+def test_ema_swap_reaches_the_hip_kernels():
+    """The HIP kernels run on packed / mirrored copies of the weights cached per (storage, version, generation)
+    (lion_amd/_wcache.py).  After the caches are warm, swapping in the EMA weights must change what the kernels
+    compute: the swapped model equals a FRESH model loaded with the same weights (nothing cached), and differs from
+    the pre-swap output."""
+    from lion_amd.models.lion import LION
+    from lion_amd.training import EMA, prior_train_step
+    cfg = _cfg(1024)
+    torch.manual_seed(0)
+    lion = LION(cfg)
+    opt = EMA(torch.optim.Adam(lion.priors.parameters(), lr=2e-3, betas=(0.9, 0.99)), ema_decay=0.5)
+    x = torch.randn(2, 1024, 3, device="cuda") * 0.5
+    for _ in range(3):
+        prior_train_step(lion.vae, lion.priors, lion.diffusion, opt, x)
+
+    xl = torch.randn(2, 4096, 1, 1, device="cuda")
+    xg = torch.randn(2, 128, 1, 1, device="cuda")
+    t = torch.tensor([5.0, 900.0], device="cuda")
+    cond = torch.randn(2, 128, 1, 1, device="cuda")
+
+    def run(priors):
+        priors.eval()
+        with torch.no_grad():
+            return (priors[0](x=xg, t=t, condition_input=None, clip_feat=None).clone(),
+                    priors[1](x=xl, t=t, condition_input=cond, clip_feat=None).clone())
+
+    g0, l0 = run(lion.priors)                                     # warms every derived-weight cache
+    opt.swap_parameters_with_ema(store_params_in_ema=True)        # EMA weights in
+    g1, l1 = run(lion.priors)
+    assert not torch.equal(g0, g1) and not torch.equal(l0, l1)
+    torch.manual_seed(0)
+    fresh = LION(cfg)
+    fresh.priors.load_state_dict(lion.priors.state_dict())
+    gf, lf = run(fresh.priors)
+    assert torch.equal(g1, gf), (g1 - gf).abs().max().item()
+    assert torch.allclose(l1, lf, rtol=1e-6, atol=1e-6), (l1 - lf).abs().max().item()
+    opt.swap_parameters_with_ema(store_params_in_ema=True)        # and back
+    g2, l2 = run(lion.priors)
+    assert torch.equal(g2, g0) and torch.allclose(l2, l0, rtol=1e-6, atol=1e-6)
+
+
 def test_clip_conditioned_prior_step():
     """config 5: AdaGN-conditioned denoisers with a synthetic [B,512] CLIP feature."""
     from lion_amd.config import released_prior_cfg
