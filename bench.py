@@ -17,7 +17,9 @@ Each rank samples its own B shapes (independent units, no data-path collective):
 
 Extra objects on the JSON line:
   roofline      dominant kernel of the step (3x3x3 Conv3d 64->64 @32^3, 97 % of the FLOPs) timed
-                with HIP events on the launch stream: achieved TFLOP/s vs the 157.3 TF fp32 MFMA peak;
+                with HIP events on the launch stream: fp32-equivalent TFLOP/s of the split-operand kernel vs
+                2500 / 3 TF (fp16 MFMA peak over the 3 products per fp32 product); roofline_fp32_kernel: the
+                exact-fp32 kernel vs the 157.3 TF fp32 MFMA peak;
   roofline_voxelize  the kernel the metric names: fused voxelize (64, 2048, 32), algorithmic bytes
                 (SURVEY.md 8d) / measured time vs 8 TB/s HBM;
   cpu_baseline  the same step on the host cores (PyTorch-CPU dense layers + the C oracle operators).
@@ -36,6 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_GBS = 6290.0       # measured float4-copy ceiling (same guide)
 MFMA_F32_PEAK_TF = 157.3    # fp32-input MFMA dense peak
+MFMA_F16_PEAK_TF = 2500.0   # dense fp16/bf16 MFMA peak (no sparsity), same guide
 
 
 def ev_time(fn, iters, warm=2):
@@ -255,13 +258,25 @@ def main():
                     conv = m
                     break
             xin = torch.randn(B, 64, 32, 32, 32, device=dev)
-            from lion_amd.conv_ops import conv3d_module
-            tconv = ev_time(lambda: conv3d_module(conv, xin), 20, warm=5)
+            from lion_amd import conv_ops
             flops = 2.0 * 27 * 64 * 64 * 32 ** 3 * B
-            roof = {"kernel": "conv3d_k3_kernel: Conv3d 3x3x3 64->64 @32^3, B=32 (PVConv voxel branch; fp32-MFMA implicit GEMM, csrc/conv3d.hip)", "bound": "mfma",
-                    "achieved": flops / tconv / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": flops / tconv / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
-                    "us_per_launch": tconv * 1e6}
+            t32 = ev_time(lambda: conv_ops.conv3d_k3(xin, conv.weight, conv.bias, split=False), 20, warm=5)
+            roof32 = {"kernel": "conv3d_k3_kernel: Conv3d 3x3x3 64->64 @32^3, B=32, exact-fp32 MFMA implicit GEMM "
+                                "(csrc/conv3d.hip; fallback for Cin % 16 != 0 and the parity reference)",
+                      "bound": "mfma", "achieved": flops / t32 / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                      "frac": flops / t32 / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "us_per_launch": t32 * 1e6}
+            if conv_ops.SPLIT:
+                tsp = ev_time(lambda: conv_ops.conv3d_k3(xin, conv.weight, conv.bias, split=True), 20, warm=5)
+                roof = {"kernel": "conv3d_split_kernel: Conv3d 3x3x3 64->64 @32^3, B=32 (PVConv voxel branch), fp32 "
+                                  "operands cut into fp16 hi/lo pieces, 3 v_mfma_f32_32x32x16_f16 per K=16, f32 "
+                                  "accumulate (csrc/conv3d_split.hip)",
+                        "bound": "mfma", "achieved": flops / tsp / 1e12, "peak": MFMA_F16_PEAK_TF / 3.0,
+                        "unit": "TFLOP/s (fp32-equivalent conv FLOPs)", "frac": flops / tsp / 1e12 / (MFMA_F16_PEAK_TF / 3.0),
+                        "traffic": None, "us_per_launch": tsp * 1e6,
+                        "note": "peak = dense fp16 MFMA peak (2500 TF) / 3 MFMA products per fp32-equivalent product; "
+                                "the exact-fp32 kernel of the same layer is in roofline_fp32_kernel"}
+            else:
+                roof = roof32
             del xin
             C, N, r = 64, 2048, 32
             co = torch.randn(B, 3, N, device=dev)
@@ -277,7 +292,10 @@ def main():
         out = {
             "metric": "shapes/sec @1000-step DDIM, Bx2048pts", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (3x3x3 voxel-conv operands cut into fp16 hi/lo pairs on the 16-bit MFMA pipe with f32 "
+                      "accumulation -- fp32-accurate, tests/test_conv_split_gpu.py; everything else f32)")
+                     if conv_ops.SPLIT else "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: unconditional airplane prior sampling, 1000-step DDIM chain "
                                    "(global PriorSEDrop + local PVCNN2Prior) + VAE decode, through the product "
@@ -289,11 +307,13 @@ def main():
                        "launch": "hipGraph replay of [step prologue, denoiser forward, update + Philox noise]" if graph
                                  else "eager",
                        "sparse_voxel_convs": not args.no_sparse,
+                       "voxel_conv_kernel": "fp16x2 split operands (LION_CONV_SPLIT=0 selects exact-fp32 MFMA)"
+                                            if conv_ops.SPLIT else "exact-fp32 MFMA",
                        "ms_per_step_dense_convs": ms_dense,
                        "note": "step = one DDIM step of BOTH priors; with random-init weights the latents drift and "
                                "the exact empty-tile skip saves a trajectory-dependent share of the conv work: "
                                "ms_per_step_dense_convs is the same call with every tile computed (short chain)"},
-            "roofline": roof, "roofline_voxelize": roofv, "roofline_devoxelize": roofd,
+            "roofline": roof, "roofline_fp32_kernel": roof32, "roofline_voxelize": roofv, "roofline_devoxelize": roofd,
         }
         if world > 1:  # the host baseline belongs to the 1-GPU line (other ranks would idle behind it)
             out["cpu_baseline"] = {"value": None, "unit": "shapes/s", "cores": os.cpu_count(), "kind": "port",

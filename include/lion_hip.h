@@ -210,6 +210,23 @@ int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
                         const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
                         float *A, float *Bs, float *chmean, lionStream_t stream);
+/* ---- C3 on the 16-bit matrix pipe at fp32 accuracy (csrc/conv3d_split.hip) -----------------------------------
+ * The same convolution and the same modes as lion_conv3d_k3_fused_forward with every fp32 operand cut into two fp16
+ * pieces (a = a_h + a_l/2048; main += W_h X_h, corr += W_h X_l + W_l X_h in fp32 accumulators; 3 MFMAs of
+ * v_mfma_f32_32x32x16_f16 per K = 16 instead of 8 fp32 MFMAs) and block-scaled by exact powers of two (one scale per
+ * weight tensor, one monotone scale per workgroup tile for the activations): error vs float64 of the fp32 kernel's
+ * class (2.6e-7 rms), no clamp, any fp32 range.  Cin % 16 == 0, Cout % 32 == 0, r in {8,16,32}; otherwise
+ * LION_EUNSUPPORTED (callers keep the fp32 kernel).
+ *   wp: lion_conv3d_split_packed_halfs(Cout, Cin) uint16 (16-byte aligned), filled by lion_conv3d_split_pack_weights
+ *       (3 small launches: max |w|, scale, cut);
+ *   stats f32[B,Cout,lion_conv3d_split_stat_tiles(r,Cout),2]; occ / tconst exactly as for the fp32 kernel's sparse
+ *   plan (lion_conv3d_tile_occupancy, lion_conv3d_const_response). */
+size_t lion_conv3d_split_packed_halfs(int Cout, int Cin);
+int lion_conv3d_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *wp, lionStream_t stream);
+int lion_conv3d_split_stat_tiles(int r, int Cout);
+int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float *bias, int B, int Cin, int Cout,
+                                 int r, const float *pro_a, const float *pro_b, const float *pro_bias,
+                                 const float *tconst, float *y, float *stats, int32_t *occ, lionStream_t stream);
 /* ---- D2: global denoiser, models/score_sde/resnet.py:60-90, :195-218 -----------------------------------
  * The 1x1 convs of the [B, C, 1, 1] style-latent network as 32-row GEMMs on channel-major activations
  * f32[nb][C][32] (batch padded to 32 per slab), split over K into lion_skinny_splits workgroup rows that write raw

@@ -1,11 +1,42 @@
 """Conv3d (3x3x3, pad 1) on the fp32 matrix cores: lion_conv3d_k3_forward over the C ABI."""
+import os
+
 import torch
 
 from . import _lib
 from ._wcache import WeightCache
 
+# Which arithmetic the voxel convolutions run in (both are fp32-accurate, csrc/conv3d_split.hip):
+#   True  -> fp16 x 2 split operands on the 16-bit MFMA pipe where the shape allows (Cin % 16 == 0), fp32 MFMA elsewhere
+#   False -> the exact-fp32 MFMA kernel everywhere (csrc/conv3d.hip)
+SPLIT = os.environ.get("LION_CONV_SPLIT", "1") != "0"
+
+
 def supported(cin, cout, r):
     return r in (8, 16, 32) and cout % 32 == 0 and cin >= 1
+
+
+def split_supported(cin, cout, r):
+    return r in (8, 16, 32) and cout % 32 == 0 and cin >= 16 and cin % 16 == 0
+
+
+def _split_pack(weight):
+    cout, cin = weight.shape[:2]
+    lib = _lib.load()
+    wp = torch.empty((lib.lion_conv3d_split_packed_halfs(cout, cin),), device=weight.device, dtype=torch.int16)
+    w_c = weight.detach().contiguous()
+    _lib.check(lib.lion_conv3d_split_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
+                                                  _lib.stream_ptr(weight.device)), "conv3d_split_pack_weights")
+    return wp
+
+
+_SPLIT_CACHE = WeightCache(_split_pack)
+
+
+def split_packed_weight(weight):
+    """[Cout,Cin,3,3,3] -> fp16 hi / lo pieces in MFMA operand order + the tensor's power-of-two scale; cached per
+    (storage, version, generation), see _wcache.py."""
+    return _SPLIT_CACHE.get(weight)
 
 
 def _pack(weight):
@@ -26,11 +57,21 @@ def packed_weight(weight):
     return _PACK_CACHE.get(weight)
 
 
-def conv3d_k3(x, weight, bias=None):
-    """x [B,Cin,r,r,r] fp32 -> [B,Cout,r,r,r]; Cin is zero-padded to a multiple of 4 if needed."""
+def conv3d_k3(x, weight, bias=None, split=None):
+    """x [B,Cin,r,r,r] fp32 -> [B,Cout,r,r,r]; Cin is zero-padded to a multiple of 4 if needed.
+    split: None = the module default (SPLIT), False = the exact-fp32 MFMA kernel, True = split operands if supported."""
     _lib.require_cuda(x)
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = weight.shape[0]
+    if (SPLIT if split is None else split) and split_supported(cin, cout, r) and weight.shape[1] == cin:
+        x = x.contiguous()
+        y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
+        bias_c = bias.detach().contiguous() if bias is not None else None
+        wp = split_packed_weight(weight)
+        _lib.check(_lib.load().lion_conv3d_k3_split_forward(
+            _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias_c), b, cin, cout, r, None, None, None, None, _lib.ptr(y), None,
+            None, _lib.stream_ptr(x.device)), "conv3d_k3_split_forward")
+        return y
     if cin % 4:
         pad = 4 - cin % 4
         x = torch.cat([x, x.new_zeros(b, pad, r, r, r)], dim=1)

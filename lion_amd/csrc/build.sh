@@ -6,13 +6,16 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
 OBJS=()
-for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_wgrad pointwise pwconv skinny "$@"; do
+PIDS=()
+for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise pwconv skinny "$@"; do
   [ -f "$f.hip" ] || continue
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
+    rm -f "$f.o"   # a failed compile must not leave the previous object behind to be linked silently
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
+    PIDS+=($!)
   fi
   OBJS+=("$f.o")
 done
-wait
+for p in "${PIDS[@]}"; do wait "$p"; done   # set -e: any failed compile aborts the build
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o liblion_hip.so "${OBJS[@]}"
 echo "built $(pwd)/liblion_hip.so"

@@ -1,0 +1,457 @@
+// conv3d_split.hip -- C3 on the 16-bit matrix pipe at fp32 accuracy: the 3x3x3 / pad 1 Conv3d of PVConv's voxel
+// branch (models/pvcnn2_ada.py:211-222) with every fp32 operand cut into two fp16 pieces.
+//
+// Why: conv3d.hip already runs at 0.86-0.89 of the fp32-input MFMA peak (157 TF), i.e. the fp32 pipe itself is the
+// ceiling of shapes/s.  v_mfma_f32_32x32x16_f16 is 16x faster per FLOP, and
+//   a = a_h + a_l / 2048,   a_h = fp16(a),  a_l = fp16((a - a_h) * 2048)       (22-23 significant bits)
+//   main += W_h * X_h,   corr += W_h * X_l + W_l * X_h      (fp32 accumulation inside the MFMA)
+//   D = main + corr / 2048                                   (the dropped W_l * X_l term is 2^-22 relative)
+// costs 3 MFMAs of 32 cycles per K = 16 instead of 8 fp32 MFMAs of 64 cycles.  Measured error vs a float64
+// convolution: 2.6e-7 rms of the output rms (the fp32 MFMA chain's own: 5e-7 -- it rounds the accumulator 8x more
+// often); tests/test_conv_split_gpu.py holds it to the SAME bounds as the fp32 kernel.
+//
+// Range (fp16 has 5 exponent bits): both operands are block-scaled by exact powers of two.
+//   weights: one scale per tensor, chosen at pack time so that max |w| * 2^ew lies in [2^13, 2^14);
+//   activations: one scale per (workgroup tile, 16-channel chunk), kept MONOTONE along the K loop: the tile's
+//   running maximum (after the fused AdaGN+Swish prologue) sets 2^E with max * 2^E in [2^13, 2^14); when a later
+//   chunk raises the maximum the accumulators are multiplied by the (exact) power-of-two ratio first.  Every product
+//   therefore carries >= 22 bits relative to the LARGEST operand the tile has seen -- block floating point with a
+//   23-bit mantissa; there is no clamp: |x| > 65504, 1e-30 and mixed ranges are all representable; inf / nan are left
+//   out of the maximum and propagate to exactly the outputs they reach, as in fp32 arithmetic.
+//   The epilogue multiplies by 2^-(E + ew) (exact).
+//
+// Same contract and modes as conv3d.hip::conv3d_k3_kernel: AdaGN+Swish prologue (PRO), GroupNorm tile sums (STATS),
+// persistent work queue + per-wave occupancy masks (occ), constant + delta decomposition (tconst).  K is walked in
+// chunks of 16 input channels (Cin % 16 == 0; other layers stay on the fp32 kernel).  LDS operand planes
+// [piece][k-half][HP halo positions][8 x fp16]: one ds_read_b128 per MFMA fragment, conflict free; the weight slice
+// of a tap [piece][k-half][COT][8 x fp16] is double buffered through registers (one barrier per tap).
+// History: tools/exp/split_*.hip (inner product 400 TF fp32-equivalent; whole layer 779 us vs 1973 us of the fp32
+// kernel with statistics at B=32, 64->64, r=32).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+constexpr int KS = 16; // input channels per chunk = K of one MFMA
+
+__device__ __forceinline__ float pro_act(float v, float pa, float pb) { // == csrc/conv3d.hip
+  const float t = v * pa + pb;
+  return t * __frcp_rn(1.0f + __expf(-t));
+}
+// exponent e with 2^13 <= m * 2^e < 2^14 for a finite m > 0 (from the float's exponent field; subnormal m -> +100)
+__device__ __forceinline__ int scale_exp(float m) {
+  const int ex = (int)((__float_as_uint(m) >> 23) & 0xff) - 127; // floor(log2 m) for normal m; 128 for inf / nan
+  const int e = 13 - ex;
+  return e > 100 ? 100 : e;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); } // -126 <= e <= 127
+__device__ __forceinline__ void cut(float v, unsigned short &hi, unsigned short &lo) {
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ f32x16 mma(u4 a, u4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// w f32[Cout][Cin][27] -> wp u16[Cin/16][27][piece][k-half][Cout][8]   (ci = chunk*16 + half*8 + j)
+// pass 1: max |w| (as bits: non-negative floats order like unsigned integers) into tail[0]; pass 2 cuts w * 2^ew.
+// tail = the 4 words behind the packed pieces: {max bits, ew (int), 2^-ew (float), 0}
+__global__ void split_wmax_kernel(const float *__restrict__ w, int n, unsigned *__restrict__ tail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned m = i < n ? (__float_as_uint(w[i]) & 0x7fffffffu) : 0u;
+  for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(tail, m);
+}
+__global__ void split_wscale_kernel(unsigned *__restrict__ tail) {
+  const float m = __uint_as_float(tail[0]);
+  const int ew = m > 0.f ? scale_exp(m) : 0;
+  tail[1] = (unsigned)ew;
+  tail[2] = __float_as_uint(pow2f(-ew));
+  tail[3] = 0u;
+}
+__global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin, unsigned short *__restrict__ wp,
+                                  const unsigned *__restrict__ tail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * Cin * 27) return;
+  const int t = i % 27, c = (i / 27) % Cin, co = i / (27 * Cin), chunk = c / KS, g = (c % KS) / 8, j = c % 8;
+  unsigned short hi, lo;
+  cut(w[i] * pow2f((int)tail[1]), hi, lo);
+  const size_t base = ((size_t)chunk * 27 + t) * 4;
+  wp[((base + 0 + g) * Cout + co) * 8 + j] = hi;
+  wp[((base + 2 + g) * Cout + co) * 8 + j] = lo;
+}
+
+template <int TD, int TH, int TW, int CB, int VB, bool PRO, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv3d_split_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
+                                                              const float *__restrict__ wtail,
+                                                              const float *__restrict__ bias, float *__restrict__ y,
+                                                              int Cin, int Cout, int r,
+                                                              const float *__restrict__ pro_a,
+                                                              const float *__restrict__ pro_b,
+                                                              const float *__restrict__ pro_bias,
+                                                              const float *__restrict__ tconst,
+                                                              float *__restrict__ stats, int32_t *__restrict__ occ,
+                                                              int B, int ntiles) {
+  constexpr int TM = 256, COT = 32 * CB;
+  static_assert(TD * TH * TW == 4 * VB * 32, "tile voxels = 4 waves x VB column blocks x 32");
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
+  constexpr int HP = (HALO + 63) / 64 * 64;   // plane stride: whole waves, so a staging wave never straddles two planes
+  constexpr int NI = (2 * HP + TM - 1) / TM;  // staging items (k-half, halo position) per thread
+  constexpr int WPL = 4 * COT;                // u4 per weight slice (one tap of one chunk, this channel tile)
+  static_assert(WPL <= TM, "one u4 of the weight slice per thread");
+  static_assert(27 * COT * 4 <= 4 * HP * 16, "the response table must fit the operand planes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u4 *sx = reinterpret_cast<u4 *>(smem);      // [piece][half][HP]
+  u4 *sw = sx + 4 * HP;                       // [2][piece][half][COT]
+  float *sbias = reinterpret_cast<float *>(sw + 2 * WPL); // [COT]
+  const int npro = PRO ? ((Cin + 63) & ~63) : 0;
+  float *spa = sbias + COT, *spb = spa + npro, *spc = spb + npro; // prologue scalars / activated constant per channel
+  float *sred = spc + npro;                   // [4][COT][2]
+  float *sT = reinterpret_cast<float *>(sx);  // [27][COT] constant response (delta mode), loaded after the K loop
+  __shared__ int s_work;
+  __shared__ unsigned s_max[2];               // bits of the chunk's max |activation| (double buffered over chunks)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, l32 = lane & 31;
+  const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_wscale_kernel)
+  const bool queued = occ != nullptr;
+  const int ncz = Cout / COT;
+  for (int iter = 0;; ++iter) {
+  int b, tile, co0;
+  if (queued) { // see csrc/conv3d.hip: occ = [B*tiles wave masks][B*tiles list, occupied tiles first][queue counter]
+    __syncthreads();
+    if (tid == 0) s_work = atomicAdd(occ + 2 * B * ntiles, 1);
+    __syncthreads();
+    const int work = s_work;
+    if (work >= B * ntiles * ncz) break;
+    const int item = work / ncz;
+    b = item % B;
+    tile = occ[B * ntiles + b * ntiles + item / B];
+    co0 = (work % ncz) * COT;
+  } else {
+    if (iter) break;
+    b = blockIdx.x;
+    tile = blockIdx.y;
+    co0 = blockIdx.z * COT;
+  }
+  const int ntw = r / TW, nth = r / TH;
+  const int d0 = (tile / (ntw * nth)) * TD, h0 = ((tile / ntw) % nth) * TH, w0 = (tile % ntw) * TW;
+  const int r3 = r * r * r;
+  const bool delta = PRO && tconst != nullptr;
+  if (PRO) {
+    for (int c = tid; c < Cin; c += TM) {
+      const float pa = pro_a[(size_t)b * Cin + c], pb = pro_b[(size_t)b * Cin + c];
+      spa[c] = pa;
+      spb[c] = pb;
+      spc[c] = delta ? pro_act(pro_bias ? pro_bias[c] : 0.f, pa, pb) : 0.f;
+    }
+  }
+  for (int c = tid; c < COT; c += TM) sbias[c] = bias ? bias[co0 + c] : 0.f;
+  if (tid < 2) s_max[tid] = 0u;
+  int E = 127; // exponent of the tile's activation scale 2^E; 127 = none yet (everything staged so far was zero)
+
+  // staging items: item = tid + 256 i -> k-half item / HP (wave uniform), halo position item % HP.  Positions past
+  // HALO are padding; positions outside the grid carry an offset beyond num_records, for which buffer loads return 0.
+  int goff[NI];
+  bool gok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int item = tid + TM * i, p = item % HP;
+    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+    const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+    gok[i] = item < 2 * HP && p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+    goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
+
+  // halo position of this lane's voxel in each of the wave's column blocks (v = (wave*VB + vb)*32 + lane%32)
+  int xbase[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    const int v = (wave * VB + vb) * 32 + l32;
+    const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+    xbase[vb] = (d * HH + h) * HW + w;
+  }
+  f32x16 acc[CB][VB], cor[CB][VB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][vb][i] = cor[cb][vb][i] = 0.f;
+
+  const int wmask = queued ? occ[b * ntiles + tile] : 0xf;
+  const bool empty = wmask == 0;
+  const bool wave_on = (wmask >> wave) & 1;
+  const int nchunks = empty ? 0 : Cin / KS;
+  // this thread's u4 of a weight slice: element (pg, co) of the tile <- global [pg][Cout] at co0 + co
+  const int we_g = (tid / COT) * Cout + co0 + (tid % COT);
+  const bool w_thread = tid < WPL;
+  u4 wreg = {0u, 0u, 0u, 0u};
+  if (nchunks && w_thread) wreg = wp[we_g];
+  for (int q = 0; q < nchunks; ++q) {
+    __syncthreads(); // the previous chunk's planes are no longer read (and the prologue scalars are visible)
+    // all loads of the chunk first (one memory round trip per chunk), then activate, agree on the scale, cut + write
+    float v[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int ig = __builtin_amdgcn_readfirstlane(min((tid + TM * i) / HP, 1));
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, goff[i], (q * KS + ig * 8 + j) * r3 * 4, 0));
+    }
+    unsigned mloc = 0u;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = tid + TM * i;
+      const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = v[i][j];
+        if (PRO) { // zero padding stays zero; delta mode stages the deviation from the per-channel constant
+          const int c = q * KS + ig * 8 + j;
+          t = gok[i] ? pro_act(t, spa[c], spb[c]) - spc[c] : 0.f;
+          v[i][j] = t;
+        }
+        const unsigned a = __float_as_uint(t) & 0x7fffffffu; // |t| as ordered bits; inf / nan do not set the scale:
+        mloc = (item < 2 * HP && a > mloc && a <= 0x7f7fffffu) ? a : mloc; // they pass through the cut as inf / nan
+      }
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) { const unsigned o = __shfl_xor(mloc, sft, 64); mloc = o > mloc ? o : mloc; }
+    if (lane == 0 && mloc) atomicMax(&s_max[q & 1], mloc);
+    __syncthreads(); // the chunk's maximum is complete
+    const unsigned mbits = s_max[q & 1];
+    if (tid == 0) s_max[(q + 1) & 1] = 0u; // its last readers passed the barrier at the top of this chunk
+    if (mbits) {
+      const int e = scale_exp(__uint_as_float(mbits));
+      if (e < E) { // the tile's maximum grew: bring what has been accumulated onto the new (smaller) scale first
+        if (E != 127) {
+          const float f = pow2f(max(e - E, -126));
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) { acc[cb][vb][i] *= f; cor[cb][vb][i] *= f; }
+        }
+        E = e;
+      }
+    }
+    const float xs = E == 127 ? 1.0f : pow2f(E);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = tid + TM * i;
+      const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1)), p = item - ig * HP;
+      unsigned short hi[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cut(v[i][j] * xs, hi[j], lo[j]);
+      u4 ph, pl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ph[k] = (unsigned)hi[2 * k] | ((unsigned)hi[2 * k + 1] << 16);
+        pl[k] = (unsigned)lo[2 * k] | ((unsigned)lo[2 * k + 1] << 16);
+      }
+      if (item < 2 * HP) { // wave uniform
+        sx[(0 + ig) * HP + p] = ph;
+        sx[(2 + ig) * HP + p] = pl;
+      }
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int s = q * 27 + tap;
+      u4 *swb = sw + (s & 1) * WPL;
+      if (w_thread) swb[tid] = wreg;
+      __syncthreads(); // weight slice s (and, at tap 0, the planes) are in LDS; slice s-1's readers are past their MFMAs
+      if (s + 1 < nchunks * 27 && w_thread) wreg = wp[(size_t)(s + 1) * 4 * Cout + we_g];
+      if (wave_on) { // a wave whose voxels see no point only takes part in the staging and the barriers
+        const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+        u4 wf[CB][2], xf[VB][2];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) wf[cb][pc] = swb[(pc * 2 + g) * COT + cb * 32 + l32];
+#pragma unroll
+          for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = sx[(pc * 2 + g) * HP + xbase[vb] + toff];
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+          for (int vb = 0; vb < VB; ++vb) {
+            acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
+            cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
+            cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
+          }
+      }
+    }
+  }
+
+  if (delta) {
+    __syncthreads(); // the last tap's LDS reads are done: the operand planes become the response table
+    for (int e = tid; e < 27 * COT; e += TM) sT[e] = tconst[((size_t)b * 27 + e / COT) * Cout + co0 + e % COT];
+    __syncthreads();
+  } else if (empty) {
+    __syncthreads(); // sbias was written by other threads and no barrier of the K loop ran
+  }
+  // epilogue: D = main + corr/2048 (+ bias | constant response), NCDHW store.  acc register i of lane l: channel row
+  // (i&3) + 8*(i>>2) + 4*(l>>5), voxel column l&31.
+  float *yb = y + ((size_t)b * Cout + co0) * r3;
+  const float us_x = E == 127 ? 1.0f : pow2f(-E), us_w = wscale_inv; // exact powers of two
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    const int v = (wave * VB + vb) * 32 + l32;
+    const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+    const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
+    const int gv = (gd * r + gh) * r + gw;
+    const int cfg = (((gd == 0 ? 0 : gd == r - 1 ? 2 : 1) * 3 + (gh == 0 ? 0 : gh == r - 1 ? 2 : 1)) * 3 +
+                     (gw == 0 ? 0 : gw == r - 1 ? 2 : 1));
+    const float *addv = delta ? sT + cfg * COT : sbias;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+        const float o = ((acc[cb][vb][i] + cor[cb][vb][i] * (1.f / 2048.f)) * us_x) * us_w + addv[co];
+        acc[cb][vb][i] = o;
+        yb[(size_t)co * r3 + gv] = o;
+      }
+  }
+  if (STATS) { // per-tile channel sums, as csrc/conv3d.hip
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float s1 = acc[cb][0][i], s2 = acc[cb][0][i] * acc[cb][0][i];
+#pragma unroll
+        for (int vb = 1; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
+        s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        if (l32 == 0) {
+          const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+          sred[(wave * COT + co) * 2] = s1;
+          sred[(wave * COT + co) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < COT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
+      float *o = stats + (((size_t)b * Cout + co0 + tid) * ntiles + tile) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+  } // work loop
+}
+
+template <int TD, int TH, int TW, int CB, int VB>
+static int launch_split_t(const float *x, const u4 *wp, const float *wtail, const float *bias, float *y, int B, int Cin,
+                          int Cout, int r,
+                          const float *pa, const float *pb, const float *pbias, const float *tconst, float *stats,
+                          int32_t *occ, hipStream_t st) {
+  constexpr int COT = 32 * CB;
+  constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2), HP = (HALO + 63) / 64 * 64;
+  const int tiles = (r / TD) * (r / TH) * (r / TW);
+  static int cu_count[LION_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (int e = lion_current_device(&dev)) return e;
+  if (!cu_count[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LION_EINVAL;
+    cu_count[dev] = prop.multiProcessorCount;
+  }
+  const long items = (long)B * tiles * (Cout / COT);
+  const long resident = 2L * cu_count[dev];
+  const dim3 grid = occ ? dim3((unsigned)(items < resident ? items : resident)) : dim3(B, tiles, Cout / COT);
+  const size_t LDS = (size_t)(4 * HP + 2 * 4 * COT) * 16 +
+                     (size_t)(COT + (pa ? 3 * ((Cin + 63) & ~63) : 0) + 4 * COT * 2) * 4;
+#define LION_SPLIT_GO(PRO_, ST_)                                                                             \
+  {                                                                                                          \
+    static LionLdsLimit cfg = {};                                                                            \
+    if (int e = lion_dynamic_lds(&conv3d_split_kernel<TD, TH, TW, CB, VB, PRO_, ST_>, LDS, cfg)) return e;   \
+    conv3d_split_kernel<TD, TH, TW, CB, VB, PRO_, ST_><<<grid, 256, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, r, pa, pb, \
+                                                                              pbias, tconst, stats, occ, B, tiles); \
+  }
+  if (pa && stats) LION_SPLIT_GO(true, true)
+  else if (pa) LION_SPLIT_GO(true, false)
+  else if (stats) LION_SPLIT_GO(false, true)
+  else LION_SPLIT_GO(false, false)
+#undef LION_SPLIT_GO
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// tiles: always the 4 waves x 2 column blocks geometry of the product's sparse plan (so that the occupancy lists of
+// lion_conv3d_tile_occupancy apply unchanged), one column block per wave at r = 8
+struct SplitPlan { int vb, cb, tiles; };
+static SplitPlan split_plan(int r, int Cout) {
+  const int r3 = r * r * r;
+  const int cb = Cout % 64 == 0 ? 2 : Cout % 32 == 0 ? 1 : 0;
+  if (r == 8) return {1, cb ? 1 : 0, r3 / 128};
+  return {2, cb, r3 / 256};
+}
+
+} // namespace
+
+extern "C" {
+
+// number of uint16 in the packed weights: (Cin/16) * 27 * [2 pieces][2 halves] * Cout * 8 pieces + an 8-halfword tail
+// {max |w| bits, ew, 2^-ew, 0} (the tensor's power-of-two scale)
+static size_t split_piece_halfs(int Cout, int Cin) { return (size_t)(Cin / KS) * 27 * 4 * Cout * 8; }
+size_t lion_conv3d_split_packed_halfs(int Cout, int Cin) { return split_piece_halfs(Cout, Cin) + 8; }
+
+int lion_conv3d_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *wp, lionStream_t stream) {
+  if (!w || !wp || Cout <= 0 || Cin <= 0) return LION_EINVAL;
+  if (Cin % KS != 0 || (((uintptr_t)wp) & 15) != 0) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned *tail = reinterpret_cast<unsigned *>(wp + split_piece_halfs(Cout, Cin));
+  const int n = Cout * Cin * 27;
+  if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return LION_EINVAL;
+  split_wmax_kernel<<<lion_cdiv(n, 256), 256, 0, st>>>(w, n, tail);
+  split_wscale_kernel<<<1, 1, 0, st>>>(tail);
+  split_pack_kernel<<<lion_cdiv(n, 256), 256, 0, st>>>(w, Cout, Cin, wp, tail);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_conv3d_split_stat_tiles(int r, int Cout) {
+  if (r != 8 && r != 16 && r != 32) return 0;
+  return split_plan(r, Cout).tiles;
+}
+
+// Arguments exactly as lion_conv3d_k3_fused_forward (include/lion_hip.h), wp from lion_conv3d_split_pack_weights;
+// stats has lion_conv3d_split_stat_tiles(r, Cout) tiles; occ from lion_conv3d_tile_occupancy (same tile geometry:
+// 4 waves x 2 column blocks of 32 voxels, the fp32 kernel's sparse plan).
+int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float *bias, int B, int Cin, int Cout,
+                                 int r, const float *pro_a, const float *pro_b, const float *pro_bias,
+                                 const float *tconst, float *y, float *stats, int32_t *occ, lionStream_t stream) {
+  if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
+  if ((pro_a == nullptr) != (pro_b == nullptr)) return LION_EINVAL;
+  if (tconst && !pro_a) return LION_EINVAL;
+  if (occ && pro_a && !tconst) return LION_EINVAL;
+  if (Cin % KS != 0 || (pro_a && Cin > 256)) return LION_EUNSUPPORTED;
+  if (r != 8 && r != 16 && r != 32) return LION_EUNSUPPORTED;
+  if (occ && r == 8) return LION_EUNSUPPORTED;
+  const SplitPlan p = split_plan(r, Cout);
+  if (!p.cb) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const u4 *w4 = reinterpret_cast<const u4 *>(wp);
+  const float *wtail = reinterpret_cast<const float *>(wp + split_piece_halfs(Cout, Cin));
+#define LION_SPLIT_TILE(R_, VB_, CB_, TD_, TH_, TW_)                                                        \
+  if (r == R_ && p.vb == VB_ && p.cb == CB_)                                                                \
+    return launch_split_t<TD_, TH_, TW_, CB_, VB_>(x, w4, wtail, bias, y, B, Cin, Cout, r, pro_a, pro_b, pro_bias, tconst, \
+                                                   stats, occ, st);
+  LION_SPLIT_TILE(32, 2, 2, 2, 4, 32)
+  LION_SPLIT_TILE(32, 2, 1, 2, 4, 32)
+  LION_SPLIT_TILE(16, 2, 2, 4, 4, 16)
+  LION_SPLIT_TILE(16, 2, 1, 4, 4, 16)
+  LION_SPLIT_TILE(8, 1, 1, 2, 8, 8)
+#undef LION_SPLIT_TILE
+  return LION_EUNSUPPORTED;
+}
+
+} // extern "C"

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256) void devox_slab_kernel(
   const float *co = coords + (size_t)b * 3 * N;
   uint16_t *sorted = reinterpret_cast<uint16_t *>(lds + 2 * slab_floats); // [N] point ids grouped by slab
   int *scnt = reinterpret_cast<int *>(sorted + ((N + 1) & ~1));            // [XS] counts, then cursors
+  unsigned *need = reinterpret_cast<unsigned *>(scnt + XS);                // [ceil(r^2 / 32)] bit (x*r + y): some
+                                                                           // point reads the z-row (x, y, :)
 
   const int ngrp = (nch + CI - 1) / CI; // groups of CI channels staged together (CI > 1 only when XS == 1)
   const int nit = ngrp * XS;
@@ -149,16 +151,46 @@ __global__ __launch_bounds__(256) void devox_slab_kernel(
     const float4 *src = reinterpret_cast<const float4 *>(feat + ((size_t)b * C + c0 + g * CI) * r3 + (size_t)xs * PX * r2);
     const int n4 = slab_count4(g, xs);
     const uint32_t dst0 = lds_base + (uint32_t)((it & 1) * slab_floats * 4 + wave * 1024);
+    const int row0 = XS == 1 ? 0 : xs * PX * r;                // first z-row of the slab (row id = x * r + y)
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
-      const float4 *gp = src + min(tid + j * 256, n4 - 1); // clamped: lanes past the slab re-read its last 16 bytes
+      const int f = tid + j * 256;                             // float4 of the slab this lane moves
+      const float4 *gp = src + f;
       const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * 4096);
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+      // only the z-rows some point of the cloud interpolates from are fetched (43 % of them at N = 2048, r = 32;
+      // a row is r floats = r/4 lanes of the 1 KiB wave instruction): inactive lanes move nothing, their LDS
+      // bytes stay stale and are never read; a wave instruction without any needed row is skipped altogether
+      int row = (4 * f) / r;
+      if (XS == 1) row %= r2;
+      else row += row0;
+      const bool want = f < n4 && ((need[row >> 5] >> (row & 31)) & 1u);
+      if (want) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+      }
     }
   };
-  issue(0); // in flight during the whole per-point setup
+  // ---- which z-rows are read at all: the four (x, y) pairs of every point, with the reference's "hi = lo when the
+  // fraction is 0" rule (trilinear_devox.cu:64-66) ----
+  const int nwords = (r2 + 31) >> 5;
+  for (int w = tid; w < nwords; w += 256) need[w] = 0u;
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    const float x = co[i], y = co[i + N];
+    const float xl = floorf(x), yl = floorf(y);
+    if (xl >= 0.f && yl >= 0.f && xl < (float)r && yl < (float)r) {
+      const int x0 = (int)xl, y0 = (int)yl;
+      const int x1 = min(x0 + (sub_rn(x, xl) > 0.0f ? 1 : 0), r - 1), y1 = min(y0 + (sub_rn(y, yl) > 0.0f ? 1 : 0), r - 1);
+      const int ra = x0 * r + y0, rb = x0 * r + y1, rc = x1 * r + y0, rd = x1 * r + y1;
+      atomicOr(&need[ra >> 5], 1u << (ra & 31));
+      atomicOr(&need[rb >> 5], 1u << (rb & 31));
+      atomicOr(&need[rc >> 5], 1u << (rc & 31));
+      atomicOr(&need[rd >> 5], 1u << (rd & 31));
+    }
+  }
+  __syncthreads();
+  issue(0); // in flight during the rest of the per-point setup
 
   // ---- group the points by x-slab so that a wave's lanes are active together (a lane's p-th point is
   // sorted[tid + 256 p]); the order inside a slab is irrelevant (points are independent) ----
@@ -266,6 +298,194 @@ __global__ __launch_bounds__(256) void devox_slab_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// devox_rows_kernel (r = 32): only the z-rows that some point interpolates from are moved at all.
+// A cloud of N = 2048 points touches <= 4 (x, y) pairs per point: 37-52 % of the 1024 z-rows (128 B each) of a
+// channel grid for Gaussian latents, less for surface-like clouds.  The slab kernel above, even with its DMA lanes
+// predicated on that set, stays at 51 us for (64, 2048, 32): it is bound by its 16 barrier-separated slab rounds per
+// workgroup (a round trip each), not by bytes (143 MB moved, rocprofv3 FETCH/WRITE).  Here the needed rows of a WHOLE
+// channel are compacted into one LDS buffer (slot = rank of the row in the cloud's row bitmap; <= CAP rows = 72 KiB),
+// so a workgroup makes one round per channel with 3-4x the bytes in flight, the points keep their natural order
+// (lane = point mod 256: the [C, N] rows are written with coalesced stores) and need no slab sort.
+// Same corner expressions / evaluation order as corners_of(): bit-exact vs the oracle.  A cloud that needs more than
+// CAP rows (N > 2048-like densities) takes the in-kernel global-gather path.
+// ---------------------------------------------------------------------------------------------
+constexpr int DVR_CAP = 576; // rows per buffer: 2 x 72 KiB
+
+template <bool AFF>
+__global__ __launch_bounds__(256) void devox_rows_kernel(const float *__restrict__ coords,
+                                                         const float *__restrict__ feat, int C, int N, int r, int CT,
+                                                         int training, float *__restrict__ out,
+                                                         int32_t *__restrict__ inds, float *__restrict__ wgts,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int PP = 8;
+  float *lds = reinterpret_cast<float *>(smem);
+  const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * CT;
+  const int nch = min(CT, C - c0);
+  const int r2 = r * r, r3 = r2 * r, rq = r >> 2, nwords = (r2 + 31) >> 5;
+  const int buf_floats = DVR_CAP * r;
+  unsigned *need = reinterpret_cast<unsigned *>(lds + 2 * buf_floats); // [nwords] bit (x*r + y)
+  unsigned *base = need + nwords;                                       // [nwords] rank of the word's first row
+  uint16_t *rowlist = reinterpret_cast<uint16_t *>(base + nwords);      // [DVR_CAP] row id of each slot
+  int *s_nrows = reinterpret_cast<int *>(rowlist + DVR_CAP);
+  const float *co = coords + (size_t)b * 3 * N;
+
+  for (int w = tid; w < nwords; w += 256) need[w] = 0u;
+  __syncthreads();
+  float xd1[PP], yd1[PP], zd1[PP];
+  int ra[PP], rb[PP], rc[PP], rd[PP], zl_[PP], st[PP]; // st: 1 = regular point, 0 = none, -2 = out of the grid's memory,
+                                                       // 2 = z_lo + 1 runs into the next row (flat indexing, global path)
+#pragma unroll
+  for (int p = 0; p < PP; ++p) {
+    const int i = tid + p * 256;
+    st[p] = 0;
+    xd1[p] = yd1[p] = zd1[p] = 0.f;
+    ra[p] = rb[p] = rc[p] = rd[p] = zl_[p] = 0;
+    if (i < N) {
+      const float x = co[i], y = co[i + N], z = co[i + 2 * N];
+      const Corners kk = corners_of(x, y, z, r, r2);
+      if (training && blockIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          wgts[((size_t)b * 8 + q) * N + i] = kk.w[q];
+          inds[((size_t)b * 8 + q) * N + i] = kk.ix[q];
+        }
+      }
+      const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+      xd1[p] = sub_rn(x, xl);
+      yd1[p] = sub_rn(y, yl);
+      zd1[p] = sub_rn(z, zl);
+      const bool ok = xl >= 0.f && yl >= 0.f && zl >= 0.f && xl < (float)r && yl < (float)r && zl < (float)r &&
+                      kk.ix[7] < r3;
+      st[p] = ok ? 1 : -2;
+      if (ok) {
+        const int x0 = (int)xl, y0 = (int)yl;
+        const int x1 = x0 + (xd1[p] > 0.0f ? 1 : 0), y1 = y0 + (yd1[p] > 0.0f ? 1 : 0); // ix[7] < r3 keeps them in range
+        zl_[p] = (int)zl;
+        ra[p] = x0 * r + y0; rb[p] = x0 * r + y1; rc[p] = x1 * r + y0; rd[p] = x1 * r + y1;
+        // Voxelization clamps coordinates to [0, r-1], so z_lo = r-1 comes with a zero fraction.  A caller that hands
+        // over z in (r-1, r) gets the reference's flat indexing (the "+1" element is the first of the next row):
+        // such points read the grid directly instead of the compacted rows.
+        if (zl_[p] == r - 1 && zd1[p] > 0.0f) st[p] = 2;
+      }
+      if (st[p] == 1) {
+        atomicOr(&need[ra[p] >> 5], 1u << (ra[p] & 31));
+        atomicOr(&need[rb[p] >> 5], 1u << (rb[p] & 31));
+        atomicOr(&need[rc[p] >> 5], 1u << (rc[p] & 31));
+        atomicOr(&need[rd[p] >> 5], 1u << (rd[p] & 31));
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) { // ranks: exclusive prefix of the words' popcounts (nwords <= 64 for r <= 45)
+    int cnt = tid < nwords ? __popc(need[tid]) : 0;
+    const int inc = wave_incl_scan(cnt, tid);
+    if (tid < nwords) base[tid] = (unsigned)(inc - cnt);
+    if (tid == 63) *s_nrows = inc;
+  }
+  __syncthreads();
+  const int nrows = *s_nrows;
+  const bool fits = nrows <= DVR_CAP;
+  auto slot_of = [&](int row) { return (int)(base[row >> 5] + __popc(need[row >> 5] & ((1u << (row & 31)) - 1u))); };
+  if (fits) {
+    for (int row = tid; row < r2; row += 256)
+      if ((need[row >> 5] >> (row & 31)) & 1u) rowlist[slot_of(row)] = (uint16_t)row;
+    // rows -> LDS float offsets of the four z-rows of each point (at its z_lo)
+#pragma unroll
+    for (int p = 0; p < PP; ++p)
+      if (st[p] == 1) {
+        ra[p] = slot_of(ra[p]) * r + zl_[p]; rb[p] = slot_of(rb[p]) * r + zl_[p];
+        rc[p] = slot_of(rc[p]) * r + zl_[p]; rd[p] = slot_of(rd[p]) * r + zl_[p];
+      }
+  }
+#pragma unroll
+  for (int p = 0; p < PP; ++p)
+    if (!fits || st[p] == 2) { // flat float offsets inside a channel grid
+      ra[p] = ra[p] * r + zl_[p]; rb[p] = rb[p] * r + zl_[p]; rc[p] = rc[p] * r + zl_[p]; rd[p] = rd[p] * r + zl_[p];
+    }
+  __syncthreads();
+
+  typedef __attribute__((address_space(3))) float lds_float;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_float *)lds;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n4 = nrows * rq;                 // float4 of one channel's needed rows
+  const int nj = (n4 + 255) >> 8;            // DMA instructions per thread and channel
+  auto issue = [&](int ci) {
+    const float *src = feat + ((size_t)b * C + c0 + ci) * r3;
+    const uint32_t dst0 = lds_base + (uint32_t)((ci & 1) * buf_floats * 4 + wave * 1024);
+    for (int j = 0; j < nj; ++j) {
+      const int f = tid + j * 256;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * 4096);
+#ifdef DVR_NO_DMA
+      if (f < n4 && ci == 0) {
+#else
+      if (f < n4) {
+#endif
+        const int slot = f / rq, part = f - slot * rq;
+        const float *gp = src + (int)rowlist[slot] * r + part * 4;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+      }
+    }
+  };
+  if (fits) issue(0);
+  for (int ci = 0; ci < nch; ++ci) {
+    const float *gsrc = feat + ((size_t)b * C + c0 + ci) * r3;
+    const float *lbuf = lds + (ci & 1) * buf_floats; // LDS address space stays visible to the compiler: ds_read, not flat
+    if (fits) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of channel ci has landed
+      __syncthreads();                                  // ... everybody's; and channel ci-1's buffer is free again
+      if (ci + 1 < nch) issue(ci + 1);
+    }
+    float *o = out + ((size_t)b * C + c0 + ci) * N;
+    float sc = 1.f, sh = 0.f;
+    if (AFF) { sc = scale[(size_t)b * C + c0 + ci]; sh = shift[(size_t)b * C + c0 + ci]; }
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const int i = tid + p * 256;
+#ifdef DVR_NO_GATHER
+      if (st[p] > 0 && ra[p] == -12345) {
+#else
+      if (st[p] > 0) {
+#endif
+        const int zo = (zd1[p] > 0.0f) ? 1 : 0;
+        float v0, v1, v2, v3, v4, v5, v6, v7;
+        if (fits && st[p] == 1) {
+          v0 = lbuf[ra[p]]; v1 = lbuf[ra[p] + zo]; v2 = lbuf[rb[p]]; v3 = lbuf[rb[p] + zo];
+          v4 = lbuf[rc[p]]; v5 = lbuf[rc[p] + zo]; v6 = lbuf[rd[p]]; v7 = lbuf[rd[p] + zo];
+        } else { // rare: dense clouds (more than DVR_CAP rows) or z beyond the clamp range
+          v0 = gsrc[ra[p]]; v1 = gsrc[ra[p] + zo]; v2 = gsrc[rb[p]]; v3 = gsrc[rb[p] + zo];
+          v4 = gsrc[rc[p]]; v5 = gsrc[rc[p] + zo]; v6 = gsrc[rd[p]]; v7 = gsrc[rd[p] + zo];
+        }
+        const float xd0 = sub_rn(1.0f, xd1[p]), yd0 = sub_rn(1.0f, yd1[p]), zd0 = sub_rn(1.0f, zd1[p]);
+        const float w0 = mul_rn(mul_rn(xd0, yd0), zd0), w1 = mul_rn(mul_rn(xd0, yd0), zd1[p]);
+        const float w2 = mul_rn(mul_rn(xd0, yd1[p]), zd0), w3 = mul_rn(mul_rn(xd0, yd1[p]), zd1[p]);
+        const float w4 = mul_rn(mul_rn(xd1[p], yd0), zd0), w5 = mul_rn(mul_rn(xd1[p], yd0), zd1[p]);
+        const float w6 = mul_rn(mul_rn(xd1[p], yd1[p]), zd0), w7 = mul_rn(mul_rn(xd1[p], yd1[p]), zd1[p]);
+        float a = mul_rn(w0, v0); // trilinear_devox.cu:96-103, left to right
+        a = add_rn(a, mul_rn(w1, v1));
+        a = add_rn(a, mul_rn(w2, v2));
+        a = add_rn(a, mul_rn(w3, v3));
+        a = add_rn(a, mul_rn(w4, v4));
+        a = add_rn(a, mul_rn(w5, v5));
+        a = add_rn(a, mul_rn(w6, v6));
+        a = add_rn(a, mul_rn(w7, v7));
+        if (AFF) {
+          float wsum = w0;
+          wsum += w1; wsum += w2; wsum += w3; wsum += w4; wsum += w5; wsum += w6; wsum += w7;
+          a = a * sc + sh * wsum;
+        }
+        o[i] = a;
+      } else if (st[p] == -2) {
+        o[i] = 0.f; // out-of-contract coordinates (the reference would read out of bounds)
+      }
+    }
+  }
+}
+
 // One workgroup per (b, c) slab; slab accumulated in LDS.
 __global__ __launch_bounds__(1024) void devox_bwd_lds_kernel(const float *__restrict__ gy,
                                                              const int32_t *__restrict__ inds,
@@ -323,8 +543,29 @@ extern "C" {
 static int devox_launch(const float *coords, const float *feat, int B, int C, int N, int r,
                         int training, float *out, int32_t *inds, float *wgts, const float *scale,
                         const float *shift, hipStream_t st) {
-  // LDS-staged path: slabs of <= 9216 floats (36 KiB), two buffers
   const int r2 = r * r;
+  // r = 32 (the large calls): compacted needed rows, one round per channel
+  if (r == 32 && N <= 2048 && (((uintptr_t)feat) & 15) == 0) {
+    const size_t lds = (size_t)2 * DVR_CAP * r * 4 + (size_t)2 * ((r2 + 31) / 32) * 4 + (size_t)DVR_CAP * 2 + 16;
+#ifdef DVR_CT
+    int CT = DVR_CT;
+#else
+    int CT = 8; // one workgroup per CU (144 KiB of LDS): the per-cloud setup is amortised over CT channels
+#endif
+    while (CT > 1 && (long)B * lion_cdiv(C, CT) < 256) CT >>= 1;
+    dim3 grid(lion_cdiv(C, CT), B);
+    static LionLdsLimit cfgr0 = {}, cfgr1 = {};
+    if (scale) {
+      if (int e = lion_dynamic_lds(&devox_rows_kernel<true>, lds, cfgr1)) return e;
+      devox_rows_kernel<true><<<grid, 256, lds, st>>>(coords, feat, C, N, r, CT, training, out, inds, wgts, scale, shift);
+    } else {
+      if (int e = lion_dynamic_lds(&devox_rows_kernel<false>, lds, cfgr0)) return e;
+      devox_rows_kernel<false><<<grid, 256, lds, st>>>(coords, feat, C, N, r, CT, training, out, inds, wgts, scale, shift);
+    }
+    LION_LAUNCH_CHECK();
+    return 0;
+  }
+  // LDS-staged path: slabs of <= 9216 floats (36 KiB), two buffers
   if ((r2 % 4) == 0 && N <= 2048 && r2 <= 4608 && (((uintptr_t)feat) & 15) == 0) {
     const int planes_max = 9216 / r2;
     const int PX = planes_max >= r ? r : planes_max - 1;
@@ -334,7 +575,8 @@ static int devox_launch(const float *coords, const float *feat, int B, int C, in
     const int ld0 = lion_cdiv((XS == 1 ? CI * r2 * r : (PX + 1) * r2) / 4, 256);
     const int ld = ld0 <= 1 ? 1 : ld0 <= 2 ? 2 : ld0 <= 4 ? 4 : 9;
     const int slab_floats = ld * 1024; // buffer stride: every lane of every DMA instruction lands inside it
-    const size_t lds = (size_t)2 * slab_floats * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)XS * 4;
+    const size_t lds = (size_t)2 * slab_floats * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)XS * 4 +
+                       (size_t)((r2 + 31) / 32) * 4;
     // channels per workgroup: amortise the per-point setup over >= 4 slabs of channels, keep >= 512 workgroups
     int CT = 4 * CI;
     while (CT > CI && (long)B * lion_cdiv(C, CT) < 512) CT >>= 1;

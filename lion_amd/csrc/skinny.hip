@@ -8,7 +8,8 @@
 //   output channels of the tile-major packed weights, B = the 32 batch columns) and the accumulator
 //   tile [32 outputs x 32 batch] is written back with coalesced rows;
 // * split-K WITHOUT in-kernel synchronisation: a layer is cut into (output tile, k-split) workgroups
-//   of 16 waves (one round of loads per wave, all in flight at once, then 16 MFMAs) that write RAW
+//   of 16 waves (one round of loads per wave -- 4 x 16 B of weights + one 16 B operand load per input partial and
+//   8-k chunk per lane --, all in flight at once, then 16 MFMAs fed from the wave's LDS slice) that write RAW
 //   partial tiles P[ks][Cout][32]; the consumer sums the partials -- with the producer's bias and
 //   ReLU -- while it loads its operand, so the hand-over is the kernel boundary.  (A last-arriver
 //   reduction inside one launch was measured 2-3x slower: a device-scope fence writes back /
@@ -22,20 +23,35 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4 *p) { // read-once weight stream: non-temporal
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // operand element k of batch column b: act_in( sum_q Pin[q][k][b] + bias_in[k] ) + addT[k][b]
+//
+// What bounds a layer (tools/exp/skinny_probe.hip, 2048 x 2048, HBM-cold weights): streaming the 16.8 MB alone takes
+// 3.9 us (4.3 TB/s, all loads of a lane in flight, non-temporal); the first version of this kernel took 16.5 us
+// because every lane fetched its operand elements with 4-byte loads -- 64 wave-level load instructions per wave
+// for 4 input partials against 4 for the weights, and the CU's one texture-address unit serialises them (11.1 us
+// with a single partial).  Now a wave brings its operand slice (8 k x 32 batch per chunk = 1 KiB per partial) in
+// with ONE coalesced 16-byte load per lane, partial and chunk, reduces / biases / activates it in registers, parks
+// it in its private 4 KiB of LDS and feeds the MFMAs from there; all weight loads of the wave (<= 4 x 16 B per
+// lane and round) are issued before anything waits.
 __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restrict__ pin, int ks_in,
                                                            const float *__restrict__ bias_in, int act_in,
                                                            const float *__restrict__ addT,
                                                            const float *__restrict__ wp, int Cin, int Cout,
                                                            float *__restrict__ pout) {
-  extern __shared__ __attribute__((aligned(16))) float smem[]; // [16][1024] per-wave partial tiles
+  extern __shared__ __attribute__((aligned(16))) float smem[]; // [16][1024]: operand slices, then partial tiles
   float(*part)[1024] = reinterpret_cast<float(*)[1024]>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int o0 = blockIdx.x * 32, ks = blockIdx.y, KS = gridDim.y, nb = blockIdx.z, NB = gridDim.z;
   const int cl = lane & 31, kh = lane >> 5;
   const int ksteps = (Cin + 1) >> 1;
   const int ksteps4 = (ksteps + 3) >> 2; // k-steps padded to a multiple of 4
-  const float *wt = wp + (size_t)blockIdx.x * (ksteps4 * 8) * 32;
+  const float4 *wt4 = reinterpret_cast<const float4 *>(wp + (size_t)blockIdx.x * (ksteps4 * 8) * 32);
   const size_t in_stride = (size_t)NB * Cin * 32; // one k-split slab of the input partials
   const float *xb = pin + (size_t)nb * Cin * 32;
   const float *ab = addT ? addT + (size_t)nb * Cin * 32 : nullptr;
@@ -45,30 +61,41 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restri
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   // weights: packed [tile][k-step / 4][k-half][32 channels][4 k-steps] -> one 16-byte load per lane covers 4 k-steps
-  // (2 KiB per wave instruction); per-wave slices start on multiples of 4 k-steps.
-  constexpr int UN = 8;
-  const float4 *wt4 = reinterpret_cast<const float4 *>(wt);
-  for (int s0 = s_lo; s0 < s_hi; s0 += UN) {
-    float4 a4[UN / 4];
-    float bv[UN];
+  // (2 KiB per wave instruction); per-wave slices start on multiples of 4 k-steps.  A round = 16 k-steps = 32 k.
+  for (int r0 = 0; r0 < per; r0 += 16) {
+    const int s0 = s_lo + r0;
+    float4 a4[4], x4[4];
 #pragma unroll
-    for (int g = 0; g < UN / 4; ++g) a4[g] = wt4[((size_t)(min(s0 + 4 * g, ksteps4 * 4 - 4) >> 2) * 2 + kh) * 32 + cl];
+    for (int g = 0; g < 4; ++g) a4[g] = ld_stream(&wt4[((size_t)(min(s0 + 4 * g, ksteps4 * 4 - 4) >> 2) * 2 + kh) * 32 + cl]);
+    // operand: chunk g = k in [2*(s0 + 4g), +8) x 32 batch columns = 256 consecutive floats: lane -> (k, 4 columns)
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int kc = min(2 * (s0 + u) + kh, Cin - 1);
-      float v = bias_in ? bias_in[kc] : 0.f;
-      for (int q = 0; q < ks_in; ++q) v += xb[q * in_stride + (size_t)kc * 32 + cl]; // fixed order
-      if (act_in == 1) v = v > 0.f ? v : 0.f;
-      if (ab) v += ab[(size_t)kc * 32 + cl];
-      bv[u] = v;
+    for (int g = 0; g < 4; ++g) {
+      const int k = 2 * (s0 + 4 * g) + (lane >> 3);
+      const int kc = min(k, Cin - 1);
+      const size_t off = (size_t)kc * 32 + (lane & 7) * 4;
+      const float bq = bias_in ? bias_in[kc] : 0.f;
+      float4 v = make_float4(bq, bq, bq, bq);
+      for (int q = 0; q < ks_in; ++q) { // fixed order
+        const float4 t = *reinterpret_cast<const float4 *>(xb + q * in_stride + off);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (act_in == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+      if (ab) { const float4 t = *reinterpret_cast<const float4 *>(ab + off); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      const bool live = k < Cin && (k >> 1) < s_hi;
+      x4[g] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (r0) __syncthreads(); // the previous round's operand reads are done (the wave's slice is private, but the
+                             // barrier must be uniform: `per` is the same for every wave of the grid)
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int k = 2 * (s0 + u) + kh;
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(&part[wave][g * 256 + lane * 4]) = x4[g];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
       const float a = (u & 3) == 0 ? a4[u >> 2].x : (u & 3) == 1 ? a4[u >> 2].y : (u & 3) == 2 ? a4[u >> 2].z : a4[u >> 2].w;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, (s0 + u < s_hi && k < Cin) ? bv[u] : 0.f, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, part[wave][(2 * u + kh) * 32 + cl], acc, 0, 0, 0);
     }
   }
+  __syncthreads(); // every wave is done reading its operand slice before the slices become partial tiles
   // acc register i of lane l: output row (i&3) + 8*(i>>2) + 4*(l>>5), batch column l&31
 #pragma unroll
   for (int i = 0; i < 16; ++i) part[wave][((i & 3) + 8 * (i >> 2) + 4 * kh) * 32 + cl] = acc[i];

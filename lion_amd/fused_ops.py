@@ -6,6 +6,7 @@ import torch
 
 from . import _lib
 from ._wcache import WeightCache
+from . import conv_ops
 from .conv_ops import packed_weight, supported
 
 
@@ -37,7 +38,7 @@ def conv3d_occupancy(counts, r, cout, b):
     return buf[0], buf[1]
 
 
-def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None):
+def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None, split=None):
     """x [B,Cin,r,r,r] -> (y [B,Cout,r,r,r], stats [B,Cout,T,2] | None).  pro = (A, Bs) applies
     swish(x*A+Bs) to the input on the fly.
     occ (from conv3d_occupancy: the first element for the conv on the voxelised grid, the second for the conv
@@ -47,16 +48,19 @@ def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None):
       * pro given and prev_conv = the convolution that produced x: x is bias1 wherever no point is near, so the
         activated input is a per-channel constant + a sparse delta; the constant's response is added in the
         epilogue (27 border configurations), the MFMA loop runs on the delta and skips tiles with no point within
-        2 voxels."""
+        2 voxels.
+    split (None = conv_ops.SPLIT): run on the split-operand kernel (fp16 x 2 pieces on the 16-bit MFMA pipe, fp32
+    accurate, csrc/conv3d_split.hip) where Cin % 16 == 0; same modes, same results within fp32 rounding."""
     lib = _lib.load()
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = conv.out_channels
+    use_split = (conv_ops.SPLIT if split is None else split) and conv_ops.split_supported(cin, cout, r)
     if cin % 4:
         assert pro is None
         x = torch.cat([x, x.new_zeros(b, 4 - cin % 4, r, r, r)], dim=1)
         cin = x.shape[1]
     x = x.contiguous()
-    wp = packed_weight(conv.weight)
+    wp = conv_ops.split_packed_weight(conv.weight) if use_split else packed_weight(conv.weight)
     y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
     st = _lib.stream_ptr(x.device)
     pa = pb = pbias = tconst = None
@@ -76,14 +80,15 @@ def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None):
                        "conv3d_const_response")
     stats = None
     if want_stats:
-        stats = torch.empty((b, cout, lib.lion_conv3d_stat_tiles(r, cout, b, int(sparse)), 2), device=x.device,
-                            dtype=torch.float32)
+        tiles = lib.lion_conv3d_split_stat_tiles(r, cout) if use_split else lib.lion_conv3d_stat_tiles(r, cout, b, int(sparse))
+        stats = torch.empty((b, cout, tiles, 2), device=x.device, dtype=torch.float32)
     if not sparse:
         occ = None
-    _lib.check(lib.lion_conv3d_k3_fused_forward(
+    fwd = lib.lion_conv3d_k3_split_forward if use_split else lib.lion_conv3d_k3_fused_forward
+    _lib.check(fwd(
         _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),
         b, cin, cout, r, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(pbias), _lib.ptr(tconst), _lib.ptr(y), _lib.ptr(stats),
-        _lib.ptr(occ), st), "conv3d_k3_fused_forward")
+        _lib.ptr(occ), st), "conv3d_k3_split_forward" if use_split else "conv3d_k3_fused_forward")
     return y, stats
 
 

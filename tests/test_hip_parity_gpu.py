@@ -29,6 +29,15 @@ def bk():
     return _backend
 
 
+@pytest.fixture(params=["fp32-mfma", "fp16x2-split"])
+def conv_kernel(request, monkeypatch):
+    """runs a test once per voxel-convolution kernel: the exact-fp32 MFMA kernel (csrc/conv3d.hip) and the
+    split-operand kernel on the 16-bit pipe (csrc/conv3d_split.hip; shapes with Cin % 16 != 0 stay on fp32 there)."""
+    from lion_amd import conv_ops
+    monkeypatch.setattr(conv_ops, "SPLIT", request.param == "fp16x2-split")
+    return request.param
+
+
 # (C, N, r) tuples of one PVCNN2Prior forward (SURVEY.md 8), plus edge cases
 VOX_CASES = [(4, 2048, 32), (32, 2048, 32), (128, 1024, 16), (192, 256, 8), (128, 64, 8),
              (64, 2048, 32), (3, 1, 8), (5, 777, 16), (7, 4096, 16), (2, 100, 6)]
@@ -138,6 +147,39 @@ def test_trilinear_devoxelize_forward_bit_exact(bk, orc, C, N, r, training):
         assert np.array_equal(host(wgts), o_wgts)
     else:
         assert tuple(inds.shape) == (1,) and tuple(wgts.shape) == (1,)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_trilinear_devoxelize_r32_row_paths(bk, orc, training):
+    """devox_rows_kernel (r = 32) moves only the z-rows some point reads, compacted in LDS.  Its three other paths:
+    (a) a cloud spread over every (x, y) column needs more rows than the LDS buffers hold -> in-kernel global gather;
+    (b) z in (r-1, r): the reference's flat index arithmetic makes the "+1" corner the first element of the NEXT row
+        (Voxelization clamps to r-1, so only a foreign caller gets there) -> per-point global path, same flat indices;
+    (c) coordinates whose corners leave the grid's memory -> 0 instead of an out-of-bounds read (documented deviation:
+        the reference reads past the buffer)."""
+    rng = np.random.default_rng(32)
+    B, C, N, r = 3, 10, 2048, 32
+    feat = rng.standard_normal((B, C, r ** 3)).astype(np.float32)
+    co = rng.uniform(0, r - 1, (B, 3, N)).astype(np.float32)           # (a) in cloud 0 and 1
+    co[2] = voxel_coords(rng, 1, N, r)[0]                                # sparse cloud next to them
+    co[2, 2, :50] = (r - 1) + rng.uniform(0.1, 0.9, 50).astype(np.float32)   # (b) z beyond the clamp range
+    co[2, 0, :50] = np.minimum(co[2, 0, :50], r - 3)                     # ... with every flat index still inside the grid
+    co[1, 2, 100:120] = (r - 1) + 0.5                                    # (b) inside a dense cloud as well
+    co[1, 0, 100:120] = np.minimum(co[1, 0, 100:120], r - 3)
+    o_out, o_inds, o_wgts = orc.trilinear_devoxelize_forward(r, training, co, feat)
+    out, inds, wgts = bk.trilinear_devoxelize_forward(r, training, dev(co), dev(feat))
+    assert np.array_equal(host(out), o_out), np.abs(host(out) - o_out).max()
+    if training:
+        assert np.array_equal(host(inds), o_inds) and np.array_equal(host(wgts), o_wgts)
+    # (c)
+    co2 = co[2:3].copy()
+    co2[0, :, 7] = (r - 1) + 0.5                                         # all three corners +1 out of the grid
+    co2[0, 0, 9] = -1.5
+    out2, _, _ = bk.trilinear_devoxelize_forward(r, False, dev(co2), dev(feat[2:3]))
+    o2 = host(out2)
+    assert np.all(o2[0, :, 7] == 0) and np.all(o2[0, :, 9] == 0)
+    keep = np.ones(N, bool); keep[[7, 9]] = False
+    assert np.array_equal(o2[0][:, keep], o_out[2][:, keep])
 
 
 @pytest.mark.parametrize("C,N,r", [(32, 2048, 32), (64, 1024, 16), (16, 300, 8)])
@@ -389,7 +431,7 @@ def test_full_size_properties(bk):
 
 
 @pytest.mark.parametrize("cin,cout,r", [(64, 64, 32), (4, 32, 32), (128, 64, 16), (192, 128, 8), (33, 32, 8)])
-def test_conv3d_mfma_matches_fp64_reference(cin, cout, r):
+def test_conv3d_mfma_matches_fp64_reference(cin, cout, r, conv_kernel):
     """C3: fp32-MFMA implicit-GEMM Conv3d vs an fp64 convolution of the same fp32 operands: the
     error must be of fp32-roundoff class (each MFMA is an fmaf chain), forward and backward."""
     from lion_amd.conv_ops import conv3d_k3, conv3d_module
@@ -508,7 +550,7 @@ def test_se_gate_and_groupnorm_fold_match_torch():
 
 
 @pytest.mark.parametrize("cin,cout,r,n", [(32, 32, 32, 2048), (64, 64, 32, 2048), (128, 128, 16, 512)])
-def test_conv3d_empty_tile_skip_is_bit_identical(cin, cout, r, n):
+def test_conv3d_empty_tile_skip_is_bit_identical(cin, cout, r, n, conv_kernel):
     """conv1 of a PVConv on the voxelised (sparse) grid: skipping the K loop of tiles whose halo holds no
     point (lion_conv3d_tile_occupancy) gives bit-identical outputs and GroupNorm sums; a flat cloud
     leaves most tiles empty."""
@@ -537,7 +579,7 @@ def bk_():
 
 
 @pytest.mark.parametrize("c,r,n,flat", [(32, 32, 2048, True), (64, 32, 2048, False), (64, 16, 700, True)])
-def test_conv3d_constant_plus_delta_matches_dense(c, r, n, flat):
+def test_conv3d_constant_plus_delta_matches_dense(c, r, n, flat, conv_kernel):
     """second conv of a PVConv: swish(AdaGN(conv1)) = per-channel constant + sparse delta.  The delta-mode kernel
     (constant response per border configuration in the epilogue, tiles with no point within 2 voxels skipped) must
     agree with the dense evaluation of the same convolution to fp32 rounding, including faces / edges / corners."""
