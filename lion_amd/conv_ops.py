@@ -17,7 +17,22 @@ def supported(cin, cout, r):
 
 
 def split_supported(cin, cout, r):
+    """what csrc/conv3d_split.hip can run"""
     return r in (8, 16, 32) and cout % 32 == 0 and cin >= 16 and cin % 16 == 0
+
+
+def split_preferred(cin, cout, r):
+    """where it is the faster kernel (tools/conv_split_bench.py, B=32): 2.1x at 64->64 r=32, 2.1x at 128->128 r=16,
+    1.1x at 32->32 r=32; at r=8 (128-voxel tiles: the weight slices are re-read per tile and the halo is 3x the tile)
+    the exact-fp32 kernel is faster (114 vs 144 us at 128->128) and stays the default."""
+    return split_supported(cin, cout, r) and r >= 16
+
+
+def use_split(split, cin, cout, r):
+    """split: None = module policy (SPLIT and split_preferred), True = wherever supported, False = never."""
+    if split is None:
+        return SPLIT and split_preferred(cin, cout, r)
+    return bool(split) and split_supported(cin, cout, r)
 
 
 def _split_pack(weight):
@@ -63,7 +78,7 @@ def conv3d_k3(x, weight, bias=None, split=None):
     _lib.require_cuda(x)
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = weight.shape[0]
-    if (SPLIT if split is None else split) and split_supported(cin, cout, r) and weight.shape[1] == cin:
+    if use_split(split, cin, cout, r) and weight.shape[1] == cin:
         x = x.contiguous()
         y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
         bias_c = bias.detach().contiguous() if bias is not None else None

@@ -311,35 +311,36 @@ __global__ __launch_bounds__(256) void devox_slab_kernel(
 // CAP rows (N > 2048-like densities) takes the in-kernel global-gather path.
 // ---------------------------------------------------------------------------------------------
 constexpr int DVR_CAP = 576; // rows per buffer: 2 x 72 KiB
+constexpr int DVR_R = 32, DVR_NT = 512, DVR_PP = 2048 / DVR_NT;      // r, threads, points per lane (N <= 2048)
+constexpr int DVR_NJ = (DVR_CAP * (DVR_R / 4) + DVR_NT - 1) / DVR_NT; // DMA instructions per thread and channel (9)
 
 template <bool AFF>
-__global__ __launch_bounds__(256) void devox_rows_kernel(const float *__restrict__ coords,
-                                                         const float *__restrict__ feat, int C, int N, int r, int CT,
-                                                         int training, float *__restrict__ out,
-                                                         int32_t *__restrict__ inds, float *__restrict__ wgts,
-                                                         const float *__restrict__ scale,
-                                                         const float *__restrict__ shift) {
+__global__ __launch_bounds__(DVR_NT) void devox_rows_kernel(const float *__restrict__ coords,
+                                                            const float *__restrict__ feat, int C, int N, int CT,
+                                                            int training, float *__restrict__ out,
+                                                            int32_t *__restrict__ inds, float *__restrict__ wgts,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int PP = 8;
+  constexpr int PP = DVR_PP, r = DVR_R, r2 = r * r, r3 = r2 * r, nwords = r2 / 32, NT = DVR_NT;
   float *lds = reinterpret_cast<float *>(smem);
   const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * CT;
   const int nch = min(CT, C - c0);
-  const int r2 = r * r, r3 = r2 * r, rq = r >> 2, nwords = (r2 + 31) >> 5;
-  const int buf_floats = DVR_CAP * r;
+  constexpr int buf_floats = DVR_CAP * r;
   unsigned *need = reinterpret_cast<unsigned *>(lds + 2 * buf_floats); // [nwords] bit (x*r + y)
   unsigned *base = need + nwords;                                       // [nwords] rank of the word's first row
   uint16_t *rowlist = reinterpret_cast<uint16_t *>(base + nwords);      // [DVR_CAP] row id of each slot
   int *s_nrows = reinterpret_cast<int *>(rowlist + DVR_CAP);
   const float *co = coords + (size_t)b * 3 * N;
 
-  for (int w = tid; w < nwords; w += 256) need[w] = 0u;
+  if (tid < nwords) need[tid] = 0u;
   __syncthreads();
   float xd1[PP], yd1[PP], zd1[PP];
   int ra[PP], rb[PP], rc[PP], rd[PP], zl_[PP], st[PP]; // st: 1 = regular point, 0 = none, -2 = out of the grid's memory,
                                                        // 2 = z_lo + 1 runs into the next row (flat indexing, global path)
 #pragma unroll
   for (int p = 0; p < PP; ++p) {
-    const int i = tid + p * 256;
+    const int i = tid + p * NT;
     st[p] = 0;
     xd1[p] = yd1[p] = zd1[p] = 0.f;
     ra[p] = rb[p] = rc[p] = rd[p] = zl_[p] = 0;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void devox_rows_kernel(const float *__restrict
     }
   }
   __syncthreads();
-  if (tid < 64) { // ranks: exclusive prefix of the words' popcounts (nwords <= 64 for r <= 45)
+  if (tid < 64) { // ranks: exclusive prefix of the words' popcounts (32 words)
     int cnt = tid < nwords ? __popc(need[tid]) : 0;
     const int inc = wave_incl_scan(cnt, tid);
     if (tid < nwords) base[tid] = (unsigned)(inc - cnt);
@@ -389,9 +390,39 @@ __global__ __launch_bounds__(256) void devox_rows_kernel(const float *__restrict
   const int nrows = *s_nrows;
   const bool fits = nrows <= DVR_CAP;
   auto slot_of = [&](int row) { return (int)(base[row >> 5] + __popc(need[row >> 5] & ((1u << (row & 31)) - 1u))); };
-  if (fits) {
-    for (int row = tid; row < r2; row += 256)
+  if (fits)
+    for (int row = tid; row < r2; row += NT)
       if ((need[row >> 5] >> (row & 31)) & 1u) rowlist[slot_of(row)] = (uint16_t)row;
+  __syncthreads();
+
+  // the float4 this lane moves in DMA instruction j is the same for every channel: (row, part) -> float offset inside
+  // a channel grid, computed once (no index arithmetic, no LDS lookup in the per-channel issue loop)
+  const int n4 = fits ? nrows * (r / 4) : 0;
+  int goff[DVR_NJ];
+#pragma unroll
+  for (int j = 0; j < DVR_NJ; ++j) {
+    const int f = tid + j * NT;
+    goff[j] = f < n4 ? (int)rowlist[f >> 3] * r + (f & 7) * 4 : -1;
+  }
+  typedef __attribute__((address_space(3))) float lds_float;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_float *)lds;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto issue = [&](int ci) {
+    const float *src = feat + ((size_t)b * C + c0 + ci) * r3;
+    const uint32_t dst0 = lds_base + (uint32_t)((ci & 1) * buf_floats * 4 + wave * 1024);
+#pragma unroll
+    for (int j = 0; j < DVR_NJ; ++j) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * (NT * 16));
+      if (goff[j] >= 0) {
+        const float *gp = src + goff[j];
+        unsigned keep; // nt: every row is read exactly once per call
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+      }
+    }
+  };
+  if (fits) issue(0); // channel 0 is in flight during the rest of the per-point setup
+  if (fits) {
     // rows -> LDS float offsets of the four z-rows of each point (at its z_lo)
 #pragma unroll
     for (int p = 0; p < PP; ++p)
@@ -405,33 +436,6 @@ __global__ __launch_bounds__(256) void devox_rows_kernel(const float *__restrict
     if (!fits || st[p] == 2) { // flat float offsets inside a channel grid
       ra[p] = ra[p] * r + zl_[p]; rb[p] = rb[p] * r + zl_[p]; rc[p] = rc[p] * r + zl_[p]; rd[p] = rd[p] * r + zl_[p];
     }
-  __syncthreads();
-
-  typedef __attribute__((address_space(3))) float lds_float;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_float *)lds;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n4 = nrows * rq;                 // float4 of one channel's needed rows
-  const int nj = (n4 + 255) >> 8;            // DMA instructions per thread and channel
-  auto issue = [&](int ci) {
-    const float *src = feat + ((size_t)b * C + c0 + ci) * r3;
-    const uint32_t dst0 = lds_base + (uint32_t)((ci & 1) * buf_floats * 4 + wave * 1024);
-    for (int j = 0; j < nj; ++j) {
-      const int f = tid + j * 256;
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * 4096);
-#ifdef DVR_NO_DMA
-      if (f < n4 && ci == 0) {
-#else
-      if (f < n4) {
-#endif
-        const int slot = f / rq, part = f - slot * rq;
-        const float *gp = src + (int)rowlist[slot] * r + part * 4;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
-      }
-    }
-  };
-  if (fits) issue(0);
   for (int ci = 0; ci < nch; ++ci) {
     const float *gsrc = feat + ((size_t)b * C + c0 + ci) * r3;
     const float *lbuf = lds + (ci & 1) * buf_floats; // LDS address space stays visible to the compiler: ds_read, not flat
@@ -445,12 +449,8 @@ __global__ __launch_bounds__(256) void devox_rows_kernel(const float *__restrict
     if (AFF) { sc = scale[(size_t)b * C + c0 + ci]; sh = shift[(size_t)b * C + c0 + ci]; }
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
-      const int i = tid + p * 256;
-#ifdef DVR_NO_GATHER
-      if (st[p] > 0 && ra[p] == -12345) {
-#else
+      const int i = tid + p * NT;
       if (st[p] > 0) {
-#endif
         const int zo = (zd1[p] > 0.0f) ? 1 : 0;
         float v0, v1, v2, v3, v4, v5, v6, v7;
         if (fits && st[p] == 1) {
@@ -545,22 +545,18 @@ static int devox_launch(const float *coords, const float *feat, int B, int C, in
                         const float *shift, hipStream_t st) {
   const int r2 = r * r;
   // r = 32 (the large calls): compacted needed rows, one round per channel
-  if (r == 32 && N <= 2048 && (((uintptr_t)feat) & 15) == 0) {
+  if (r == DVR_R && N <= 2048 && (((uintptr_t)feat) & 15) == 0) {
     const size_t lds = (size_t)2 * DVR_CAP * r * 4 + (size_t)2 * ((r2 + 31) / 32) * 4 + (size_t)DVR_CAP * 2 + 16;
-#ifdef DVR_CT
-    int CT = DVR_CT;
-#else
     int CT = 8; // one workgroup per CU (144 KiB of LDS): the per-cloud setup is amortised over CT channels
-#endif
     while (CT > 1 && (long)B * lion_cdiv(C, CT) < 256) CT >>= 1;
     dim3 grid(lion_cdiv(C, CT), B);
     static LionLdsLimit cfgr0 = {}, cfgr1 = {};
     if (scale) {
       if (int e = lion_dynamic_lds(&devox_rows_kernel<true>, lds, cfgr1)) return e;
-      devox_rows_kernel<true><<<grid, 256, lds, st>>>(coords, feat, C, N, r, CT, training, out, inds, wgts, scale, shift);
+      devox_rows_kernel<true><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift);
     } else {
       if (int e = lion_dynamic_lds(&devox_rows_kernel<false>, lds, cfgr0)) return e;
-      devox_rows_kernel<false><<<grid, 256, lds, st>>>(coords, feat, C, N, r, CT, training, out, inds, wgts, scale, shift);
+      devox_rows_kernel<false><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift);
     }
     LION_LAUNCH_CHECK();
     return 0;

@@ -64,36 +64,60 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restri
   // (2 KiB per wave instruction); per-wave slices start on multiples of 4 k-steps.  A round = 16 k-steps = 32 k.
   for (int r0 = 0; r0 < per; r0 += 16) {
     const int s0 = s_lo + r0;
-    float4 a4[4], x4[4];
+    float4 a4[4], x4[2][4], t4[2];
+    float bq[2];
+    // the weights of the whole round (HBM, the long latency) are requested first; the operand partials (L2 / MALL
+    // resident, written by the previous layer) follow two chunks ahead of their use, so that chunk g's MFMAs run
+    // while later chunks are still in flight and the kernel stays under the 128 registers of a 1024-thread workgroup
 #pragma unroll
-    for (int g = 0; g < 4; ++g) a4[g] = ld_stream(&wt4[((size_t)(min(s0 + 4 * g, ksteps4 * 4 - 4) >> 2) * 2 + kh) * 32 + cl]);
+    for (int g = 0; g < 4; ++g)
+      a4[g] = ld_stream(&wt4[((size_t)(min(s0 + 4 * g, ksteps4 * 4 - 4) >> 2) * 2 + kh) * 32 + cl]);
     // operand: chunk g = k in [2*(s0 + 4g), +8) x 32 batch columns = 256 consecutive floats: lane -> (k, 4 columns)
+    auto fetch = [&](int g, int slot) {
+      const int kc = min(2 * (s0 + 4 * g) + (lane >> 3), Cin - 1);
+      const size_t off = (size_t)kc * 32 + (lane & 7) * 4;
+      bq[slot] = bias_in ? bias_in[kc] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        x4[slot][q] = q < ks_in ? *reinterpret_cast<const float4 *>(xb + q * in_stride + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      t4[slot] = ab ? *reinterpret_cast<const float4 *>(ab + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0, 0);
+    fetch(1, 1);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      const int sl = g & 1;
       const int k = 2 * (s0 + 4 * g) + (lane >> 3);
-      const int kc = min(k, Cin - 1);
-      const size_t off = (size_t)kc * 32 + (lane & 7) * 4;
-      const float bq = bias_in ? bias_in[kc] : 0.f;
-      float4 v = make_float4(bq, bq, bq, bq);
-      for (int q = 0; q < ks_in; ++q) { // fixed order
-        const float4 t = *reinterpret_cast<const float4 *>(xb + q * in_stride + off);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      float4 v = make_float4(bq[sl], bq[sl], bq[sl], bq[sl]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v.x += x4[sl][q].x; v.y += x4[sl][q].y; v.z += x4[sl][q].z; v.w += x4[sl][q].w; } // fixed order
+      if (ks_in > 4) { // more input partials than the unrolled four (not produced by lion_skinny_splits today)
+        const size_t off = (size_t)min(k, Cin - 1) * 32 + (lane & 7) * 4;
+        for (int q = 4; q < ks_in; ++q) {
+          const float4 t = *reinterpret_cast<const float4 *>(xb + q * in_stride + off);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
       }
       if (act_in == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-      if (ab) { const float4 t = *reinterpret_cast<const float4 *>(ab + off); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+      v.x += t4[sl].x; v.y += t4[sl].y; v.z += t4[sl].z; v.w += t4[sl].w;
       const bool live = k < Cin && (k >> 1) < s_hi;
-      x4[g] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (r0) __syncthreads(); // the previous round's operand reads are done (the wave's slice is private, but the
-                             // barrier must be uniform: `per` is the same for every wave of the grid)
+      if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g + 2 < 4) fetch(g + 2, sl);
+      // the slice is private to the wave and a wave's LDS operations execute in order: no workgroup barrier, only
+      // a compiler fence between the lanes' writes and the (other lanes') reads
+      *reinterpret_cast<float4 *>(&part[wave][g * 256 + lane * 4]) = v;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4 *>(&part[wave][g * 256 + lane * 4]) = x4[g];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float a = (u & 3) == 0 ? a4[u >> 2].x : (u & 3) == 1 ? a4[u >> 2].y : (u & 3) == 2 ? a4[u >> 2].z : a4[u >> 2].w;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, part[wave][(2 * u + kh) * 32 + cl], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+        const int u = 4 * g + e;
+        const float a = e == 0 ? a4[g].x : e == 1 ? a4[g].y : e == 2 ? a4[g].z : a4[g].w;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, part[wave][(2 * u + kh) * 32 + cl], acc, 0, 0, 0);
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // next round rewrites the slice after these reads
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads(); // every wave is done reading its operand slice before the slices become partial tiles
   // acc register i of lane l: output row (i&3) + 8*(i>>2) + 4*(l>>5), batch column l&31

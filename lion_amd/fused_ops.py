@@ -54,7 +54,7 @@ def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None, s
     lib = _lib.load()
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = conv.out_channels
-    use_split = (conv_ops.SPLIT if split is None else split) and conv_ops.split_supported(cin, cout, r)
+    use_split = conv_ops.use_split(split, cin, cout, r)
     if cin % 4:
         assert pro is None
         x = torch.cat([x, x.new_zeros(b, 4 - cin % 4, r, r, r)], dim=1)
