@@ -256,15 +256,25 @@ int lion_row_stats(const float *x, int rows, int L, float *stats, lionStream_t s
 /* G1 itself: the 1x1 Conv1d / Conv2d of SharedMLP (pvcnn2_ada.py:120) as an fp32-MFMA GEMM over
  * x f32[B,Cin,L] (L = N or M*U) with the previous layer's AdaGN+Swish applied to the operand in flight
  * (pro_a/pro_b f32[B,Cin] or both NULL) and this layer's GroupNorm sums in the epilogue
- * (stats f32[B,Cout,lion_pwconv_stat_tiles(Cout,L),2] or NULL; fold with lion_groupnorm_fold).
- * w f32[Cout,Cin] -> wp f32[ceil2(Cin),Cout] once per weight (lion_pwconv_packed_floats floats).
- * Cout in {32,64,128,256} and a weight slice that fits LDS; otherwise LION_EUNSUPPORTED (callers keep the
- * library GEMM, which also serves the short, latency-bound activations better). */
+ * (stats f32[B,Cout,lion_pwconv_stat_tiles(Cout,Cin,L),2] or NULL; fold with lion_groupnorm_fold).
+ * w f32[Cout,Cin] -> wp f32[ceil2(Cin),ceil64(Cout)] once per weight (lion_pwconv_packed_floats floats).
+ * Any Cout (channel tiles of 32..256 output rows; rows beyond Cout carry zero weights and are never stored); the
+ * weight slice of a tile must fit LDS (150 KiB), otherwise LION_EUNSUPPORTED. */
 size_t lion_pwconv_packed_floats(int Cout, int Cin);
 int lion_pwconv_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream);
-int lion_pwconv_stat_tiles(int Cout, int L);
+int lion_pwconv_stat_tiles(int Cout, int Cin, int L);
 int lion_pwconv_forward(const float *x, const float *wp, const float *bias, int B, int Cin, int Cout, int L,
                         const float *pro_a, const float *pro_b, float *y, float *stats, lionStream_t stream);
+/* ---- P5: LinearAttention (models/pvcnn2_ada.py:43-71) between its two 1x1 convolutions ---------------------
+ * qkv f32[B, 3*H*D, N] (to_qkv's output, channel order (qkv, head, d)) -> out f32[B, H*D, N] (to_out's input):
+ * softmax over the N points of every k row, ctx = softmax(k) v^T (D x D), out = ctx^T q.  D = 32 (every
+ * LinearAttention of the models); one workgroup per (batch, head), fp32 MFMA. */
+int lion_linear_attention_core(const float *qkv, int B, int H, int D, int N, float *out, lionStream_t stream);
+/* nn.Linear on [B,K] (time-embedding MLP, batched AdaGN style projections): y[b][o] = act(bias[o] + sum_k x[b][k] W[o][k]),
+ * wp = lion_pwconv_pack_weights(W f32[O,K]); act 0 none / 1 relu / 2 leaky-relu(slope).  One launch, fixed summation
+ * order (4 K-quarters combined in order). */
+int lion_linear_forward(const float *x, const float *wp, const float *bias, int B, int K, int O, int act, float slope,
+                        float *y, lionStream_t stream);
 int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows, int L, float *y,
                       lionStream_t stream);
 int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int rows, int M, int U,

@@ -21,23 +21,32 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CB, int VB, bool PRO, bool STATS>
+// WLDS = false (short activations: L = 16 .. a few thousand columns): the weights are NOT staged in LDS -- every wave
+// reads its A operands (128-byte rows of the k-major packed copy) straight from L2.  A staged 64-137 KiB slice per
+// workgroup is repaid only by many column tiles; with a handful of tiles it is pure latency, and a workgroup that needs
+// most of a CU's LDS cannot start beside the voxelize / devoxelize / convolution workgroups of the main stream (the
+// point branch of a PVConv runs on a side stream, in their shadow).
+template <int CB, int VB, bool PRO, bool STATS, bool WLDS>
 __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict__ x, const float *__restrict__ wp,
                                                         const float *__restrict__ bias, float *__restrict__ y,
-                                                        int Cin, int Cout, int L, const float *__restrict__ pro_a,
+                                                        int Cin, int Cout, int CoutY, int L,
+                                                        const float *__restrict__ pro_a,
                                                         const float *__restrict__ pro_b, float *__restrict__ stats) {
+  // Cout: channels of the packed weights (a multiple of 32, zero rows beyond CoutY); CoutY: channels of y / bias / stats
   constexpr int COUT = CB * 32; // output channels of this workgroup: [co0, co0 + COUT)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ksteps = (Cin + 1) >> 1;
-  float *sw = smem;                       // [2 * ksteps][COUT] weight slice of this channel tile
-  float *spa = sw + 2 * ksteps * COUT;    // [Cin] prologue scale   (PRO)
+  float *sw = smem;                       // [2 * ksteps][COUT] weight slice of this channel tile (WLDS)
+  float *spa = sw + (WLDS ? 2 * ksteps * COUT : 0); // [Cin] prologue scale   (PRO)
   float *spb = spa + (PRO ? Cin : 0);     // [Cin] prologue shift   (PRO)
   float *sred = spb + (PRO ? Cin : 0);    // [4][COUT][2]           (STATS)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, co0 = blockIdx.y * COUT, cl = lane & 31, kh = lane >> 5;
-  for (int e = tid; e < 2 * ksteps * COUT; e += 256) {
-    const int k = e / COUT, c = e - k * COUT;
-    sw[e] = wp[(size_t)k * Cout + co0 + c];
+  if (WLDS) {
+    for (int e = tid; e < 2 * ksteps * COUT; e += 256) {
+      const int k = e / COUT, c = e - k * COUT;
+      sw[e] = wp[(size_t)k * Cout + co0 + c];
+    }
   }
   if (PRO) {
     for (int c = tid; c < Cin; c += 256) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
@@ -80,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
         const bool kok = k < Cin; // odd Cin: zero operand (the packed weights are zero there too)
         float av[CB];
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) av[cb] = sw[k * COUT + cb * 32 + cl];
+        for (int cb = 0; cb < CB; ++cb)
+          av[cb] = WLDS ? sw[k * COUT + cb * 32 + cl] : wp[(size_t)k * Cout + co0 + cb * 32 + cl]; // rows exist to ceil2(Cin)
 #pragma unroll
         for (int vb = 0; vb < VB; ++vb) {
           float v = bv[u][vb];
@@ -100,18 +110,19 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
 
   // epilogue: + bias, [B, Cout, L] store.  acc register i of lane l: channel row (i&3) + 8*(i>>2) + 4*(l>>5),
   // column l&31 -> 32 consecutive columns per (register, half-wave).
-  float *yb = y + ((size_t)b * Cout + co0) * L;
+  float *yb = y + ((size_t)b * CoutY + co0) * L;
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-      const float bz = bias ? bias[co0 + co] : 0.f;
+      const bool rok = co0 + co < CoutY; // padded channel rows (CoutY % 32 != 0) are computed on zeros and dropped
+      const float bz = (bias && rok) ? bias[co0 + co] : 0.f;
 #pragma unroll
       for (int vb = 0; vb < VB; ++vb) {
         const float o = acc[cb][vb][i] + bz;
         acc[cb][vb][i] = cok[vb] ? o : 0.f;
-        if (cok[vb]) yb[(size_t)co * L + col[vb]] = o;
+        if (cok[vb] && rok) yb[(size_t)co * L + col[vb]] = o;
       }
     }
   if (STATS) {
@@ -131,54 +142,194 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
         }
       }
     __syncthreads();
-    for (int c = tid; c < COUT; c += 256) {
+    for (int c = tid; c < COUT && co0 + c < CoutY; c += 256) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { s1 += sred[(w * COUT + c) * 2]; s2 += sred[(w * COUT + c) * 2 + 1]; }
-      float *o = stats + (((size_t)b * Cout + co0 + c) * gridDim.x + blockIdx.x) * 2;
+      float *o = stats + (((size_t)b * CoutY + co0 + c) * gridDim.x + blockIdx.x) * 2;
       o[0] = s1;
       o[1] = s2;
     }
   }
 }
 
-// [Cout][Cin] (nn.Conv1d / Conv2d weight with kernel 1) -> [ceil2(Cin)][Cout], zero padded
-__global__ void pwconv_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int Cin_pad,
+
+// ---- short activations (L <= PW_SMALL_L columns): latency, not bytes ------------------------------------------------
+// The layers above with a few hundred columns (point branches of the r = 8 / 16 PVConvs, feature propagation, the
+// last set-abstraction stages, the classifier, the attention projections) are GEMMs of a few MFLOP.  With the tiling
+// of the large kernel they would run on 32 workgroups, each walking its k-steps behind one L2 round trip at a time
+// (measured: 150 us at Cin = 256).  Here a workgroup owns 32 columns x 64 output channels and its four waves SPLIT K:
+// a wave requests the operands of all its k-steps (<= 32 per round: 2 weight rows + 1 activation row of 128 bytes
+// each) before the first MFMA -- one round trip -- and the four partial tiles are combined through LDS in a fixed
+// order.  Same arithmetic (fmaf chains over k, then ((w0 + w1) + w2) + w3), prologue and GroupNorm sums as above.
+constexpr int PW_SMALL_L = 4096;
+template <bool PRO, bool STATS>
+__global__ __launch_bounds__(256) void pwconv_small_kernel(const float *__restrict__ x, const float *__restrict__ wp,
+                                                           const float *__restrict__ bias, float *__restrict__ y,
+                                                           int Cin, int Cout, int CoutY, int L,
+                                                           const float *__restrict__ pro_a,
+                                                           const float *__restrict__ pro_b, float *__restrict__ stats) {
+  __shared__ float part[4][2][1024];
+  extern __shared__ __attribute__((aligned(16))) float smem[]; // [2][Cin] prologue scalars (PRO)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.z, co0 = blockIdx.y * 64, col = blockIdx.x * 32 + cl;
+  const bool cok = col < L;
+  const int colc = cok ? col : L - 1;
+  const int ksteps = (Cin + 1) >> 1, per = (ksteps + 3) >> 2;
+  const int s_lo = min(ksteps, wave * per), s_hi = min(ksteps, s_lo + per);
+  float *spa = smem, *spb = smem + Cin;
+  if (PRO) {
+    for (int c = tid; c < Cin; c += 256) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
+    __syncthreads();
+  }
+  const float *xb = x + (size_t)b * Cin * L;
+  f32x16 acc[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+  constexpr int UN = 32;
+  for (int s0 = s_lo; s0 < s_hi; s0 += UN) {
+    float av[UN][2], bv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k = min(2 * min(s0 + u, ksteps - 1) + kh, 2 * ksteps - 1); // packed rows exist up to ceil2(Cin)
+      av[u][0] = wp[(size_t)k * Cout + co0 + cl];
+      av[u][1] = wp[(size_t)k * Cout + co0 + 32 + cl];
+      bv[u] = xb[(size_t)min(k, Cin - 1) * L + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k = 2 * (s0 + u) + kh;
+      float v = bv[u];
+      if (PRO) {
+        const int kc = min(k, Cin - 1);
+        const float t = v * spa[kc] + spb[kc];
+        v = t * __frcp_rn(1.0f + __expf(-t)); // swish, as in pwconv_kernel
+      }
+      v = (s0 + u < s_hi && k < Cin && cok) ? v : 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], v, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], v, acc[1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[wave][cb][((i & 3) + 8 * (i >> 2) + 4 * kh) * 32 + cl] = acc[cb][i];
+  __syncthreads();
+  // thread -> (channel row = tid / 32 + 8 j, column = tid % 32): 8 channels per thread, coalesced 128-byte row stores
+  const int c = tid & 31, colo = blockIdx.x * 32 + c;
+  const bool ok = colo < L;
+  float *yb = y + ((size_t)b * CoutY + co0) * L;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = (tid >> 5) + 8 * j, cb = row >> 5, e = (row & 31) * 32 + c;
+    float o = ((part[0][cb][e] + part[1][cb][e]) + part[2][cb][e]) + part[3][cb][e];
+    const bool rok = co0 + row < CoutY;
+    o += (bias && rok) ? bias[co0 + row] : 0.f;
+    if (ok && rok) yb[(size_t)row * L + colo] = o;
+    if (STATS) {
+      float s1 = ok ? o : 0.f, s2 = s1 * s1;
+      s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      if (c == 0 && rok) {
+        float *so = stats + (((size_t)b * CoutY + co0 + row) * gridDim.x + blockIdx.x) * 2;
+        so[0] = s1;
+        so[1] = s2;
+      }
+    }
+  }
+}
+
+// nn.Linear on a [B, K] activation (time embedding MLP latent_points_ada.py:47-48, the AdaGN style projections
+// adagn.py:45-60 batched by models/adagn.py::StylePlan): y[b][o] = act(bias[o] + sum_k x[b][k] W[o][k]).
+// The batch (<= 32 rows per slab) sits on the MFMA columns, 32 output features on the rows, the four waves of a
+// workgroup split K and combine through LDS in a fixed order.  W comes k-major from lion_pwconv_pack_weights
+// (coalesced 128-byte operand rows); x is a few KiB and stays in L1.  Latency bound by construction: one launch.
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float *__restrict__ x, const float *__restrict__ wp,
+                                                          const float *__restrict__ bias, int Bn, int K, int O,
+                                                          int Opad, int act, float slope, float *__restrict__ y) {
+  __shared__ float part[4][1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cl = lane & 31, kh = lane >> 5;
+  const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int ksteps = (K + 1) >> 1, per = (ksteps + 3) >> 2;
+  const int s_lo = min(ksteps, wave * per), s_hi = min(ksteps, s_lo + per);
+  const int brow = min(b0 + cl, Bn - 1);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int s = s_lo; s < s_hi; ++s) {
+    const int k = 2 * s + kh, kc = min(k, K - 1);
+    const float a = wp[(size_t)k * Opad + o0 + cl];          // packed rows exist up to ceil2(K): zero beyond K
+    const float v = (k < K && b0 + cl < Bn) ? x[(size_t)brow * K + kc] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[wave][((i & 3) + 8 * (i >> 2) + 4 * kh) * 32 + cl] = acc[i];
+  __syncthreads();
+#pragma unroll
+  for (int e = tid; e < 1024; e += 256) {
+    const int o = o0 + (e >> 5), b = b0 + (e & 31);
+    if (o < O && b < Bn) {
+      float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+      if (bias) v += bias[o];
+      if (act == 1) v = v > 0.f ? v : 0.f;
+      else if (act == 2) v = v > 0.f ? v : v * slope;
+      y[(size_t)b * O + o] = v;
+    }
+  }
+}
+
+// [Cout][Cin] (nn.Conv1d / Conv2d weight with kernel 1) -> [ceil2(Cin)][ceil64(Cout)], zero padded
+__global__ void pwconv_pack_kernel(const float *__restrict__ w, int Cout, int Cout_pad, int Cin, int Cin_pad,
                                    float *__restrict__ wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Cin_pad * Cout) return;
-  const int co = i % Cout, k = i / Cout;
-  wp[i] = k < Cin ? w[(size_t)co * Cin + k] : 0.f;
+  if (i >= Cin_pad * Cout_pad) return;
+  const int co = i % Cout_pad, k = i / Cout_pad;
+  wp[i] = (k < Cin && co < Cout) ? w[(size_t)co * Cin + k] : 0.f;
 }
 
 // Tile choice: a workgroup covers 4 waves x VB x 32 columns x CB x 32 output channels; CB x VB = 8
 // accumulator tiles (128 VGPRs).  All output channels in one workgroup when Cout <= 256 (the activation
 // is then read once); Cout = 32: 4 column blocks per wave.
 struct PwPlan { int cb, vb; };
-static PwPlan pw_plan(int Cout) {
-  switch (Cout) {
-  case 32: return {1, 4};
-  case 64: return {2, 4};
-  case 128: return {4, 2};
-  case 256: return {8, 1};
-  default: return {0, 0};
-  }
-}
-static size_t pw_lds(int cb, int Cin, bool pro) {
+static int pw_pad(int Cout) { return (Cout + 31) / 32 * 32; }     // channel rows the tiles cover
+static int pw_stride(int Cout) { return (Cout + 63) / 64 * 64; }  // row stride of the packed copy (zero columns beyond Cout)
+static size_t pw_lds(int cb, int Cin, bool pro, bool wlds = true) {
   const int ksteps = (Cin + 1) / 2;
-  return ((size_t)2 * ksteps * cb * 32 + (pro ? 2 * Cin : 0) + 4 * cb * 32 * 2) * 4;
+  return ((size_t)(wlds ? 2 * ksteps * cb * 32 : 0) + (pro ? 2 * Cin : 0) + 4 * cb * 32 * 2) * 4;
+}
+constexpr size_t PW_LDS_MAX = 150 * 1024;
+// Cout: any; the channel tile is the largest of 256 / 128 / 64 / 32 rows that divides ceil32(Cout) and whose weight slice
+// (with the prologue scalars: the plan must not depend on the mode) fits LDS
+static PwPlan pw_plan(int Cout, int Cin) {
+  const int blocks = pw_pad(Cout) / 32;
+  if (blocks <= 0 || Cin <= 0) return {0, 0};
+  if (blocks % 8 == 0 && pw_lds(8, Cin, true) <= PW_LDS_MAX) return {8, 1};
+  if (blocks % 4 == 0 && pw_lds(4, Cin, true) <= PW_LDS_MAX) return {4, 2};
+  if (blocks % 2 == 0 && pw_lds(2, Cin, true) <= PW_LDS_MAX) return {2, 4};
+  if (pw_lds(1, Cin, true) <= PW_LDS_MAX) return {1, 4};
+  return {0, 0};
 }
 
 template <int CB, int VB>
 static int launch_pw(const float *x, const float *wp, const float *bias, float *y, int B, int Cin, int Cout, int L,
                      const float *pa, const float *pb, float *stats, hipStream_t st) {
-  const dim3 grid(lion_cdiv(L, 4 * VB * 32), Cout / (CB * 32), B);
-  const size_t lds = pw_lds(CB, Cin, pa != nullptr);
+  const int Cpad = pw_pad(Cout);
+  const dim3 grid(lion_cdiv(L, 4 * VB * 32), Cpad / (CB * 32), B);
+  // weights through LDS only when a workgroup's column tile is one of many (the staging is then amortised by the L2)
+  const bool wlds = (long)grid.x * B >= 2048;
+  const size_t lds = pw_lds(CB, Cin, pa != nullptr, wlds);
 #define LION_PW_GO(PRO_, ST_)                                                                              \
   {                                                                                                        \
-    static LionLdsLimit cfg = {};                                                                          \
-    if (int e = lion_dynamic_lds(&pwconv_kernel<CB, VB, PRO_, ST_>, lds, cfg)) return e;                   \
-    pwconv_kernel<CB, VB, PRO_, ST_><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, Cout, L, pa, pb, stats); \
+    static LionLdsLimit cfg = {}, cfg_g = {};                                                              \
+    if (wlds) {                                                                                            \
+      if (int e = lion_dynamic_lds(&pwconv_kernel<CB, VB, PRO_, ST_, true>, lds, cfg)) return e;           \
+      pwconv_kernel<CB, VB, PRO_, ST_, true><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, pw_stride(Cout), Cout, L, pa, pb, stats); \
+    } else {                                                                                               \
+      if (int e = lion_dynamic_lds(&pwconv_kernel<CB, VB, PRO_, ST_, false>, lds, cfg_g)) return e;        \
+      pwconv_kernel<CB, VB, PRO_, ST_, false><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, pw_stride(Cout), Cout, L, pa, pb, stats); \
+    }                                                                                                      \
   }
   if (pa && stats) LION_PW_GO(true, true)
   else if (pa) LION_PW_GO(true, false)
@@ -193,40 +344,65 @@ static int launch_pw(const float *x, const float *wp, const float *bias, float *
 
 extern "C" {
 
-size_t lion_pwconv_packed_floats(int Cout, int Cin) { return (size_t)((Cin + 1) / 2 * 2) * Cout; }
+size_t lion_pwconv_packed_floats(int Cout, int Cin) { return (size_t)((Cin + 1) / 2 * 2) * pw_stride(Cout); }
 
 int lion_pwconv_pack_weights(const float *w, int Cout, int Cin, float *wp, lionStream_t stream) {
   if (!w || !wp || Cout <= 0 || Cin <= 0) return LION_EINVAL;
-  const int Cin_pad = (Cin + 1) / 2 * 2;
-  pwconv_pack_kernel<<<lion_cdiv(Cin_pad * Cout, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cout, Cin, Cin_pad, wp);
+  const int Cin_pad = (Cin + 1) / 2 * 2, Cout_pad = pw_stride(Cout);
+  pwconv_pack_kernel<<<lion_cdiv(Cin_pad * Cout_pad, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(w, Cout, Cout_pad, Cin,
+                                                                                                       Cin_pad, wp);
   LION_LAUNCH_CHECK();
   return 0;
 }
 
 // column tiles per batch element = rows of the stats tensor per channel (0: shape not supported)
-int lion_pwconv_stat_tiles(int Cout, int L) {
-  const PwPlan p = pw_plan(Cout);
+int lion_pwconv_stat_tiles(int Cout, int Cin, int L) {
+  if (L > 0 && L <= PW_SMALL_L && Cout > 0 && Cin > 0) return lion_cdiv(L, 32); // pwconv_small_kernel: 32-column tiles
+  const PwPlan p = pw_plan(Cout, Cin);
   return (p.cb && L > 0) ? lion_cdiv(L, 4 * p.vb * 32) : 0;
 }
 
 // x f32[B,Cin,L], wp from lion_pwconv_pack_weights, bias f32[Cout] or NULL -> y f32[B,Cout,L];
-// Cout in {32,64,128,256}, weight slice <= 150 KiB of LDS.  pro_a / pro_b f32[B,Cin] (both or neither):
-// the input is swish(x*a+b).  stats f32[B,Cout,lion_pwconv_stat_tiles(Cout,L),2] or NULL.
-// Meant for the large activations (set-abstraction MLPs, L = M*U); short ones are latency bound and
-// better served by the library GEMM.
+// any Cout (channel tiles of 32..256, rows beyond Cout are zero weights and never stored), weight slice <= 150 KiB of LDS.  pro_a / pro_b f32[B,Cin] (both or neither):
+// the input is swish(x*a+b).  stats f32[B,Cout,lion_pwconv_stat_tiles(Cout,Cin,L),2] or NULL.
+// Built around the large activations (set-abstraction MLPs, L = M*U: one read + one write per layer); the short ones
+// (L = 16 .. 256 points, classifier, attention projections) are latency bound whatever runs them and use it too.
 int lion_pwconv_forward(const float *x, const float *wp, const float *bias, int B, int Cin, int Cout, int L,
                         const float *pro_a, const float *pro_b, float *y, float *stats, lionStream_t stream) {
   if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0) return LION_EINVAL;
   if ((pro_a == nullptr) != (pro_b == nullptr)) return LION_EINVAL;
-  const PwPlan p = pw_plan(Cout);
-  if (!p.cb || pw_lds(p.cb, Cin, pro_a != nullptr) > 150 * 1024) return LION_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (L <= PW_SMALL_L) {
+    const dim3 grid(lion_cdiv(L, 32), pw_stride(Cout) / 64, B);
+    const size_t lds = pro_a ? (size_t)2 * Cin * 4 : 0;
+    if (lds > 64 * 1024) return LION_EUNSUPPORTED;
+    if (pro_a && stats) pwconv_small_kernel<true, true><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, pw_stride(Cout), Cout, L, pro_a, pro_b, stats);
+    else if (pro_a) pwconv_small_kernel<true, false><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, pw_stride(Cout), Cout, L, pro_a, pro_b, stats);
+    else if (stats) pwconv_small_kernel<false, true><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, pw_stride(Cout), Cout, L, pro_a, pro_b, stats);
+    else pwconv_small_kernel<false, false><<<grid, 256, lds, st>>>(x, wp, bias, y, Cin, pw_stride(Cout), Cout, L, pro_a, pro_b, stats);
+    LION_LAUNCH_CHECK();
+    return 0;
+  }
+  const PwPlan p = pw_plan(Cout, Cin);
+  if (!p.cb) return LION_EUNSUPPORTED;
   switch (p.cb) {
   case 1: return launch_pw<1, 4>(x, wp, bias, y, B, Cin, Cout, L, pro_a, pro_b, stats, st);
   case 2: return launch_pw<2, 4>(x, wp, bias, y, B, Cin, Cout, L, pro_a, pro_b, stats, st);
   case 4: return launch_pw<4, 2>(x, wp, bias, y, B, Cin, Cout, L, pro_a, pro_b, stats, st);
   default: return launch_pw<8, 1>(x, wp, bias, y, B, Cin, Cout, L, pro_a, pro_b, stats, st);
   }
+}
+
+// y f32[B,O] = act(x f32[B,K] W^T + bias), wp = lion_pwconv_pack_weights(W f32[O,K]) (k-major, O padded to 32);
+// act 0 none / 1 relu / 2 leaky-relu(slope).  nn.Linear of the time-embedding MLP and the batched AdaGN projections.
+int lion_linear_forward(const float *x, const float *wp, const float *bias, int B, int K, int O, int act, float slope,
+                        float *y, lionStream_t stream) {
+  if (!x || !wp || !y || B <= 0 || K <= 0 || O <= 0 || act < 0 || act > 2) return LION_EINVAL;
+  const int Opad = pw_stride(O);
+  linear_rows_kernel<<<dim3(pw_pad(O) / 32, lion_cdiv(B, 32)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      x, wp, bias, B, K, O, Opad, act, slope, y);
+  LION_LAUNCH_CHECK();
+  return 0;
 }
 
 } // extern "C"

@@ -156,6 +156,7 @@ def _pw_pack(weight):
 
 
 _PW_CACHE = WeightCache(_pw_pack)
+PW_ALL = __import__("os").environ.get("LION_PW_ALL", "1") != "0"
 
 
 def pw_packed_weight(weight):
@@ -164,18 +165,19 @@ def pw_packed_weight(weight):
 
 
 def pw_supported(conv, x):
-    """large activations only (>= 4 M output elements, rows >= 1024 long): the short ones are latency
-    bound and stay on the library GEMM."""
-    cout, cin = conv.out_channels, conv.in_channels
-    L = x[0, 0].numel()
-    lds = (2 * ((cin + 1) // 2) * cout + 2 * cin + 8 * cout) * 4
-    return (cout in (32, 64, 128, 256) and lds <= 150 * 1024 and L >= 1024
-            and x.shape[0] * L * cout >= (1 << 22) and conv.groups == 1
-            and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
-            and all(p == 0 for p in conv.padding))
+    """every kernel-size-1 Conv1d / Conv2d whose weight tile fits LDS (all of the released models'): large
+    activations (set-abstraction MLPs) for the bytes, short ones (L = 16..256 points, classifier, attention
+    projections, time embedding) so that no library GEMM / layout-transposing convolution is left in the step."""
+    if not PW_ALL:  # A/B switch (LION_PW_ALL=0): only the large activations, the rest on the library GEMM
+        L = x[0, 0].numel()
+        if not (conv.out_channels in (32, 64, 128, 256) and L >= 1024 and x.shape[0] * L * conv.out_channels >= (1 << 22)):
+            return False
+    return (conv.groups == 1 and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
+            and all(p == 0 for p in conv.padding) and x.is_cuda and x.dtype == torch.float32 and x[0, 0].numel() > 0
+            and _lib.load().lion_pwconv_stat_tiles(conv.out_channels, conv.in_channels, x[0, 0].numel()) > 0)
 
 
-def pwconv_fused(x, conv, pro=None):
+def pwconv_fused(x, conv, pro=None, want_stats=True):
     """1x1 conv of a [B,Cin,*] activation on the MFMA kernel: y [B,Cout,*] and its GroupNorm tile sums
     [B,Cout,T,2]; pro = (A, Bs) applies swish(x*A+Bs) (the previous layer's AdaGN + Swish) in flight."""
     lib = _lib.load()
@@ -185,7 +187,8 @@ def pwconv_fused(x, conv, pro=None):
     cout = conv.out_channels
     wp = pw_packed_weight(conv.weight)
     y = torch.empty((b, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
-    stats = torch.empty((b, cout, lib.lion_pwconv_stat_tiles(cout, L), 2), device=x.device, dtype=torch.float32)
+    stats = torch.empty((b, cout, lib.lion_pwconv_stat_tiles(cout, cin, L), 2), device=x.device,
+                        dtype=torch.float32) if want_stats else None
     pa = pb = None
     if pro is not None:
         pa, pb = pro[0].contiguous(), pro[1].contiguous()
@@ -194,6 +197,31 @@ def pwconv_fused(x, conv, pro=None):
                                        _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats),
                                        _lib.stream_ptr(x.device)), "pwconv_forward")
     return y, stats
+
+
+def linear_rows(x, weight, bias=None, act=0, slope=0.0):
+    """nn.Linear on [B, K]: act(x W^T + b) in ONE launch on the fp32 MFMA kernel (lion_linear_forward);
+    act 0 none / 1 relu / 2 leaky-relu(slope)."""
+    lib = _lib.load()
+    x = x.contiguous()
+    b, k = x.shape
+    o = weight.shape[0]
+    wp = pw_packed_weight(weight)
+    y = torch.empty((b, o), device=x.device, dtype=torch.float32)
+    bias_c = bias.detach().contiguous() if bias is not None else None
+    _lib.check(lib.lion_linear_forward(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias_c), b, k, o, int(act), float(slope),
+                                       _lib.ptr(y), _lib.stream_ptr(x.device)), "linear_forward")
+    return y
+
+
+def linear_attention_core(qkv, heads, dim_head):
+    """[B, 3*heads*dim_head, N] -> [B, heads*dim_head, N]: softmax over N of k, ctx = k v^T, out = ctx^T q."""
+    qkv = qkv.contiguous()
+    b, n = qkv.shape[0], qkv[0, 0].numel()
+    out = torch.empty((b, heads * dim_head) + tuple(qkv.shape[2:]), device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.load().lion_linear_attention_core(_lib.ptr(qkv), b, heads, dim_head, n, _lib.ptr(out),
+                                                      _lib.stream_ptr(qkv.device)), "linear_attention_core")
+    return out
 
 
 def affine_swish(x, A, Bs, reduce_max=False):

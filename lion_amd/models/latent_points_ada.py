@@ -96,8 +96,12 @@ class PVCNN2Unet(nn.Module):
             t = temb
             if t.ndim == 0 and not len(t.shape) == 1:
                 t = t.view(1).expand(B)
-            temb = self.embedf(self.get_timestep_embedding(t, inputs.device))[:, :, None] \
-                .expand(-1, -1, inputs.shape[-1])
+            emb = self.get_timestep_embedding(t, inputs.device)
+            if pvcnn2_ada.own_kernels(emb) and len(self.embedf) == 3:  # Linear -> LeakyReLU(0.1) -> Linear: 2 launches
+                emb = pvcnn2_ada.linear(self.embedf[2], pvcnn2_ada.linear(self.embedf[0], emb, 2, self.embedf[1].negative_slope))
+            else:
+                emb = self.embedf(emb)
+            temb = emb[:, :, None].expand(-1, -1, inputs.shape[-1])
         style = kwargs['style']
         if self.clip_forge_enable:
             clip_feat = kwargs['clip_feat']

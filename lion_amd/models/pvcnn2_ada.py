@@ -10,6 +10,7 @@ Differences that matter on MI355X (all numerically equivalent to fp32 rounding, 
     block is kept as given (shape contract of the callers), nothing is re-laid-out on the host.
 """
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -23,7 +24,7 @@ FUSE_INFERENCE = True  # module-level switch (tests compare the fused and the la
 # conv1 of a PVConv reads the voxelised grid: skip (exactly) the tiles whose halo holds no point
 SPARSE_CONV1 = True
 # run the point branch of a PVConv on a second stream, concurrently with its voxel branch (inference)
-OVERLAP_POINT_BRANCH = True
+OVERLAP_POINT_BRANCH = os.environ.get("LION_OVERLAP_POINT_BRANCH", "1") != "0"
 _POINT_STREAMS = {}
 
 
@@ -69,6 +70,12 @@ class LinearAttention(nn.Module):
         self.to_out = nn.Conv2d(hidden_dim, dim, 1)
 
     def forward(self, x):
+        if own_kernels(x) and self.to_qkv.out_channels == 3 * self.heads * 32 and fused_ops.pw_supported(self.to_qkv, x):
+            # inference: 3 launches -- to_qkv (MFMA 1x1 conv), the attention core of one workgroup per (batch, head)
+            # (csrc/attention.hip), to_out -- instead of conv, rearrange copy, softmax, two bmm, rearrange, conv
+            qkv = fused_ops.pwconv_fused(x, self.to_qkv, None, want_stats=False)[0]
+            core = fused_ops.linear_attention_core(qkv, self.heads, 32)
+            return fused_ops.pwconv_fused(core, self.to_out, None, want_stats=False)[0]
         x = x.unsqueeze(-1)  # [B, C, N, 1]
         b, c, h, w = x.shape
         qkv = self.to_qkv(x)
@@ -118,12 +125,31 @@ class BallQuery(nn.Module):
             self.radius, self.num_neighbors, ', include coordinates' if self.include_coordinates else '')
 
 
+def own_kernels(x):
+    """inference on the GPU in fp32: every dense layer has a kernel of liblion_hip.so"""
+    return (FUSE_INFERENCE and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and not torch.is_autocast_enabled())
+
+
+def linear(lin, x, act=0, slope=0.0):
+    """nn.Linear (+ ReLU / LeakyReLU) on [B, K]: one MFMA launch in inference, torch otherwise."""
+    if own_kernels(x) and x.dim() == 2:
+        return fused_ops.linear_rows(x, lin.weight, lin.bias, act, slope)
+    y = lin(x)
+    return y if act == 0 else (torch.relu(y) if act == 1 else nn.functional.leaky_relu(y, slope))
+
+
 def conv1x1(conv, x):
     """kernel-size-1 Conv1d / Conv2d as a (broadcast) matrix product.  Same arithmetic; the point is the backward:
     autograd then differentiates a GEMM (rocBLAS) instead of asking the convolution library for backward-data /
     backward-filter kernels of a 1x1 conv, for which it falls back to naive kernels on an untuned box (5 ms per
     layer, 60 of the 158 ms of a VAE training step).  Inference keeps the library's forward kernel (measured 0.6 ms per
     denoiser step faster than the batched matmul for these shapes)."""
+    if own_kernels(x) and fused_ops.pw_supported(conv, x):
+        if x[0, 0].numel() == 1:  # [B, C, 1(, 1)]: a Linear over the batch (one column per sample would waste the tile)
+            y = fused_ops.linear_rows(x.reshape(x.shape[0], x.shape[1]), conv.weight.flatten(1), conv.bias)
+            return y.reshape(x.shape[0], conv.out_channels, *x.shape[2:])
+        return fused_ops.pwconv_fused(x, conv, None, want_stats=False)[0]  # fp32 MFMA GEMM, no layout transposes
     if (x.is_cuda and torch.is_grad_enabled() and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
             and all(p == 0 for p in conv.padding) and conv.groups == 1):
         y = torch.matmul(conv.weight.flatten(1), x.flatten(2))

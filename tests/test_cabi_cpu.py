@@ -108,10 +108,13 @@ def test_host_side_plan_functions():
     assert lib.lion_conv3d_wgrad_workspace_floats(32, 32, 32, 32) == 32 * 4 * 4 * 32 * 32 * 27  # 4 spatial splits
     assert lib.lion_conv3d_wgrad_workspace_floats(32, 3, 32, 32) == 0      # Cin % 4 != 0: library fallback
     # pointwise conv: column tiles of 4 waves x VB x 32 columns
-    assert lib.lion_pwconv_stat_tiles(64, 32768) == 32768 // 512
-    assert lib.lion_pwconv_stat_tiles(128, 1000) == -(-1000 // 256)
-    assert lib.lion_pwconv_stat_tiles(48, 1000) == 0
-    assert lib.lion_pwconv_packed_floats(64, 35) == 36 * 64
+    assert lib.lion_pwconv_stat_tiles(64, 35, 32768) == 32768 // 512
+    assert lib.lion_pwconv_stat_tiles(128, 64, 8000) == -(-8000 // 256)
+    assert lib.lion_pwconv_stat_tiles(48, 16, 10000) == -(-10000 // 512)   # 48 -> two 32-row tiles, one half masked
+    assert lib.lion_pwconv_stat_tiles(256, 320, 8192) == 8192 // 512        # 256 / 128 rows x 320 k do not fit LDS: 64-row tiles
+    assert lib.lion_pwconv_stat_tiles(4, 128, 2048) == 2048 // 32           # <= 4096 columns: the K-split kernel, 32-column tiles
+    assert lib.lion_pwconv_stat_tiles(128, 256, 64) == 2
+    assert lib.lion_pwconv_packed_floats(64, 35) == 36 * 64 and lib.lion_pwconv_packed_floats(4, 128) == 128 * 64
     # skinny GEMM: split K until ~256 workgroups, >= 8 k-steps per wave
     assert lib.lion_skinny_splits(2048, 2048) == 4
     assert lib.lion_skinny_splits(2048, 256) == 8                        # 8 output tiles only: split K further

@@ -467,7 +467,10 @@ def _swish64(t):
 
 
 @pytest.mark.parametrize("cin,cout,L,pro", [(35, 32, 4096, False), (32, 64, 4096, True), (67, 128, 1000, True),
-                                            (131, 128, 333, False), (64, 256, 2048, True)])
+                                            (131, 128, 333, False), (64, 256, 2048, True),
+                                            # > 4096 columns: the LDS-weight kernel for the large activations
+                                            (35, 32, 9000, False), (32, 64, 20000, True), (67, 128, 8192, True),
+                                            (64, 256, 5000, True)])
 def test_pwconv_matches_fp64_reference(cin, cout, L, pro):
     """G1: 1x1 conv on the fp32-MFMA kernel (lion_pwconv_forward) with the AdaGN+Swish prologue and the
     GroupNorm tile sums vs an fp64 evaluation of the same expression (odd Cin, ragged L, masked tail)."""
@@ -489,7 +492,72 @@ def test_pwconv_matches_fp64_reference(cin, cout, L, pro):
     sums = st.double().sum(2)  # [B, Cout, 2] over the column tiles
     assert torch.allclose(sums[..., 0], ref.sum(-1), rtol=1e-4, atol=1e-4 * scale * L ** 0.5)
     assert torch.allclose(sums[..., 1], ref.square().sum(-1), rtol=1e-4)
-    assert _lib.load().lion_pwconv_stat_tiles(cout, L) == st.shape[2]
+    assert _lib.load().lion_pwconv_stat_tiles(cout, cin, L) == st.shape[2]
+
+
+@pytest.mark.parametrize("cin,cout,L", [(128, 4, 2048), (64, 384, 1024), (131, 48, 16), (320, 256, 300), (64, 256, 1),
+                                        (259, 96, 77)])
+def test_pwconv_any_cout_and_short_rows(cin, cout, L):
+    """G1 for the short activations / classifier / attention projections: any Cout (rows padded to 32 inside the
+    kernel, never stored), rows as short as one column, weight tiles chosen to fit LDS (320 -> 256: 64-row tiles)."""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(cin + cout + L)
+    B = 3
+    conv = torch.nn.Conv1d(cin, cout, 1).cuda()
+    x = torch.randn(B, cin, L, device="cuda")
+    assert fo.pw_supported(conv, x)
+    ref = torch.einsum("oc,bcl->bol", conv.weight.double()[:, :, 0], x.double()) + conv.bias.double()[None, :, None]
+    with torch.no_grad():
+        y, st = fo.pwconv_fused(x, conv, None)
+        y2, st2 = fo.pwconv_fused(x, conv, None, want_stats=False)
+    assert st2 is None and torch.equal(y, y2) and tuple(y.shape) == (B, cout, L)
+    scale = ref.abs().max().item()
+    assert (y.double() - ref).abs().max().item() / scale < 1e-5
+    sums = st.double().sum(2)
+    assert torch.allclose(sums[..., 0], ref.sum(-1), rtol=1e-4, atol=1e-4 * scale * max(L, 1) ** 0.5)
+    assert torch.allclose(sums[..., 1], ref.square().sum(-1), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,K,O,act", [(32, 128, 6144, 0), (32, 64, 64, 2), (5, 64, 64, 0), (40, 129, 37, 1), (1, 512, 128, 0)])
+def test_linear_rows_matches_fp64_reference(B, K, O, act):
+    """nn.Linear on own MFMA kernel (time-embedding MLP, batched AdaGN projections): odd K / O, batch tails, slabs."""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(B + K + O)
+    lin = torch.nn.Linear(K, O).cuda()
+    x = torch.randn(B, K, device="cuda")
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.1)
+    with torch.no_grad():
+        got = fo.linear_rows(x, lin.weight, lin.bias, act, 0.1)
+    assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,C,N", [(3, 64, 1024), (2, 128, 16), (2, 64, 100), (1, 32, 2048)])
+def test_linear_attention_matches_fp64_reference(B, C, N):
+    """P5 (models/pvcnn2_ada.py:43-71): the module's inference path -- to_qkv on the MFMA 1x1 conv, the attention
+    core of csrc/attention.hip, to_out -- against the reference's expressions evaluated in float64, and against the
+    module's own torch path (grad mode)."""
+    from lion_amd.models.pvcnn2_ada import LinearAttention
+    torch.manual_seed(B + C + N)
+    att = LinearAttention(C).cuda().eval()
+    x = torch.randn(B, C, N, device="cuda")
+    wq, wo, bo = att.to_qkv.weight.double()[:, :, 0, 0], att.to_out.weight.double()[:, :, 0, 0], att.to_out.bias.double()
+    qkv = torch.einsum("oc,bcn->bon", wq, x.double()).view(B, 3, att.heads, 32, N)
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, att.heads * 32, N)
+    ref = torch.einsum("oc,bcn->bon", wo, out) + bo[None, :, None]
+    with torch.no_grad():
+        got = att(x)
+    assert tuple(got.shape) == (B, C, N)
+    assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+    with torch.enable_grad():
+        lib_path = att(x.clone().requires_grad_(True))     # grad mode: the torch formulation
+    assert (lib_path.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("cin,cmid,cout,B", [(2048, 2048, 256, 32), (128, 2048, 2048, 5), (256, 128, 64, 40)])
