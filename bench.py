@@ -147,9 +147,142 @@ def _spawn(args):
     sys.exit(rc)
 
 
+
+def train_bench(args, rank, world, dev, backend):
+    """--mode train_vae | train_prior: one data-parallel training step of BASELINE.json configs[2] / configs[3] at the
+    per-GPU share of the quoted batch (B = 128 / 4 and 256 / 8 = 32 x 2048 points): forward + backward + bucketed
+    gradient averaging (lion_amd/dist.py; hooks armed at world size 1 too) + Adam, synthetic N(0, 1) clouds.
+    value = samples/s over all ranks.  The step is captured in one hipGraph when it can be (world size 1; 7.8 k launches
+    per VAE step otherwise leave the GPU idle 80 % of the time); `launch` says which one ran."""
+    import torch.distributed as dist
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.dist import BucketedGradAverager, broadcast_params
+    from lion_amd import training
+    vae_mode = args.mode == "train_vae"
+    cfg = released_prior_cfg("chair" if vae_mode else "car")
+    B = args.batch if args.batch_given else 32
+    K, W = (args.steps if args.steps_given else 20), args.warmup
+    torch.manual_seed(0)
+    use_graph = world == 1 and not args.no_graph
+    if vae_mode:
+        from lion_amd.models.vae_adain import Model as VAE
+        model = VAE(cfg).to(dev).train()
+        params = list(model.parameters())
+        name = "configs[2]: hvae_trainer VAE step (style encoder + latent-point encoder + decoder), chair, B=128 over 4 GPUs"
+    else:
+        from lion_amd.models.lion import LION
+        lion = LION(cfg, device=dev)
+        lion.vae.eval()
+        for p_ in lion.vae.parameters():
+            p_.requires_grad_(False)
+        model = lion.priors.train()
+        params = list(model.parameters())
+        name = "configs[3]: train_2prior step (frozen VAE encode + global + local denoiser), car, B=256 over 8 GPUs"
+    if world > 1:
+        broadcast_params(params)
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), capturable=use_graph)
+    averager = BucketedGradAverager(params)
+    torch.manual_seed(1234 + rank)
+    x = torch.randn(B, 2048, 3, device=dev)
+    static_loss = [None]
+
+    def step():
+        nonlocal opt, averager
+        if vae_mode:
+            loss, _ = training.vae_train_step(model, opt, x, step=0, averager=averager, distributed=world > 1)
+        else:
+            loss, _ = training.prior_train_step(lion.vae, model, lion.diffusion, opt, x, averager=averager,
+                                                distributed=world > 1)
+        static_loss[0] = loss
+        return loss
+
+    launch = "eager"
+    for _ in range(max(W, 3)):
+        step()
+    torch.cuda.synchronize()
+    runner = step
+    if use_graph:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            runner = g.replay
+            launch = "hipGraph replay of the whole step (forward, backward, Adam)"
+            g.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # capture is an optimisation: say so and measure the eager step
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            print(f"bench: training-step capture failed ({type(e).__name__}); eager launches", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            # an aborted capture leaves gradient views / optimizer state pointing into the dead graph pool: start over
+            averager.remove_hooks()
+            for p_ in params:
+                p_.grad = None
+            opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99))
+            averager = BucketedGradAverager(params)
+            runner = step
+            launch = f"eager (capture failed: {type(e).__name__})"
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        runner()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    ms = elapsed / K * 1e3
+    loss_v = float(static_loss[0])
+    if rank == 0:
+        from lion_amd import conv_ops
+        with torch.no_grad():
+            xin = torch.randn(32, 64, 32, 32, 32, device=dev)
+            gy = torch.randn(32, 64, 32, 32, 32, device=dev)
+            tw = ev_time(lambda: conv_ops.conv3d_k3_wgrad(xin, gy, (64, 64, 3, 3, 3)), 10, warm=3)
+        flops = 2.0 * 27 * 64 * 64 * 32 ** 3 * 32
+        out = {"metric": "samples/sec, one data-parallel training step (fwd + bwd + grad averaging + Adam)",
+               "value": world * B / (ms / 1e3), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32 (voxel-conv forward / data-gradient operands cut into fp16 pairs on the 16-bit MFMA pipe, f32 "
+                        "accumulate; weight gradient exact-fp32 MFMA)" if conv_ops.SPLIT else "f32",
+               "data": "synthetic",
+               "config": {"workload": name, "samples_per_gpu": B, "points": 2048, "launch": launch,
+                          "gradient_averaging": f"BucketedGradAverager, {len(averager.buckets)} buckets, world {world}",
+                          "final_loss": loss_v},
+               "roofline": {"kernel": "conv3d_wgrad_kernel: weight gradient of Conv3d 3x3x3 64->64 @32^3, B=32 "
+                                      "(fp32 MFMA, csrc/conv3d_wgrad.hip)", "bound": "mfma", "achieved": flops / tw / 1e12,
+                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / tw / 1e12 / MFMA_F32_PEAK_TF,
+                            "traffic": None, "us_per_launch": tw * 1e6},
+               "cpu_baseline": {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                                "sample": "not timed for the training modes (the sampling line carries the host baseline)"}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--mode", choices=["sample", "train_vae", "train_prior"], default="sample",
+                    help="sample (default): the BASELINE metric; train_*: one training step of configs[2] / configs[3]")
     ap.add_argument("--steps", type=int, default=1000,
                     help="DDIM steps per prior that are timed; 1000 = the metric's real chain (~17 s)")
     ap.add_argument("--warmup", type=int, default=3)
@@ -160,6 +293,8 @@ def main():
                     help="run the voxel convolutions densely (no exact skip of all-zero input tiles)")
     ap.add_argument("--no-dense-check", action="store_true", help="skip the short dense (--no-sparse) side measurement")
     args = ap.parse_args()
+    args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in sys.argv[1:])
+    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn(args)
     from lion_amd.models import pvcnn2_ada
@@ -180,6 +315,8 @@ def main():
 
     from lion_amd import _lib
     _lib.load()  # fail loudly if the HIP extension is missing
+    if args.mode != "sample":
+        return train_bench(args, rank, world, dev, backend)
     from lion_amd.config import released_prior_cfg
     from lion_amd.sampling import generate_samples_vada_2prior, rank_seed
 

@@ -123,7 +123,10 @@ class Model(nn.Module):
         output['hist/global_var'] = gs.exp()
         if 'LatentPoint' in self.args.shapelatent.decoder_type:
             latent_pts = zl.view(batch_size, -1, self.latent_dim + self.input_dim)[:, :, :self.input_dim]
-            output['vis/latent_pts'] = latent_pts.detach().cpu().view(batch_size, -1, self.input_dim)
+            # the reference copies this to the host on every call (vae_adain.py:206): a device->host sync per training
+            # step, and not capturable in a hipGraph.  It stays on the device; the (out-of-scope) visualiser that reads
+            # it calls .cpu() itself.
+            output['vis/latent_pts'] = latent_pts.detach().reshape(batch_size, -1, self.input_dim)
         output['final_pred'] = output['x_0_pred']
         return output
 

@@ -1,0 +1,47 @@
+# Round profile set (run through gpurun from the repo root): everything the roofline numbers of DESIGN.md / bench.py are
+# checked against.  Output: gpurun_out/profiles/<tag>_*; copy what should be judged into profiles/.
+TAG=${1:-r02}
+R=$PWD; O=$R/gpurun_out/profiles; mkdir -p $O
+python bench.py > $O/${TAG}_bench_default_1000steps.json 2> $O/${TAG}_bench_default.err
+python bench.py --mode train_vae > $O/${TAG}_bench_train_vae.json 2>> $O/${TAG}_bench_default.err
+python bench.py --mode train_prior > $O/${TAG}_bench_train_prior.json 2>> $O/${TAG}_bench_default.err
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-dense-check > $O/${TAG}_bench_steps20_line.json 2> /dev/null )
+python tools/kstats.py $O/step_trace 70 > $O/${TAG}_bench_steps20_kernel_stats.txt 2>&1
+cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
+bash tools/prof_traffic.sh vox_64_2048_32 vox_fused -- python tools/one_vox.py 64 2048 32 > /dev/null 2>&1
+bash tools/prof_traffic.sh devox_64_2048_32 devox -- python tools/one_devox.py 64 2048 32 > /dev/null 2>&1
+bash tools/prof_traffic.sh global_prior skinny -- python tools/one_global_prior.py > /dev/null 2>&1
+for n in vox_64_2048_32 devox_64_2048_32 global_prior; do cp gpurun_out/traffic/$n.json $O/${TAG}_${n}_traffic.json; done
+# MFMA-busy of the dominant conv on both kernels (own PMC passes, no tracing)
+( cd /tmp; export TMPDIR=/tmp
+  for k in split fp32; do
+    S=1; [ $k = fp32 ] && S=0
+    LION_CONV_SPLIT=$S timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_$k -- python $R/tools/one_conv.py 64 64 32 > /dev/null 2>&1
+    LION_CONV_SPLIT=$S timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$k -- python $R/tools/one_conv.py 64 64 32 > /dev/null 2>&1
+  done )
+python - "$TAG" <<'PY'
+import csv, glob, json, sys, collections
+tag = sys.argv[1]; O = "gpurun_out/profiles"
+out = {}
+for k in ("split", "fp32"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(f"{O}/pmc_{k}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "conv3d" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"] and "wmax" not in r["Kernel_Name"] and "wscale" not in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = []
+    for f in glob.glob(f"{O}/trace_{k}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "conv3d_split_kernel" in r["Kernel_Name"] or "conv3d_k3_kernel" in r["Kernel_Name"]:
+                dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    e = {c: sum(v) / len(v) for c, v in acc.items()}
+    if dur: e["avg_us"] = sum(dur) / len(dur)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e:
+        e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 128.0)  # GRBM_GUI_ACTIVE is summed over the 8 XCDs; x 32 CUs x 4 SIMDs each
+    out[k] = e
+json.dump({"kernel": "Conv3d 3x3x3 64->64 @32^3, B=32 (tools/one_conv.py)", "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE [sum over 8 XCDs] x 128 SIMDs per XCD); the counter pass runs at ~2.0 GHz (DVFS)", **out},
+          open(f"{O}/{tag}_conv_mfma_util.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+rm -rf $O/step_trace $O/pmc_* $O/trace_*
+ls -la $O
