@@ -148,6 +148,40 @@ def _spawn(args):
 
 
 
+def demo_bench(args, rank, world, dev):
+    """--mode demo: BASELINE.json configs[0] -- demo.py's chair prior, ONE shape x 2048 points, 100 DDIM steps per prior
+    + decode -- as a latency line on the GPU (the reference quotes it as CPU-only plumbing; there is no CPU path in this
+    product).  The timed call is the product sampler; value = seconds per shape, median of 5 calls after one warm-up."""
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.sampling import generate_samples_vada_2prior, rank_seed
+    cfg = released_prior_cfg("chair")
+    lion = build_models(cfg, dev)
+    shapes = lion.vae.latent_shape()
+    K = args.steps if args.steps_given else 100
+    times = []
+    with torch.no_grad():
+        for i in range(6):
+            torch.manual_seed(rank_seed(1234, rank, i))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pts = generate_samples_vada_2prior(shapes, lion.priors, lion.diffusion, lion.vae, 1, ddim_step=K,
+                                               graph=not args.no_graph)[0]
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    assert tuple(pts.shape) == (1, 2048, 3) and bool(torch.isfinite(pts).all())
+    lat = sorted(times[1:])[len(times[1:]) // 2]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "seconds per shape (latency), 1 x 2048 pts, %d DDIM steps per prior + decode" % K, "value": lat,
+            "unit": "s", "n_gpus": world, "steps": K, "warmup": 1, "ms_per_step": lat / K * 1e3, "higher_is_better": False,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[0]: demo.py chair prior, 1 shape x 2048 pts, %d DDIM steps, on the GPU" % K,
+                       "calls_timed": len(times) - 1, "first_call_seconds_incl_graph_capture": times[0],
+                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+            "cpu_baseline": {"value": None, "unit": "s", "cores": os.cpu_count(), "kind": "port",
+                             "sample": "see the --mode sample line"}}), flush=True)
+
+
 def train_bench(args, rank, world, dev, backend):
     """--mode train_vae | train_prior: one data-parallel training step of BASELINE.json configs[2] / configs[3] at the
     per-GPU share of the quoted batch (B = 128 / 4 and 256 / 8 = 32 x 2048 points): forward + backward + bucketed
@@ -281,8 +315,9 @@ def train_bench(args, rank, world, dev, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--mode", choices=["sample", "train_vae", "train_prior"], default="sample",
-                    help="sample (default): the BASELINE metric; train_*: one training step of configs[2] / configs[3]")
+    ap.add_argument("--mode", choices=["sample", "demo", "train_vae", "train_prior"], default="sample",
+                    help="sample (default): the BASELINE metric; demo: configs[0] as a latency line (1 shape, 100 DDIM "
+                         "steps); train_*: one training step of configs[2] / configs[3]")
     ap.add_argument("--steps", type=int, default=1000,
                     help="DDIM steps per prior that are timed; 1000 = the metric's real chain (~17 s)")
     ap.add_argument("--warmup", type=int, default=3)
@@ -315,6 +350,8 @@ def main():
 
     from lion_amd import _lib
     _lib.load()  # fail loudly if the HIP extension is missing
+    if args.mode == "demo":
+        return demo_bench(args, rank, world, dev)
     if args.mode != "sample":
         return train_bench(args, rank, world, dev, backend)
     from lion_amd.config import released_prior_cfg

@@ -121,6 +121,35 @@ def _w_sampling(rank, world):
     assert not torch.equal(allp[0], allp[4])
 
 
+def _w_pair_matrix(rank, world):
+    """lion_amd.metrics.pairwise_distance shards the ROWS of the pair matrix over the ranks and all-gathers them
+    (the reference evaluates everything on rank 0, base_trainer.py:491-495).  The distance kernels need a GPU; here the
+    sharding / gathering logic runs with a CPU stand-in for the two distance functions (ragged split: 7 rows, 2 ranks)."""
+    from lion_amd import metrics
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    def cd(a, b):                                   # brute-force Chamfer, same return convention as the kernels
+        P = ((a[:, :, None, :] - b[:, None, :, :]) ** 2).sum(-1)
+        return P.min(2)[0], P.min(1)[0]
+
+    metrics.distChamferCUDAnograd = cd
+    metrics.emd_approx = lambda a, b, require_grad=False: (a.mean(1) - b.mean(1)).abs().sum(-1)
+    g = torch.Generator().manual_seed(5)
+    smp, ref = torch.rand(7, 20, 3, generator=g), torch.rand(5, 20, 3, generator=g)
+    full = metrics.pairwise_distance("CD", smp, ref, pair_batch=6, rank=0, world=1)
+    mine = metrics.pairwise_distance("CD", smp, ref, pair_batch=6, rank=rank, world=world)
+    assert tuple(mine.shape) == (7, 5) and torch.equal(mine, full)
+    emd = metrics.pairwise_distance("EMD", smp, ref, pair_batch=4, rank=rank, world=world)
+    assert torch.allclose(emd, metrics.pairwise_distance("EMD", smp, ref, pair_batch=4))
+    res = metrics.compute_all_metrics(smp, ref, batch_size=8, rank=rank, world=world)
+    res1 = metrics.compute_all_metrics(smp, ref, batch_size=8)
+    assert res == res1 and "1-NN-CD-acc" in res
+
+
+def test_sharded_pair_matrix_two_ranks():
+    _run(_w_pair_matrix)
+
+
 def test_bucketed_gradient_averaging_two_ranks():
     _run(_w_bucketed)
 

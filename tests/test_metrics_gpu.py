@@ -39,3 +39,26 @@ def test_compute_all_metrics_separates_distributions():
     assert r_far['lgan_mmd-CD'] > 5 * r_same['lgan_mmd-CD']
     paired = EMD_CD(same, same.clone(), batch_size=8)
     assert paired['MMD-CD'].item() == 0.0 and paired['MMD-EMD'].item() < 1e-5
+
+
+def test_compute_all_metrics_matches_the_reference_golden():
+    """the whole driver on the HIP Chamfer / EMD kernels against tests/golden/metrics.npz, the output of the REFERENCE's
+    compute_all_metrics on the same clouds (make_golden_metrics.py): pair matrices, MMD / COV / 1-NNA under both
+    distances, and the device JSD."""
+    import os
+    from conftest import GOLDEN
+    from lion_amd import metrics
+    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    smp, ref = torch.from_numpy(z["smp"]), torch.from_numpy(z["ref"])
+    M = metrics.pairwise_distance("CD", ref, smp, pair_batch=37).cpu().numpy()     # ragged last batch
+    np.testing.assert_allclose(M, z["M_rs_CD"], rtol=1e-5, atol=1e-8)
+    M = metrics.pairwise_distance("EMD", ref, smp, pair_batch=64).cpu().numpy()
+    np.testing.assert_allclose(M, z["M_rs_EMD"], rtol=5e-4)                        # v_exp_f32 vs expf in the auction
+    res = metrics.compute_all_metrics(smp, ref, batch_size=64)
+    for k in res:
+        want = float(z["res/" + k])
+        tol = 1e-5 if "CD" in k else 1e-3
+        assert abs(res[k] - want) <= tol * max(abs(want), 1e-3), (k, res[k], want)
+    assert set(res) == {k[4:] for k in z.files if k.startswith("res/")}
+    jsd = metrics.jsd_between_point_cloud_sets(smp.cuda(), ref.cuda())
+    assert abs(jsd - float(z["jsd"])) < 1e-6
