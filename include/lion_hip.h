@@ -84,6 +84,11 @@ int lion_ball_query(const float *centers, const float *points, int B, int M, int
  * feat f32[B,C,N], idx i32[B,M,U] -> out f32[B,C,M,U];  gy f32[B,C,M,U] -> gx f32[B,C,N]. */
 int lion_grouping_forward(const float *feat, const int32_t *idx, int B, int C, int N, int M,
                           int U, float *out, lionStream_t stream);
+/* BallQuery.forward (models/pvcnn2_ada.py:98-114) without the subtraction pass and the torch.cat of the grouped
+ * activation: out f32[B, 3 + C, M, U], channels 0..2 = coords[b,:,idx[b,m,u]] - centers[b,:,m], 3.. = feat[b,:,idx]
+ * (feat NULL with C = 0: coordinates only).  coords f32[B,3,N], centers f32[B,3,M], feat f32[B,C,N], idx i32[B,M,U]. */
+int lion_group_points_forward(const float *coords, const float *centers, const float *feat, const int32_t *idx,
+                              int B, int C, int N, int M, int U, float *out, lionStream_t stream);
 int lion_grouping_backward(const float *gy, const int32_t *idx, int B, int C, int N, int M,
                            int U, float *gx, lionStream_t stream);
 

@@ -19,3 +19,32 @@ def invalidate_weight_caches() -> None:
     packed / mirrored weights, style plans and captured graphs are rebuilt on next use (lion_amd/_wcache.py)."""
     from . import _wcache
     _wcache.invalidate_all()
+
+
+def _poison_uninitialised():
+    """LION_DEBUG_POISON=1: every torch.empty / empty_like on the GPU is filled with NaN (float) / a large negative
+    number (int32), so that a kernel reading memory it was supposed to overwrite first shows up as NaN / an index far
+    out of range instead of as a rare, allocator-history-dependent mismatch.  Debug aid for the -m gpu suite."""
+    import torch
+    real_empty, real_like = torch.empty, torch.empty_like
+
+    def fill(t):
+        if t.is_cuda and t.numel():
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+            elif t.dtype in (torch.int32, torch.int16):
+                t.fill_(-30000)
+        return t
+
+    def empty(*a, **k):
+        return fill(real_empty(*a, **k))
+
+    def empty_like(*a, **k):
+        return fill(real_like(*a, **k))
+
+    torch.empty, torch.empty_like = empty, empty_like
+
+
+import os as _os
+if _os.environ.get("LION_DEBUG_POISON") == "1":
+    _poison_uninitialised()

@@ -27,6 +27,7 @@ SIGNATURES = {
     "lion_trilinear_devoxelize_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_ball_query": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "lion_grouping_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lion_group_points_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lion_grouping_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lion_furthest_point_sampling": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "lion_gather_features_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

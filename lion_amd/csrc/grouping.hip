@@ -12,30 +12,47 @@
 
 namespace {
 
+// out is a channel slice of a [B, Ctot, MU] tensor (Ctot = C for the plain operator); centers (optional, [B, C, M]):
+// out = feat[idx] - centers[m] -- the neighbour coordinates relative to their centre (pvcnn2_ada.py:104-105), so that
+// BallQuery.forward writes coordinates and features straight into ONE [B, 3 + C, M, U] tensor: no subtraction pass,
+// no torch.cat of the 147 MB activation.  The subtraction is a single IEEE operation, as in the reference.
 template <int CT>
 __global__ __launch_bounds__(256) void grouping_fwd_kernel(const float *__restrict__ feat,
                                                            const int32_t *__restrict__ idx, int C,
-                                                           int N, int MU,
+                                                           int N, int MU, int Ctot, int U,
+                                                           const float *__restrict__ centers,
                                                            float *__restrict__ out) {
   const int b = blockIdx.z;
   const int e = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (e >= MU) return;
   const int c0 = blockIdx.y * CT, c1 = min(C, c0 + CT);
   const int32_t *id = idx + (size_t)b * MU + e;
+  const int M = MU / U;
   if (e + 3 < MU && (MU & 3) == 0) {
     const int4 t = *reinterpret_cast<const int4 *>(id);
     const int i0 = min(max(t.x, 0), N - 1), i1 = min(max(t.y, 0), N - 1),
               i2 = min(max(t.z, 0), N - 1), i3 = min(max(t.w, 0), N - 1);
     const float *f = feat + ((size_t)b * C + c0) * N;
-    float *o = out + ((size_t)b * C + c0) * MU + e;
+    float *o = out + ((size_t)b * Ctot + c0) * MU + e;
+    if (centers) {
+      const int m0 = e / U, m1 = (e + 1) / U, m2 = (e + 2) / U, m3 = (e + 3) / U;
+      const float *ct = centers + ((size_t)b * C + c0) * M;
+      for (int c = c0; c < c1; ++c, f += N, o += MU, ct += M)
+        *reinterpret_cast<float4 *>(o) = make_float4(sub_rn(f[i0], ct[m0]), sub_rn(f[i1], ct[m1]),
+                                                     sub_rn(f[i2], ct[m2]), sub_rn(f[i3], ct[m3]));
+    } else {
 #pragma unroll 4
-    for (int c = c0; c < c1; ++c, f += N, o += MU)
-      *reinterpret_cast<float4 *>(o) = make_float4(f[i0], f[i1], f[i2], f[i3]);
+      for (int c = c0; c < c1; ++c, f += N, o += MU)
+        *reinterpret_cast<float4 *>(o) = make_float4(f[i0], f[i1], f[i2], f[i3]);
+    }
   } else {
     for (int q = 0; q < 4 && e + q < MU; ++q) {
       const int i = min(max(id[q], 0), N - 1);
-      for (int c = c0; c < c1; ++c)
-        out[((size_t)b * C + c) * MU + e + q] = feat[((size_t)b * C + c) * N + i];
+      for (int c = c0; c < c1; ++c) {
+        float v = feat[((size_t)b * C + c) * N + i];
+        if (centers) v = sub_rn(v, centers[((size_t)b * C + c) * M + (e + q) / U]);
+        out[((size_t)b * Ctot + c) * MU + e + q] = v;
+      }
     }
   }
 }
@@ -93,9 +110,28 @@ static int scatter_rows(const float *gy, const int32_t *idx, int B, int C, int N
 
 extern "C" {
 
+static int grouping_launch(const float *feat, const int32_t *idx, int B, int C, int N, int M, int U, int Ctot,
+                           const float *centers, float *out, lionStream_t stream);
+
 int lion_grouping_forward(const float *feat, const int32_t *idx, int B, int C, int N, int M, int U,
                           float *out, lionStream_t stream) {
   if (!feat || !idx || !out || B <= 0 || C <= 0 || N <= 0 || M <= 0 || U <= 0) return LION_EINVAL;
+  return grouping_launch(feat, idx, B, C, N, M, U, C, nullptr, out, stream);
+}
+
+// BallQuery.forward (pvcnn2_ada.py:98-114) in two launches and no concatenation: out f32[B, 3 + C, M, U] with
+// channels 0..2 = coords[b, :, idx] - centers[b, :, m] and 3.. = feat[b, :, idx] (feat may be NULL with C = 0).
+int lion_group_points_forward(const float *coords, const float *centers, const float *feat, const int32_t *idx,
+                              int B, int C, int N, int M, int U, float *out, lionStream_t stream) {
+  if (!coords || !centers || !idx || !out || B <= 0 || C < 0 || N <= 0 || M <= 0 || U <= 0) return LION_EINVAL;
+  if (C > 0 && !feat) return LION_EINVAL;
+  if (int e = grouping_launch(coords, idx, B, 3, N, M, U, 3 + C, centers, out, stream)) return e;
+  if (C > 0) return grouping_launch(feat, idx, B, C, N, M, U, 3 + C, nullptr, out + (size_t)3 * M * U, stream);
+  return 0;
+}
+
+static int grouping_launch(const float *feat, const int32_t *idx, int B, int C, int N, int M, int U, int Ctot,
+                           const float *centers, float *out, lionStream_t stream) {
   const int MU = M * U;
   const int et = lion_cdiv(lion_cdiv(MU, 4), 256);
   int ct = 16;
@@ -103,11 +139,11 @@ int lion_grouping_forward(const float *feat, const int32_t *idx, int B, int C, i
   dim3 grid(et, lion_cdiv(C, ct), B);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (ct) {
-  case 16: grouping_fwd_kernel<16><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, out); break;
-  case 8:  grouping_fwd_kernel<8><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, out); break;
-  case 4:  grouping_fwd_kernel<4><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, out); break;
-  case 2:  grouping_fwd_kernel<2><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, out); break;
-  default: grouping_fwd_kernel<1><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, out); break;
+  case 16: grouping_fwd_kernel<16><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, Ctot, U, centers, out); break;
+  case 8:  grouping_fwd_kernel<8><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, Ctot, U, centers, out); break;
+  case 4:  grouping_fwd_kernel<4><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, Ctot, U, centers, out); break;
+  case 2:  grouping_fwd_kernel<2><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, Ctot, U, centers, out); break;
+  default: grouping_fwd_kernel<1><<<grid, 256, 0, st>>>(feat, idx, C, N, MU, Ctot, U, centers, out); break;
   }
   LION_LAUNCH_CHECK();
   return 0;

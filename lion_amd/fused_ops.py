@@ -199,6 +199,21 @@ def pwconv_fused(x, conv, pro=None, want_stats=True):
     return y, stats
 
 
+def group_points(coords, centers, feat, idx):
+    """[B, 3 + C, M, U]: neighbour coordinates relative to their centre and (feat not None) the gathered features, in
+    one tensor (BallQuery.forward, pvcnn2_ada.py:98-114) -- no subtraction pass, no torch.cat."""
+    b, _, n = coords.shape
+    m, u = idx.shape[1], idx.shape[2]
+    c = 0 if feat is None else feat.shape[1]
+    out = torch.empty((b, 3 + c, m, u), device=coords.device, dtype=torch.float32)
+    co, ce, ix = coords.contiguous(), centers.contiguous(), idx.contiguous()
+    fe = feat.contiguous() if feat is not None else None
+    _lib.check(_lib.load().lion_group_points_forward(_lib.ptr(co), _lib.ptr(ce), _lib.ptr(fe), _lib.ptr(ix), b, c, n,
+                                                     m, u, _lib.ptr(out), _lib.stream_ptr(coords.device)),
+               "group_points_forward")
+    return out
+
+
 def linear_rows(x, weight, bias=None, act=0, slope=0.0):
     """nn.Linear on [B, K]: act(x W^T + b) in ONE launch on the fp32 MFMA kernel (lion_linear_forward);
     act 0 none / 1 relu / 2 leaky-relu(slope)."""

@@ -17,6 +17,7 @@ import torch
 
 _PLAN = None
 _SIDE = {}
+ENABLED = __import__("os").environ.get("LION_GEOMETRY_PREFETCH", "1") != "0"
 
 
 def _side_stream(device):
@@ -55,7 +56,7 @@ def prefetch(sa_modules, coords):
     """sa_modules: the PointNetSAModule of each stage, in order; coords f32[B,3,N] (the tensor object
     the first stage will receive)."""
     global _PLAN
-    if (not sa_modules or not coords.is_cuda or torch.is_grad_enabled() or coords.dim() != 3
+    if (not ENABLED or not sa_modules or not coords.is_cuda or torch.is_grad_enabled() or coords.dim() != 3
             or coords.shape[1] != 3 or not coords.is_contiguous() or coords.dtype != torch.float32):
         yield
         return

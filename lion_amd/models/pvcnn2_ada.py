@@ -110,6 +110,10 @@ class BallQuery(nn.Module):
             points_coords = points_coords.float().contiguous()
             centers_coords = centers_coords.float().contiguous()
             neighbor_indices = F.ball_query(centers_coords, points_coords, self.radius, self.num_neighbors)
+            if own_kernels(points_coords) and self.include_coordinates and points_coords.shape[1] == 3 \
+                    and (points_features is None or points_features.dtype == torch.float32):
+                # inference: relative coordinates and features written straight into one [B, 3 + C, M, U] tensor
+                return fused_ops.group_points(points_coords, centers_coords, points_features, neighbor_indices)
             neighbor_coordinates = F.grouping(points_coords, neighbor_indices)
             neighbor_coordinates = neighbor_coordinates - centers_coords.unsqueeze(-1)
             if points_features is None:

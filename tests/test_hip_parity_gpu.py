@@ -231,6 +231,24 @@ def test_grouping_forward_backward(bk, orc, C, N, M, U):
     np.testing.assert_allclose(orc.grouping_backward(gy, idx, N), ref, rtol=TOL, atol=TOL)
 
 
+@pytest.mark.parametrize("C,N,M,U", [(32, 2048, 1024, 32), (0, 256, 64, 32), (5, 100, 7, 3)])
+def test_group_points_equals_grouping_sub_cat(bk, orc, C, N, M, U):
+    """lion_group_points_forward == cat([grouping(coords) - centers, grouping(feat)]) of BallQuery.forward
+    (pvcnn2_ada.py:98-114), bit for bit (the subtraction is one IEEE operation either way)."""
+    from lion_amd import fused_ops as fo
+    rng = np.random.default_rng(C + N)
+    B = 2
+    co = gaussian_cloud(rng, B, N)
+    ctr = np.ascontiguousarray(co[:, :, :M])
+    idx = rng.integers(0, N, (B, M, U)).astype(np.int32)
+    feat = rng.standard_normal((B, C, N)).astype(np.float32) if C else None
+    want = orc.grouping_forward(co, idx) - ctr[:, :, :, None]
+    if C:
+        want = np.concatenate([want, orc.grouping_forward(feat, idx)], 1)
+    got = fo.group_points(dev(co), dev(ctr), dev(feat) if C else None, dev(idx))
+    assert np.array_equal(host(got), want.astype(np.float32))
+
+
 @pytest.mark.parametrize("N,M", [(2048, 1024), (1024, 256), (256, 64), (64, 16), (700, 33),
                                  (4096, 50), (5000, 20), (3, 3), (10, 1)])
 def test_furthest_point_sampling_bit_exact(bk, orc, N, M):
