@@ -22,10 +22,9 @@ def split_supported(cin, cout, r):
 
 
 def split_preferred(cin, cout, r):
-    """where it is the faster kernel (tools/conv_split_bench.py, B=32): 2.1x at 64->64 r=32, 2.1x at 128->128 r=16,
-    1.1x at 32->32 r=32; at r=8 (128-voxel tiles: the weight slices are re-read per tile and the halo is 3x the tile)
-    the exact-fp32 kernel is faster (114 vs 144 us at 128->128) and stays the default."""
-    return split_supported(cin, cout, r) and r >= 16
+    """where it is the faster kernel (tools/conv_split_bench.py, B=32): 2.2x at 64->64 r=32, 2.5x at 128->128 r=16,
+    1.5x at 32->32 r=32, 2.1x at r=8 (the pipelined half-sample kernel) -- everywhere it can run."""
+    return split_supported(cin, cout, r)
 
 
 def use_split(split, cin, cout, r):

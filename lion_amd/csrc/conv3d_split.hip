@@ -24,7 +24,8 @@
 // persistent work queue + per-wave occupancy masks (occ), constant + delta decomposition (tconst).  K is walked in
 // chunks of 16 input channels (Cin % 16 == 0; other layers stay on the fp32 kernel).  LDS operand planes
 // [piece][k-half][HP halo positions][8 x fp16]: one ds_read_b128 per MFMA fragment, conflict free; the weight slice
-// of a tap [piece][k-half][COT][8 x fp16] is double buffered through registers (one barrier per tap).
+// of a tap [piece][k-half][COT][8 x fp16] goes registers -> LDS in groups of 3 taps, double buffered (one barrier per
+// group: 9 per chunk).
 // History: tools/exp/split_*.hip (inner product 400 TF fp32-equivalent; whole layer 779 us vs 1973 us of the fp32
 // kernel with statistics at B=32, 64->64, r=32).
 #include "common.h"
@@ -85,6 +86,19 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
   wp[((base + 2 + g) * Cout + co) * 8 + j] = lo;
 }
 
+#ifdef SPLIT_EXP_TIMING
+// experiment build only: per-phase shader-clock totals of wave 0 of every workgroup (s_memtime), read with
+// lion_debug_split_phases().  Phases: 0 item prologue, 1 chunk barrier A, 2 load issue + wait + activate + max,
+// 3 barrier B (max complete), 4 cut + LDS write, 5 group barrier (weights handoff), 6 taps of a group, 7 epilogue.
+__device__ unsigned long long g_split_phase[8];
+#define PH_MARK(k)                                                                    \
+  do {                                                                                \
+    const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[k] += (unsigned)(n_ - t_ph); t_ph = n_; \
+  } while (0)
+#else
+#define PH_MARK(k) do { } while (0)
+#endif
+
 template <int TD, int TH, int TW, int CB, int VB, bool PRO, bool STATS, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
                                                               const float *__restrict__ wtail,
@@ -102,12 +116,14 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   constexpr int HP = (HALO + 63) / 64 * 64;   // plane stride: whole waves, so a staging wave never straddles two planes
   constexpr int NI = (2 * HP + TM - 1) / TM;  // staging items (k-half, halo position) per thread
   constexpr int WPL = 4 * COT;                // u4 per weight slice (one tap of one chunk, this channel tile)
-  static_assert(WPL <= TM, "one u4 of the weight slice per thread");
+  constexpr int TG = 3;                       // taps per barrier: the weight slices of a (kd, kh) row of taps travel together
+  static_assert(WPL <= TM, "one u4 of a tap's weight slice per thread");
+  static_assert(27 % TG == 0, "whole groups per chunk");
   static_assert(27 * COT * 4 <= 4 * HP * 16, "the response table must fit the operand planes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u4 *sx = reinterpret_cast<u4 *>(smem);      // [piece][half][HP]
-  u4 *sw = sx + 4 * HP;                       // [2][piece][half][COT]
-  float *sbias = reinterpret_cast<float *>(sw + 2 * WPL); // [COT]
+  u4 *sw = sx + 4 * HP;                       // [2][TG taps][piece][half][COT]
+  float *sbias = reinterpret_cast<float *>(sw + 2 * TG * WPL); // [COT]
   const int npro = PRO ? ((Cin + 63) & ~63) : 0;
   float *spa = sbias + COT, *spb = spa + npro, *spc = spb + npro; // prologue scalars / activated constant per channel
   float *sred = spc + npro;                   // [4][COT][2]
@@ -119,6 +135,10 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_wscale_kernel)
   const bool queued = occ != nullptr;
   const int ncz = Cout / COT;
+#ifdef SPLIT_EXP_TIMING
+  unsigned long long t_ph = __builtin_readcyclecounter(); // totals stay in registers until the workgroup ends: an
+  unsigned ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // atomic per mark would sit in front of every vmcnt wait
+#endif
   for (int iter = 0;; ++iter) {
   int b, tile, co0;
   if (queued) { // see csrc/conv3d.hip: occ = [B*tiles wave masks][B*tiles list, occupied tiles first][queue counter]
@@ -191,10 +211,39 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   // this thread's u4 of a weight slice: element (pg, co) of the tile <- global [pg][Cout] at co0 + co
   const int we_g = (tid / COT) * Cout + co0 + (tid % COT);
   const bool w_thread = tid < WPL;
-  u4 wreg = {0u, 0u, 0u, 0u};
-  if (nchunks && w_thread) wreg = wp[we_g];
+#ifndef SPLIT_WEIGHTS_L2
+  // weight slices travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction lands at
+  // M0 + lane * 16), one group of TG taps ahead of their use, into the buffer the group before last was read from.  No
+  // registers and no VALU on the way: the register ring this replaces cost 12 VGPRs at the 256-register limit (87
+  // spills), and the compiler was free to sink its loads next to their LDS writes (s_memtime phase counters: 29 % of a
+  // wave's cycles went into waiting for them).  The DMA is issued right behind the group barrier and awaited (vmcnt 0)
+  // in front of the next one.
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const uint32_t sw_lds = (uint32_t)(uintptr_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw) + (uint32_t)wave * 1024u;
+  auto weights_dma = [&](int sg) { // group sg of the K walk (chunk sg / 9, taps (sg % 9) * TG ..) -> buffer sg & 1
+    if (w_thread) {                // wave uniform: WPL is a multiple of 64
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        const u4 *gp = wp + ((size_t)sg * TG + t) * 4 * Cout + we_g;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(sw_lds + (uint32_t)(((sg & 1) * TG + t) * WPL * 16));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+      }
+    }
+  };
+  if (nchunks) weights_dma(0);
+#else
+  (void)we_g; (void)w_thread;
+#endif
+  PH_MARK(0);
   for (int q = 0; q < nchunks; ++q) {
     __syncthreads(); // the previous chunk's planes are no longer read (and the prologue scalars are visible)
+    PH_MARK(1);
+#ifdef SPLIT_EXP_NO_STAGE
+    if (q > 0) goto taps; // experiment: only the first chunk is staged (the tap loop then runs on stale planes)
+#endif
+    {
     // all loads of the chunk first (one memory round trip per chunk), then activate, agree on the scale, cut + write
     float v[NI][8];
 #pragma unroll
@@ -223,7 +272,9 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     }
     for (int sft = 32; sft > 0; sft >>= 1) { const unsigned o = __shfl_xor(mloc, sft, 64); mloc = o > mloc ? o : mloc; }
     if (lane == 0 && mloc) atomicMax(&s_max[q & 1], mloc);
+    PH_MARK(2);
     __syncthreads(); // the chunk's maximum is complete
+    PH_MARK(3);
     const unsigned mbits = s_max[q & 1];
     if (tid == 0) s_max[(q + 1) & 1] = 0u; // its last readers passed the barrier at the top of this chunk
     if (mbits) {
@@ -260,33 +311,93 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         sx[(2 + ig) * HP + p] = pl;
       }
     }
+    }
+    PH_MARK(4);
+#ifdef SPLIT_EXP_NO_STAGE
+  taps:
+#endif
+#ifndef SPLIT_WEIGHTS_L2
+    // 27 taps in 9 groups of TG, ONE barrier per group: behind it the group's weight slices (DMA issued a group ago,
+    // awaited just before) and -- for the first group -- the chunk's operand planes are visible, and the buffer of the
+    // group before is free for the DMA of the next one.
 #pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      const int s = q * 27 + tap;
-      u4 *swb = sw + (s & 1) * WPL;
-      if (w_thread) swb[tid] = wreg;
-      __syncthreads(); // weight slice s (and, at tap 0, the planes) are in LDS; slice s-1's readers are past their MFMAs
-      if (s + 1 < nchunks * 27 && w_thread) wreg = wp[(size_t)(s + 1) * 4 * Cout + we_g];
-      if (wave_on) { // a wave whose voxels see no point only takes part in the staging and the barriers
+    for (int grp = 0; grp < 27 / TG; ++grp) {
+      const int sg = q * (27 / TG) + grp;
+      const u4 *swg = sw + (sg & 1) * TG * WPL;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PH_MARK(1);
+      __syncthreads();
+      PH_MARK(5);
+      if (sg + 1 < nchunks * (27 / TG)) weights_dma(sg + 1);
+      if (wave_on) {
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          const int tap = grp * TG + t;
+          const u4 *swb = swg + t * WPL;
+          const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+          u4 wf[CB][2], xf[VB][2];
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) wf[cb][pc] = swb[(pc * 2 + g) * COT + cb * 32 + l32];
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = sx[(pc * 2 + g) * HP + xbase[vb] + toff];
+          }
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) {
+              acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
+              cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
+              cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
+            }
+        }
+      }
+      PH_MARK(6);
+    }
+#else
+    // Experiment (-DSPLIT_WEIGHTS_L2), measured and REJECTED: the 27 taps without a barrier, every wave fetching its own
+    // A fragments straight from L2 into a register ring two taps ahead.  1411 us against 819 us for the LDS hand-off at
+    // 64->64 r=32 (the ring costs 48 registers on top of 128 accumulators: 190 spills inside the tap loop, and 4x the
+    // L2 reads of the same hot 4 KiB slices).
+    __syncthreads(); // the chunk's planes are complete
+    PH_MARK(5);
+    if (wave_on) {
+      const u4 *wq = wp + (size_t)q * 27 * 4 * Cout + co0 + l32; // tap t, piece pc, block cb: wq[(t*4 + pc*2 + g)*Cout + cb*32]
+      u4 wring[3][CB][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) wring[t][cb][pc] = wq[(size_t)(t * 4 + pc * 2 + g) * Cout + cb * 32];
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        if (tap + 2 < 27) {
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+              wring[(tap + 2) % 3][cb][pc] = wq[(size_t)((tap + 2) * 4 + pc * 2 + g) * Cout + cb * 32];
+        }
         const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
-        u4 wf[CB][2], xf[VB][2];
+        u4 xf[VB][2];
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb) wf[cb][pc] = swb[(pc * 2 + g) * COT + cb * 32 + l32];
+        for (int pc = 0; pc < 2; ++pc)
 #pragma unroll
           for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = sx[(pc * 2 + g) * HP + xbase[vb] + toff];
-        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
           for (int vb = 0; vb < VB; ++vb) {
-            acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
-            cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
-            cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
+            acc[cb][vb] = mma(wring[tap % 3][cb][0], xf[vb][0], acc[cb][vb]);
+            cor[cb][vb] = mma(wring[tap % 3][cb][0], xf[vb][1], cor[cb][vb]);
+            cor[cb][vb] = mma(wring[tap % 3][cb][1], xf[vb][0], cor[cb][vb]);
           }
       }
     }
+    PH_MARK(6);
+#endif
   }
 
   if (delta) {
@@ -316,7 +427,14 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
         const float o = ((acc[cb][vb][i] + cor[cb][vb][i] * (1.f / 2048.f)) * us_x) * us_w + addv[co];
         acc[cb][vb][i] = o;
+#ifdef SPLIT_EXP_NO_STORE
+        if (o == 1.2345e30f)
+#endif
+#ifdef SPLIT_Y_NT
+        __builtin_nontemporal_store(o, &yb[(size_t)co * r3 + gv]);
+#else
         yb[(size_t)co * r3 + gv] = o;
+#endif
       }
   }
   if (STATS) { // per-tile channel sums, as csrc/conv3d.hip
@@ -345,7 +463,12 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       o[1] = s2;
     }
   }
+  PH_MARK(7);
   } // work loop
+#ifdef SPLIT_EXP_TIMING
+  if (tid == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_split_phase[k], (unsigned long long)ph_acc[k]);
+#endif
 }
 
 template <int TD, int TH, int TW, int CB, int VB, int OCC>
@@ -367,7 +490,7 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
   const long items = (long)B * tiles * (Cout / COT);
   const long resident = (long)OCC * cu_count[dev];
   const dim3 grid = occ ? dim3((unsigned)(items < resident ? items : resident)) : dim3(B, tiles, Cout / COT);
-  const size_t LDS = (size_t)(4 * HP + 2 * 4 * COT) * 16 +
+  const size_t LDS = (size_t)(4 * HP + 2 * 3 * 4 * COT) * 16 + // planes + two groups of 3 taps of weight slices
                      (size_t)(COT + (pa ? 3 * ((Cin + 63) & ~63) : 0) + 4 * COT * 2) * 4;
 #define LION_SPLIT_GO(PRO_, ST_)                                                                             \
   {                                                                                                          \
@@ -385,16 +508,291 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
   return 0;
 }
 
+// ---- r = 8: the pipelined form -------------------------------------------------------------------------------------
+// A sample has only 512 voxels, so B * Cout / 32 half-sample tiles (256 voxels x 32 channels) are all the work there is:
+// ONE workgroup per CU at B = 32, Cout = 128, nothing else resident to hide its latencies behind.  The tile therefore
+// pipelines itself:
+//   * operand planes double buffered: the global loads of chunk q+1 are issued in front of the 27 taps of chunk q and
+//     land in registers while the MFMAs run; they are activated, scaled, cut and written to the other plane buffer
+//     behind the taps (one barrier for the chunk maximum);
+//   * weight slices by LDS-DMA in groups of 9 taps (one kd plane: 18 KiB), ring of three groups, issued TWO groups
+//     (108 MFMAs per wave) ahead; waited for with a counted s_waitcnt (memory operations retire in order; the counts
+//     below are the operations this wave is known to have issued behind the awaited DMA -- at least DMA_MIN weight
+//     instructions per group and the NI*8 operand loads -- so they can only be too strict, never too lax);
+//   * fragments of tap t+1 are read from LDS in front of the MFMAs of tap t.
+// Voxel -> lane: a column block of 32 voxels is 8 w x {h, h+4, h+1, h+5}: 16 consecutive lanes read two halo rows whose
+// 16-byte slots differ by 40 = 8 (mod 16) -- conflict-free ds_read_b128 with the 10-wide halo rows of an 8-wide tile.
+// Dense only (the sparse plan starts at r = 16), prologue and statistics as conv3d_split_kernel, no delta mode.
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool PRO, bool STATS>
+__global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
+                                                                  const float *__restrict__ wtail,
+                                                                  const float *__restrict__ bias, float *__restrict__ y,
+                                                                  int Cin, int Cout, const float *__restrict__ pro_a,
+                                                                  const float *__restrict__ pro_b,
+                                                                  float *__restrict__ stats) {
+  constexpr int r = 8, r3 = 512, TD = 4, TH = 8, TW = 8, VB = 2, COT = 32, TM = 256;
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW; // 600
+  constexpr int HP = (HALO + 63) / 64 * 64;                                 // 640
+  constexpr int NI = 2 * HP / TM;                                           // 5 staging items per thread
+  static_assert(2 * HP % TM == 0, "whole staging rounds");
+  constexpr int WPL = 4 * COT, TG = 9, NG = 27 / TG;                        // 128 u4 per tap slice; groups of 9 taps
+  constexpr int DMA_PER_GROUP = TG * WPL / 64, DMA_MIN = DMA_PER_GROUP / 4; // 18 wave instructions over 4 waves
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u4 *sx = reinterpret_cast<u4 *>(smem);      // [2][piece][half][HP]
+  u4 *sw = sx + 2 * 4 * HP;                   // [3][TG][piece][half][COT]
+  float *sbias = reinterpret_cast<float *>(sw + 3 * TG * WPL);
+  const int npro = PRO ? ((Cin + 63) & ~63) : 0;
+  float *spa = sbias + COT, *spb = spa + npro;
+  float *sred = spb + npro;                   // [4][COT][2]
+  __shared__ unsigned s_max[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, l32 = lane & 31;
+  const int b = blockIdx.x, tile = blockIdx.y, co0 = blockIdx.z * COT, d0 = tile * TD;
+  const float wscale_inv = wtail[2];
+  if (PRO)
+    for (int c = tid; c < Cin; c += TM) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
+  if (tid < COT) sbias[tid] = bias ? bias[co0 + tid] : 0.f;
+  if (tid < 2) s_max[tid] = 0u;
+  int E = 127;
+#ifdef SPLIT_EXP_TIMING
+  unsigned long long t_ph = __builtin_readcyclecounter();
+  unsigned ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+  int goff[NI];
+  bool gok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int p = (tid + TM * i) % HP;
+    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+    const int gd = d0 - 1 + hd, gh = hh - 1, gw = hw - 1;
+    gok[i] = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+    goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
+  // this lane's voxel in column block vbk = wave * VB + vb: d = vbk / 2, w = l % 8, h = 2 (vbk % 2) + {0, 4, 1, 5}[l / 8]
+  int xbase[VB], vox[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    const int vbk = wave * VB + vb;
+    const int d = vbk >> 1, w = l32 & 7, h = (vbk & 1) * 2 + ((l32 >> 4) & 1) + 4 * ((l32 >> 3) & 1);
+    xbase[vb] = (d * HH + h) * HW + w;
+    vox[vb] = ((d0 + d) * r + h) * r + w;
+  }
+  f32x16 acc[VB], cor[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[vb][i] = cor[vb][i] = 0.f;
+
+  const int nchunks = Cin / KS, ngroups = nchunks * NG;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const uint32_t sw_lds = (uint32_t)(uintptr_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw);
+  auto weights_dma = [&](int sg) { // group sg (chunk sg / 3, taps 9 (sg % 3) ..) -> ring slot sg % 3
+    const u4 *src = wp + (size_t)sg * TG * 4 * Cout + co0;
+    const uint32_t dst0 = sw_lds + (uint32_t)((sg % 3) * TG * WPL * 16);
+    for (int i = wave; i < DMA_PER_GROUP; i += 4) { // instruction i: tap i / 2, planes 2 (i % 2) + {0, 1}, 32 channels each
+      const u4 *gp = src + (size_t)((i >> 1) * 4 + (i & 1) * 2 + g) * Cout + l32;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(i * 1024));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+    }
+  };
+  float v[NI][8];
+  auto issue_loads = [&](int q) { // all 40 operand loads of a chunk, unconditionally (outside the grid: offset past the end -> 0)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int ig = __builtin_amdgcn_readfirstlane((tid + TM * i) / HP);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, goff[i], (q * KS + ig * 8 + j) * r3 * 4, 0));
+    }
+  };
+  auto stage = [&](int q) { // registers -> activated, scaled, cut -> plane buffer q & 1 (contains the chunk-maximum barrier)
+    unsigned mloc = 0u;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int ig = __builtin_amdgcn_readfirstlane((tid + TM * i) / HP);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = v[i][j];
+        if (PRO) {
+          const int c = q * KS + ig * 8 + j;
+          t = gok[i] ? pro_act(t, spa[c], spb[c]) : 0.f;
+          v[i][j] = t;
+        }
+        const unsigned a = __float_as_uint(t) & 0x7fffffffu;
+        mloc = (a > mloc && a <= 0x7f7fffffu) ? a : mloc;
+      }
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) { const unsigned o = __shfl_xor(mloc, sft, 64); mloc = o > mloc ? o : mloc; }
+    if (lane == 0 && mloc) atomicMax(&s_max[q & 1], mloc);
+    __syncthreads(); // the chunk's maximum is complete
+    const unsigned mbits = s_max[q & 1];
+    if (tid == 0) s_max[(q + 1) & 1] = 0u; // last read behind the previous chunk's maximum barrier
+    if (mbits) {
+      const int e = scale_exp(__uint_as_float(mbits));
+      if (e < E) {
+        if (E != 127) {
+          const float f = pow2f(max(e - E, -126));
+#pragma unroll
+          for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[vb][i] *= f; cor[vb][i] *= f; }
+        }
+        E = e;
+      }
+    }
+    const float xs = E == 127 ? 1.0f : pow2f(E);
+    u4 *dstp = sx + (q & 1) * 4 * HP;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = tid + TM * i;
+      const int ig = __builtin_amdgcn_readfirstlane(item / HP), p = item - ig * HP;
+      unsigned short hi[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cut(v[i][j] * xs, hi[j], lo[j]);
+      u4 ph, pl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ph[k] = (unsigned)hi[2 * k] | ((unsigned)hi[2 * k + 1] << 16);
+        pl[k] = (unsigned)lo[2 * k] | ((unsigned)lo[2 * k + 1] << 16);
+      }
+      dstp[(0 + ig) * HP + p] = ph;
+      dstp[(2 + ig) * HP + p] = pl;
+    }
+  };
+
+  weights_dma(0);
+  if (ngroups > 1) weights_dma(1);
+  issue_loads(0);
+  __syncthreads(); // prologue scalars, s_max = 0
+  stage(0);
+  PH_MARK(0);
+  for (int q = 0; q < nchunks; ++q) {
+    const u4 *sxq = sx + (q & 1) * 4 * HP;
+    const bool more = q + 1 < nchunks;
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      const int sg = q * NG + grp;
+      // group sg's slices must have landed.  Issued behind them by this wave, in order: [grp 0] the DMA of group sg + 1;
+      // [grp 1, 2] the DMA of group sg + 1 and this chunk's operand prefetch (when there is a next chunk)
+      const bool dma_behind = sg + 1 < ngroups;
+      if (grp == 0 || !more) { if (dma_behind) wait_vm<DMA_MIN>(); else wait_vm<0>(); }
+      else { if (dma_behind) wait_vm<DMA_MIN + NI * 8>(); else wait_vm<NI * 8>(); }
+      PH_MARK(1);
+      __syncthreads(); // slices of group sg and (grp 0) the planes of chunk q visible; ring slot of group sg - 1 free
+      PH_MARK(5);
+      if (sg + 2 < ngroups) weights_dma(sg + 2);
+      if (grp == 0 && more) issue_loads(q + 1);
+      const u4 *swg = sw + (sg % 3) * TG * WPL;
+      u4 wf[2][2], xf[2][VB][2];
+      auto frags = [&](int t, int s_) {
+        const int tap = grp * TG + t;
+        const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          wf[s_][pc] = swg[t * WPL + (pc * 2 + g) * COT + l32];
+#pragma unroll
+          for (int vb = 0; vb < VB; ++vb) xf[s_][vb][pc] = sxq[(pc * 2 + g) * HP + xbase[vb] + toff];
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        if (t + 1 < TG) frags(t + 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0); // keep the reads of tap t + 1 in front of the MFMAs of tap t (one wave per SIMD:
+#pragma unroll                             // nothing else hides the LDS latency)
+        for (int vb = 0; vb < VB; ++vb) {
+          acc[vb] = mma(wf[t & 1][0], xf[t & 1][vb][0], acc[vb]);
+          cor[vb] = mma(wf[t & 1][0], xf[t & 1][vb][1], cor[vb]);
+          cor[vb] = mma(wf[t & 1][1], xf[t & 1][vb][0], cor[vb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      PH_MARK(6);
+    }
+    if (more) stage(q + 1); // plane buffer (q + 1) & 1: last read by the taps of chunk q - 1, two barriers ago
+    PH_MARK(4);
+  }
+
+  float *yb = y + ((size_t)b * Cout + co0) * r3;
+  const float us_x = E == 127 ? 1.0f : pow2f(-E), us_w = wscale_inv;
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = (i & 3) + 8 * (i >> 2) + 4 * g;
+      const float o = ((acc[vb][i] + cor[vb][i] * (1.f / 2048.f)) * us_x) * us_w + sbias[co];
+      acc[vb][i] = o;
+      yb[(size_t)co * r3 + vox[vb]] = o;
+    }
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s1 = acc[0][i], s2 = acc[0][i] * acc[0][i];
+#pragma unroll
+      for (int vb = 1; vb < VB; ++vb) { s1 += acc[vb][i]; s2 += acc[vb][i] * acc[vb][i]; }
+      s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      if (l32 == 0) {
+        const int co = (i & 3) + 8 * (i >> 2) + 4 * g;
+        sred[(wave * COT + co) * 2] = s1;
+        sred[(wave * COT + co) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < COT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
+      float *o = stats + (((size_t)b * Cout + co0 + tid) * (r / TD) + tile) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+  PH_MARK(7);
+#ifdef SPLIT_EXP_TIMING
+  if (tid == 0)
+    for (int kk = 0; kk < 8; ++kk) atomicAdd(&g_split_phase[kk], (unsigned long long)ph_acc[kk]);
+#endif
+}
+
+static int launch_split_pipe(const float *x, const u4 *wp, const float *wtail, const float *bias, float *y, int B, int Cin,
+                             int Cout, const float *pa, const float *pb, float *stats, hipStream_t st) {
+  constexpr int HP = 640, COT = 32;
+  const dim3 grid(B, 2, Cout / COT);
+  const size_t LDS = (size_t)(2 * 4 * HP + 3 * 9 * 4 * COT) * 16 +
+                     (size_t)(COT + (pa ? 2 * ((Cin + 63) & ~63) : 0) + 4 * COT * 2) * 4;
+#define LION_PIPE_GO(PRO_, ST_)                                                                              \
+  {                                                                                                          \
+    static LionLdsLimit cfg = {};                                                                            \
+    if (int e = lion_dynamic_lds(&conv3d_split_pipe_kernel<PRO_, ST_>, LDS, cfg)) return e;                  \
+    conv3d_split_pipe_kernel<PRO_, ST_><<<grid, 256, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, pa, pb, stats); \
+  }
+  if (pa && stats) LION_PIPE_GO(true, true)
+  else if (pa) LION_PIPE_GO(true, false)
+  else if (stats) LION_PIPE_GO(false, true)
+  else LION_PIPE_GO(false, false)
+#undef LION_PIPE_GO
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
 // tiles: always the 4 waves x 2 column blocks geometry of the product's sparse plan (so that the occupancy lists of
 // lion_conv3d_tile_occupancy apply unchanged), one column block per wave at r = 8
 struct SplitPlan { int vb, cb, tiles; };
 static SplitPlan split_plan(int r, int Cout) {
   const int r3 = r * r * r;
   const int cb = Cout % 64 == 0 ? 2 : Cout % 32 == 0 ? 1 : 0;
-  // r = 8: a workgroup takes a WHOLE sample (512 voxels = 4 waves x 4 column blocks) x 32 output channels: the halo is
-  // only the zero padding, the weight slices are read once per sample instead of once per 128-voxel tile (measured
-  // with 128-voxel tiles: 144 us at 128->128, B=32, slower than the fp32 kernel's 114 us)
-  if (r == 8) return {4, cb ? 1 : 0, 1};
+  // r = 8: the pipelined half-sample kernel (conv3d_split_pipe_kernel): 2 tiles of 256 voxels, 32 channels per workgroup
+  // (history: 128-voxel tiles 144 us, whole-sample tiles x 32 channels on B * Cout/32 = 128 workgroups 104-108 us at
+  // 128->128, B=32, against 114 us of the fp32 kernel)
+  if (r == 8) return {2, Cout % 32 == 0 ? 1 : 0, 2};
   return {2, cb, r3 / 256};
 }
 
@@ -421,6 +819,14 @@ int lion_conv3d_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *
   return 0;
 }
 
+#ifdef SPLIT_EXP_TIMING
+int lion_debug_split_phases(unsigned long long *host8, int reset) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_split_phase), 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_phase), z, 64) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+
 int lion_conv3d_split_stat_tiles(int r, int Cout) {
   if (r != 8 && r != 16 && r != 32) return 0;
   return split_plan(r, Cout).tiles;
@@ -444,6 +850,10 @@ int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float
   hipStream_t st = static_cast<hipStream_t>(stream);
   const u4 *w4 = reinterpret_cast<const u4 *>(wp);
   const float *wtail = reinterpret_cast<const float *>(wp + split_piece_halfs(Cout, Cin));
+  if (r == 8) {
+    if (tconst) return LION_EUNSUPPORTED;
+    return launch_split_pipe(x, w4, wtail, bias, y, B, Cin, Cout, pro_a, pro_b, stats, st);
+  }
 #define LION_SPLIT_TILE(R_, VB_, CB_, TD_, TH_, TW_, OCC_)                                                  \
   if (r == R_ && p.vb == VB_ && p.cb == CB_)                                                                \
     return launch_split_t<TD_, TH_, TW_, CB_, VB_, OCC_>(x, w4, wtail, bias, y, B, Cin, Cout, r, pro_a, pro_b, pro_bias, tconst, \
@@ -452,7 +862,6 @@ int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float
   LION_SPLIT_TILE(32, 2, 1, 2, 4, 32, 2)
   LION_SPLIT_TILE(16, 2, 2, 4, 4, 16, 2)
   LION_SPLIT_TILE(16, 2, 1, 4, 4, 16, 2)
-  LION_SPLIT_TILE(8, 4, 1, 8, 8, 8, 1) // B * Cout/32 workgroups <= one per CU: all 512 registers, no spills
 #undef LION_SPLIT_TILE
   return LION_EUNSUPPORTED;
 }

@@ -86,6 +86,34 @@ def main():
             cf = torch.randn(B, C, M, device="cuda", generator=g)
             nbytes = 4 * B * (C * M + 6 * N + C * N)
             rec("three_nn_interpolate(K11+12)", (C, N, M), timeit(lambda: bk.three_nearest_neighbors_interpolate_forward(pts, ctr, cf), args.iters), nbytes)
+    if want("bwd"):
+        # the backward operators of the training path (K3, K5, K8, K12-grad) at the largest shapes of a forward;
+        # algorithmic bytes: gradient in + indices / weights + dense gradient out, each once
+        C, N, r = 64, 2048, 32
+        co = torch.randn(B, 3, N, device="cuda", generator=g)
+        feat = torch.randn(B, C, N, device="cuda", generator=g)
+        _, nc, ind, cnt = bk.voxelize_points_forward(feat, co, r, True, 0.0)
+        gy = torch.randn(B, C, r ** 3, device="cuda", generator=g)
+        rec("avg_voxelize_backward(K3)", (C, N, r), timeit(lambda: bk.avg_voxelize_backward(gy, ind, cnt), args.iters),
+            4 * B * (C * min(r ** 3, N) + N + r ** 3 + C * N))
+        grid = torch.randn(B, C, r ** 3, device="cuda", generator=g)
+        _, inds, wgts = bk.trilinear_devoxelize_forward(r, True, nc, grid)
+        gyp = torch.randn(B, C, N, device="cuda", generator=g)
+        rec("trilinear_devoxelize_backward(K5)", (C, N, r), timeit(lambda: bk.trilinear_devoxelize_backward(gyp, inds, wgts, r), args.iters),
+            4 * B * (C * N + 16 * N + C * r ** 3))
+        Cg, Ng, Mg = 35, 2048, 1024
+        idx = torch.randint(0, Ng, (B, Mg, 32), device="cuda", dtype=torch.int32)
+        gyg = torch.randn(B, Cg, Mg, 32, device="cuda", generator=g)
+        rec("grouping_backward(K8)", (Cg, Ng, Mg), timeit(lambda: bk.grouping_backward(gyg, idx, Ng), args.iters),
+            4 * B * (Cg * Mg * 32 + Mg * 32 + Cg * Ng))
+        Ci, Ni, Mi = 192, 2048, 1024
+        pts = torch.randn(B, 3, Ni, device="cuda", generator=g)
+        ctr = pts[:, :, :Mi].contiguous()
+        cf = torch.randn(B, Ci, Mi, device="cuda", generator=g)
+        _, ii, iw = bk.three_nearest_neighbors_interpolate_forward(pts, ctr, cf)
+        gyi = torch.randn(B, Ci, Ni, device="cuda", generator=g)
+        rec("three_nn_interpolate_backward(K12g)", (Ci, Ni, Mi), timeit(lambda: bk.three_nearest_neighbors_interpolate_backward(gyi, ii, iw, Mi), args.iters),
+            4 * B * (Ci * Ni + 6 * Ni + Ci * Mi))
     if want("cd"):
         from lion_amd.chamfer3d import chamfer_3DDist_nograd
         from lion_amd.emd import earth_mover_distance_nograd

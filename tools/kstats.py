@@ -1,7 +1,8 @@
 """Compact per-kernel table from a rocprofv3 --kernel-trace CSV directory.
-usage: kstats.py DIR [top_n] [--between-markers [MARKER]] [--per N]
+usage: kstats.py DIR [top_n] [--between-markers [MARKER]] [--per N] [--by-grid]
 --between-markers keeps only kernels launched between the first and last launch of MARKER (default
-chamfer_fwd_kernel); --per N divides totals by N (e.g. steps) to print per-step microseconds."""
+chamfer_fwd_kernel); --per N divides totals by N (e.g. steps) to print per-step microseconds; --by-grid keeps
+launches of one kernel with different grids apart (the grid, in workgroups, is appended to the name)."""
 import csv, glob, re, sys
 from collections import defaultdict
 
@@ -23,7 +24,11 @@ if marker:
     rows = [r for r in rows if lo < int(r["Start_Timestamp"]) < hi]
 agg = defaultdict(lambda: [0, 0.0])
 for r in rows:
-    k = short(r["Kernel_Name"]); dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    k = short(r["Kernel_Name"])
+    if "--by-grid" in sys.argv:
+        g = [int(r.get("Grid_Size_" + a, 0) or 0) // max(int(r.get("Workgroup_Size_" + a, 1) or 1), 1) for a in "XYZ"]
+        k = k[:44] + " [%d,%d,%d]" % tuple(g)
+    dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg[k][0] += 1; agg[k][1] += dur
 tot = sum(v[1] for v in agg.values())
 span = (max(int(r["End_Timestamp"]) for r in rows) - min(int(r["Start_Timestamp"]) for r in rows)) / 1e3 if rows else 0
