@@ -270,6 +270,16 @@ int lion_pwconv_pack_weights(const float *w, int Cout, int Cin, float *wp, lionS
 int lion_pwconv_stat_tiles(int Cout, int Cin, int L);
 int lion_pwconv_forward(const float *x, const float *wp, const float *bias, int B, int Cin, int Cout, int L,
                         const float *pro_a, const float *pro_b, float *y, float *stats, lionStream_t stream);
+/* G1 on the 16-bit matrix pipe at fp32 accuracy (csrc/pwconv_split.hip): same contract as lion_pwconv_forward with both
+ * operands cut into fp16 hi / lo pieces (power-of-two block scaling per tensor for w, per column and 16-channel chunk for
+ * the activation, fp32 accumulation; error within that of the fp32 MFMA chain).  w f32[Cout,Cin] -> wp once per weight
+ * (lion_pwconv_split_packed_halfs uint16, 16-byte aligned); stats f32[B,Cout,lion_pwconv_split_stat_tiles(Cout,Cin,L),2].
+ * Any Cout, Cin, L with Cin * L < 2^29. */
+size_t lion_pwconv_split_packed_halfs(int Cout, int Cin);
+int lion_pwconv_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *wp, lionStream_t stream);
+int lion_pwconv_split_stat_tiles(int Cout, int Cin, int L);
+int lion_pwconv_split_forward(const float *x, const uint16_t *wp, const float *bias, int B, int Cin, int Cout, int L,
+                              const float *pro_a, const float *pro_b, float *y, float *stats, lionStream_t stream);
 /* ---- P5: LinearAttention (models/pvcnn2_ada.py:43-71) between its two 1x1 convolutions ---------------------
  * qkv f32[B, 3*H*D, N] (to_qkv's output, channel order (qkv, head, d)) -> out f32[B, H*D, N] (to_out's input):
  * softmax over the N points of every k row, ctx = softmax(k) v^T (D x D), out = ctx^T q.  D = 32 (every

@@ -10,6 +10,7 @@ from ._wcache import WeightCache
 #   True  -> fp16 x 2 split operands on the 16-bit MFMA pipe where the shape allows (Cin % 16 == 0), fp32 MFMA elsewhere
 #   False -> the exact-fp32 MFMA kernel everywhere (csrc/conv3d.hip)
 SPLIT = os.environ.get("LION_CONV_SPLIT", "1") != "0"
+SPLIT_MIN_R = int(os.environ.get("LION_CONV_SPLIT_MIN_R", "8"))   # A/B switch: 16 keeps the r = 8 layers on the fp32 kernel
 
 
 def supported(cin, cout, r):
@@ -24,7 +25,7 @@ def split_supported(cin, cout, r):
 def split_preferred(cin, cout, r):
     """where it is the faster kernel (tools/conv_split_bench.py, B=32): 2.2x at 64->64 r=32, 2.5x at 128->128 r=16,
     1.5x at 32->32 r=32, 2.1x at r=8 (the pipelined half-sample kernel) -- everywhere it can run."""
-    return split_supported(cin, cout, r)
+    return split_supported(cin, cout, r) and r >= SPLIT_MIN_R
 
 
 def use_split(split, cin, cout, r):

@@ -7,9 +7,9 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
 OBJS=()
 PIDS=()
-for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise pwconv skinny attention "$@"; do
+for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise pwconv pwconv_split skinny attention "$@"; do
   [ -f "$f.hip" ] || continue
-  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ split_ops.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
     rm -f "$f.o"   # a failed compile must not leave the previous object behind to be linked silently
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
     PIDS+=($!)

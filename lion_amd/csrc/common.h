@@ -72,6 +72,27 @@ __device__ __forceinline__ float row16_sum_rn(float v) { // exact same tree as v
   v = __fadd_rn(v, LION_DPP_F32(v, 0x140)); // row_mirror
   return v;
 }
+// max over the 64 lanes of a wave, valid in LANE 63 only: DPP butterflies inside the 16-lane rows, then the classic
+// row_bcast:15 (lane 15 of a row -> the next row, rows 1 and 3) and row_bcast:31 (lane 31 -> rows 2 and 3) steps -- no
+// LDS crossbar (__shfl_xor = ds_bpermute: 6 round trips per reduction).
+__device__ __forceinline__ unsigned wave_max_u32_lane63(unsigned v) {
+#define LION_DPP_U32(x, ctrl, rmask) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rmask), 0xf, true))
+  unsigned o;
+  o = LION_DPP_U32(v, 0xB1, 0xf); v = o > v ? o : v;
+  o = LION_DPP_U32(v, 0x4E, 0xf); v = o > v ? o : v;
+  o = LION_DPP_U32(v, 0x141, 0xf); v = o > v ? o : v;
+  o = LION_DPP_U32(v, 0x140, 0xf); v = o > v ? o : v;
+  o = LION_DPP_U32(v, 0x142, 0xa); v = o > v ? o : v; // row_bcast:15 into rows 1, 3 (disabled rows read 0: a no-op for max)
+  o = LION_DPP_U32(v, 0x143, 0xc); v = o > v ? o : v; // row_bcast:31 into rows 2, 3
+#undef LION_DPP_U32
+  return v;
+}
+// v + (the value of the other 16-lane row of the same 32-lane half), valid in the ODD rows only (lanes 16-31, 48-63):
+// row_bcast:15 hands lane 15 of rows 0 / 2 -- after row16_sum_rn every lane of a row holds the row's sum -- to rows
+// 1 / 3.  Same two addends as v += __shfl_xor(v, 16) (addition commutes), without the LDS round trip.
+__device__ __forceinline__ float row_pair_sum_odd_rows(float v) {
+  return __fadd_rn(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true)));
+}
 __device__ __forceinline__ float row16_max(float v) {
   float o;
   o = LION_DPP_F32(v, 0xB1); v = o > v ? o : v;

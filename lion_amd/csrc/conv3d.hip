@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
 #pragma unroll
         for (int vb = 1; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
         s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2); // 16-lane rows on DPP, then the two rows of the half-wave
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        if ((lane & 31) == 0) {
+        s1 = row_pair_sum_odd_rows(s1); s2 = row_pair_sum_odd_rows(s2);
+        if ((lane & 31) == 16) { // the row pair's sum lives in the odd rows
           const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
           sred[(wave * COT + co) * 2] = s1;
           sred[(wave * COT + co) * 2 + 1] = s2;

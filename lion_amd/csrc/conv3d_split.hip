@@ -28,52 +28,12 @@
 // group: 9 per chunk).
 // History: tools/exp/split_*.hip (inner product 400 TF fp32-equivalent; whole layer 779 us vs 1973 us of the fp32
 // kernel with statistics at B=32, 64->64, r=32).
-#include "common.h"
+#include "split_ops.h"
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-constexpr int KS = 16; // input channels per chunk = K of one MFMA
-
-__device__ __forceinline__ float pro_act(float v, float pa, float pb) { // == csrc/conv3d.hip
-  const float t = v * pa + pb;
-  return t * __frcp_rn(1.0f + __expf(-t));
-}
-// exponent e with 2^13 <= m * 2^e < 2^14 for a finite m > 0 (from the float's exponent field; subnormal m -> +100)
-__device__ __forceinline__ int scale_exp(float m) {
-  const int ex = (int)((__float_as_uint(m) >> 23) & 0xff) - 127; // floor(log2 m) for normal m; 128 for inf / nan
-  const int e = 13 - ex;
-  return e > 100 ? 100 : e;
-}
-__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); } // -126 <= e <= 127
-__device__ __forceinline__ void cut(float v, unsigned short &hi, unsigned short &lo) {
-  const _Float16 h = (_Float16)v;
-  const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
-  hi = __builtin_bit_cast(unsigned short, h);
-  lo = __builtin_bit_cast(unsigned short, l);
-}
-__device__ __forceinline__ f32x16 mma(u4 a, u4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-}
-
 // w f32[Cout][Cin][27] -> wp u16[Cin/16][27][piece][k-half][Cout][8]   (ci = chunk*16 + half*8 + j)
-// pass 1: max |w| (as bits: non-negative floats order like unsigned integers) into tail[0]; pass 2 cuts w * 2^ew.
-// tail = the 4 words behind the packed pieces: {max bits, ew (int), 2^-ew (float), 0}
-__global__ void split_wmax_kernel(const float *__restrict__ w, int n, unsigned *__restrict__ tail) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned m = i < n ? (__float_as_uint(w[i]) & 0x7fffffffu) : 0u;
-  for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(tail, m);
-}
-__global__ void split_wscale_kernel(unsigned *__restrict__ tail) {
-  const float m = __uint_as_float(tail[0]);
-  const int ew = m > 0.f ? scale_exp(m) : 0;
-  tail[1] = (unsigned)ew;
-  tail[2] = __float_as_uint(pow2f(-ew));
-  tail[3] = 0u;
-}
+// pack: cuts w * 2^ew (split_ops.h: split_wmax_kernel / split_wscale_kernel fill the tail first).
 __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin, unsigned short *__restrict__ wp,
                                   const unsigned *__restrict__ tail) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,8 +230,8 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         mloc = (item < 2 * HP && a > mloc && a <= 0x7f7fffffu) ? a : mloc; // they pass through the cut as inf / nan
       }
     }
-    for (int sft = 32; sft > 0; sft >>= 1) { const unsigned o = __shfl_xor(mloc, sft, 64); mloc = o > mloc ? o : mloc; }
-    if (lane == 0 && mloc) atomicMax(&s_max[q & 1], mloc);
+    mloc = wave_max_u32_lane63(mloc);
+    if (lane == 63 && mloc) atomicMax(&s_max[q & 1], mloc);
     PH_MARK(2);
     __syncthreads(); // the chunk's maximum is complete
     PH_MARK(3);
@@ -281,7 +241,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       const int e = scale_exp(__uint_as_float(mbits));
       if (e < E) { // the tile's maximum grew: bring what has been accumulated onto the new (smaller) scale first
         if (E != 127) {
-          const float f = pow2f(max(e - E, -126));
+          const float f = pow2f(max(e - SPLIT_HEADROOM - E, -126));
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -289,7 +249,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
               for (int i = 0; i < 16; ++i) { acc[cb][vb][i] *= f; cor[cb][vb][i] *= f; }
         }
-        E = e;
+        E = e - SPLIT_HEADROOM;
       }
     }
     const float xs = E == 127 ? 1.0f : pow2f(E);
@@ -446,8 +406,8 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
         for (int vb = 1; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
         s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        if (l32 == 0) {
+        s1 = row_pair_sum_odd_rows(s1); s2 = row_pair_sum_odd_rows(s2);
+        if (l32 == 16) { // the row pair's sum lives in the odd rows
           const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
           sred[(wave * COT + co) * 2] = s1;
           sred[(wave * COT + co) * 2 + 1] = s2;
@@ -523,8 +483,6 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
 // Voxel -> lane: a column block of 32 voxels is 8 w x {h, h+4, h+1, h+5}: 16 consecutive lanes read two halo rows whose
 // 16-byte slots differ by 40 = 8 (mod 16) -- conflict-free ds_read_b128 with the 10-wide halo rows of an 8-wide tile.
 // Dense only (the sparse plan starts at r = 16), prologue and statistics as conv3d_split_kernel, no delta mode.
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 template <bool PRO, bool STATS>
 __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
                                                                   const float *__restrict__ wtail,
@@ -629,8 +587,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
         mloc = (a > mloc && a <= 0x7f7fffffu) ? a : mloc;
       }
     }
-    for (int sft = 32; sft > 0; sft >>= 1) { const unsigned o = __shfl_xor(mloc, sft, 64); mloc = o > mloc ? o : mloc; }
-    if (lane == 0 && mloc) atomicMax(&s_max[q & 1], mloc);
+    mloc = wave_max_u32_lane63(mloc);
+    if (lane == 63 && mloc) atomicMax(&s_max[q & 1], mloc);
     __syncthreads(); // the chunk's maximum is complete
     const unsigned mbits = s_max[q & 1];
     if (tid == 0) s_max[(q + 1) & 1] = 0u; // last read behind the previous chunk's maximum barrier
@@ -638,13 +596,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
       const int e = scale_exp(__uint_as_float(mbits));
       if (e < E) {
         if (E != 127) {
-          const float f = pow2f(max(e - E, -126));
+          const float f = pow2f(max(e - SPLIT_HEADROOM - E, -126));
 #pragma unroll
           for (int vb = 0; vb < VB; ++vb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc[vb][i] *= f; cor[vb][i] *= f; }
         }
-        E = e;
+        E = e - SPLIT_HEADROOM;
       }
     }
     const float xs = E == 127 ? 1.0f : pow2f(E);
@@ -738,8 +696,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
 #pragma unroll
       for (int vb = 1; vb < VB; ++vb) { s1 += acc[vb][i]; s2 += acc[vb][i] * acc[vb][i]; }
       s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
-      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-      if (l32 == 0) {
+      s1 = row_pair_sum_odd_rows(s1); s2 = row_pair_sum_odd_rows(s2);
+      if (l32 == 16) { // the row pair's sum lives in the odd rows
         const int co = (i & 3) + 8 * (i >> 2) + 4 * g;
         sred[(wave * COT + co) * 2] = s1;
         sred[(wave * COT + co) * 2 + 1] = s2;

@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
   float *spa = sw + (WLDS ? 2 * ksteps * COUT : 0); // [Cin] prologue scale   (PRO)
   float *spb = spa + (PRO ? Cin : 0);     // [Cin] prologue shift   (PRO)
   float *sred = spb + (PRO ? Cin : 0);    // [4][COUT][2]           (STATS)
+  float *sbias = sred + 4 * COUT * 2;     // [COUT] bias of this channel tile, zero beyond CoutY (read from global in the
+                                          // epilogue, every load would sit in front of a store's vmcnt wait)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, co0 = blockIdx.y * COUT, cl = lane & 31, kh = lane >> 5;
   if (WLDS) {
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
   if (PRO) {
     for (int c = tid; c < Cin; c += 256) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
   }
+  for (int c = tid; c < COUT; c += 256) sbias[c] = (bias && co0 + c < CoutY) ? bias[co0 + c] : 0.f;
   __syncthreads();
   const int col0 = (blockIdx.x * 4 + wave) * VB * 32;
   int col[VB];
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
     for (int i = 0; i < 16; ++i) {
       const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
       const bool rok = co0 + co < CoutY; // padded channel rows (CoutY % 32 != 0) are computed on zeros and dropped
-      const float bz = (bias && rok) ? bias[co0 + co] : 0.f;
+      const float bz = sbias[co];
 #pragma unroll
       for (int vb = 0; vb < VB; ++vb) {
         const float o = acc[cb][vb][i] + bz;
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
 #pragma unroll
         for (int vb = 0; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
         s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        if (cl == 0) {
+        s1 = row_pair_sum_odd_rows(s1); s2 = row_pair_sum_odd_rows(s2);
+        if (cl == 16) { // the row pair's sum lives in the odd rows
           const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
           sred[(wave * COUT + co) * 2] = s1;
           sred[(wave * COUT + co) * 2 + 1] = s2;
@@ -182,6 +185,9 @@ __global__ __launch_bounds__(256) void pwconv_small_kernel(const float *__restri
     for (int c = tid; c < Cin; c += 256) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
     __syncthreads();
   }
+  float brow[8]; // this thread's 8 output rows (tid / 32 + 8 j): fetched now, not in front of the stores
+#pragma unroll
+  for (int j = 0; j < 8; ++j) brow[j] = (bias && co0 + (tid >> 5) + 8 * j < CoutY) ? bias[co0 + (tid >> 5) + 8 * j] : 0.f;
   const float *xb = x + (size_t)b * Cin * L;
   f32x16 acc[2];
 #pragma unroll
@@ -226,13 +232,13 @@ __global__ __launch_bounds__(256) void pwconv_small_kernel(const float *__restri
     const int row = (tid >> 5) + 8 * j, cb = row >> 5, e = (row & 31) * 32 + c;
     float o = ((part[0][cb][e] + part[1][cb][e]) + part[2][cb][e]) + part[3][cb][e];
     const bool rok = co0 + row < CoutY;
-    o += (bias && rok) ? bias[co0 + row] : 0.f;
+    o += brow[j];
     if (ok && rok) yb[(size_t)row * L + colo] = o;
     if (STATS) {
       float s1 = ok ? o : 0.f, s2 = s1 * s1;
       s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
-      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-      if (c == 0 && rok) {
+      s1 = row_pair_sum_odd_rows(s1); s2 = row_pair_sum_odd_rows(s2);
+      if (c == 16 && rok) { // the row pair's sum lives in the odd rows
         float *so = stats + (((size_t)b * CoutY + co0 + row) * gridDim.x + blockIdx.x) * 2;
         so[0] = s1;
         so[1] = s2;
@@ -297,7 +303,7 @@ static int pw_pad(int Cout) { return (Cout + 31) / 32 * 32; }     // channel row
 static int pw_stride(int Cout) { return (Cout + 63) / 64 * 64; }  // row stride of the packed copy (zero columns beyond Cout)
 static size_t pw_lds(int cb, int Cin, bool pro, bool wlds = true) {
   const int ksteps = (Cin + 1) / 2;
-  return ((size_t)(wlds ? 2 * ksteps * cb * 32 : 0) + (pro ? 2 * Cin : 0) + 4 * cb * 32 * 2) * 4;
+  return ((size_t)(wlds ? 2 * ksteps * cb * 32 : 0) + (pro ? 2 * Cin : 0) + 4 * cb * 32 * 2 + cb * 32) * 4;
 }
 constexpr size_t PW_LDS_MAX = 150 * 1024;
 // Cout: any; the channel tile is the largest of 256 / 128 / 64 / 32 rows that divides ceil32(Cout) and whose weight slice

@@ -1,0 +1,58 @@
+// split_ops.h -- what the split-operand kernels share (conv3d_split.hip, pwconv_split.hip): an fp32 operand is cut into
+// two fp16 pieces a = a_h + a_l / 2048 after an exact power-of-two block scaling, products are accumulated in fp32 on
+// v_mfma_f32_32x32x16_f16:  main += A_h B_h,  corr += A_h B_l + A_l B_h,  D = main + corr / 2048.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+constexpr int KS = 16; // input channels per chunk = K of one MFMA
+
+__device__ __forceinline__ float pro_act(float v, float pa, float pb) { // == csrc/conv3d.hip
+  const float t = v * pa + pb;
+  return t * __frcp_rn(1.0f + __expf(-t));
+}
+// exponent e with 2^13 <= m * 2^e < 2^14 for a finite m > 0 (from the float's exponent field; subnormal m -> +100)
+__device__ __forceinline__ int scale_exp(float m) {
+  const int ex = (int)((__float_as_uint(m) >> 23) & 0xff) - 127; // floor(log2 m) for normal m; 128 for inf / nan
+  const int e = 13 - ex;
+  return e > 100 ? 100 : e;
+}
+// A running block scale 2^E is set SPLIT_HEADROOM binades below the cut's ceiling (max * 2^E in [2^9, 2^10) when it is
+// chosen) and only replaced when a later maximum reaches 2^14: growth by less than 2^4..2^5 costs no accumulator
+// rescale.  Nothing is lost: fp16 is normal down to 2^-14, i.e. 2^-23 of the block maximum, and subnormal steps below
+// that are 2^-33 of it.
+constexpr int SPLIT_HEADROOM = 4;
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); } // -126 <= e <= 127
+__device__ __forceinline__ void cut(float v, unsigned short &hi, unsigned short &lo) {
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ f32x16 mma(u4 a, u4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// ---- the per-tensor power-of-two scale of a packed weight: tail = 4 words behind the pieces {max |w| bits, ew, 2^-ew, 0}
+// with max |w| * 2^ew in [2^13, 2^14).  pass 1: max |w| (as bits: non-negative floats order like unsigned integers).
+static __global__ void split_wmax_kernel(const float *__restrict__ w, int n, unsigned *__restrict__ tail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned m = i < n ? (__float_as_uint(w[i]) & 0x7fffffffu) : 0u;
+  for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(tail, m);
+}
+static __global__ void split_wscale_kernel(unsigned *__restrict__ tail) {
+  const float m = __uint_as_float(tail[0]);
+  const int ew = m > 0.f ? scale_exp(m) : 0;
+  tail[1] = (unsigned)ew;
+  tail[2] = __float_as_uint(pow2f(-ew));
+  tail[3] = 0u;
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+} // namespace

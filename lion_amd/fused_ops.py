@@ -164,6 +164,34 @@ def pw_packed_weight(weight):
     return _PW_CACHE.get(weight)
 
 
+def _pw_split_pack(weight):
+    cout, cin = weight.shape[:2]
+    lib = _lib.load()
+    wp = torch.empty((lib.lion_pwconv_split_packed_halfs(cout, cin),), device=weight.device, dtype=torch.int16)
+    w_c = weight.detach().reshape(cout, cin).contiguous()
+    _lib.check(lib.lion_pwconv_split_pack_weights(_lib.ptr(w_c), cout, cin, _lib.ptr(wp),
+                                                  _lib.stream_ptr(weight.device)), "pwconv_split_pack_weights")
+    return wp
+
+
+_PW_SPLIT_CACHE = WeightCache(_pw_split_pack)
+# Which arithmetic the 1x1 convolutions run in (both fp32-accurate): fp16 x 2 split operands on the 16-bit MFMA pipe
+# (csrc/pwconv_split.hip) where it is the faster kernel, the fp32 MFMA kernels elsewhere and everywhere with
+# LION_PW_SPLIT=0.  tools/pw_bench.py, B = 32 (graph replay, us fp32 -> split): 192->128 L=2048 78 -> 28, 128->128 (+AdaGN
+# prologue) 106 -> 26, 128->256 196 -> 46, 320->256 L=512 63 -> 27; short activations (B x L < 8192 columns: a handful
+# of workgroups, latency bound) and the long thin ones (L >= 8192 with Cin x Cout < 8192: the fp32 kernel already moves
+# 3.1-3.8 TB/s) stay on the fp32 kernels.
+PW_SPLIT = __import__("os").environ.get("LION_PW_SPLIT", "1") != "0"
+
+
+def pw_use_split(split, b, cin, cout, L):
+    """split: None = module policy, True = wherever the kernel can run, False = never."""
+    can = cin * L < (1 << 29) and cin <= 4096
+    if split is None:
+        return PW_SPLIT and can and b * L >= 8192 and (L <= 4096 or cin * cout >= 8192)
+    return bool(split) and can
+
+
 def pw_supported(conv, x):
     """every kernel-size-1 Conv1d / Conv2d whose weight tile fits LDS (all of the released models'): large
     activations (set-abstraction MLPs) for the bytes, short ones (L = 16..256 points, classifier, attention
@@ -177,25 +205,28 @@ def pw_supported(conv, x):
             and _lib.load().lion_pwconv_stat_tiles(conv.out_channels, conv.in_channels, x[0, 0].numel()) > 0)
 
 
-def pwconv_fused(x, conv, pro=None, want_stats=True):
+def pwconv_fused(x, conv, pro=None, want_stats=True, split=None):
     """1x1 conv of a [B,Cin,*] activation on the MFMA kernel: y [B,Cout,*] and its GroupNorm tile sums
-    [B,Cout,T,2]; pro = (A, Bs) applies swish(x*A+Bs) (the previous layer's AdaGN + Swish) in flight."""
+    [B,Cout,T,2]; pro = (A, Bs) applies swish(x*A+Bs) (the previous layer's AdaGN + Swish) in flight.
+    split: see pw_use_split (None = the split-operand kernel for long activations, the fp32 MFMA kernels for short)."""
     lib = _lib.load()
     x = x.contiguous()
     b, cin = x.shape[:2]
     L = x[0, 0].numel()
     cout = conv.out_channels
-    wp = pw_packed_weight(conv.weight)
+    use_split = pw_use_split(split, b, cin, cout, L)
+    wp = _PW_SPLIT_CACHE.get(conv.weight) if use_split else pw_packed_weight(conv.weight)
     y = torch.empty((b, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
-    stats = torch.empty((b, cout, lib.lion_pwconv_stat_tiles(cout, cin, L), 2), device=x.device,
-                        dtype=torch.float32) if want_stats else None
+    tiles = (lib.lion_pwconv_split_stat_tiles if use_split else lib.lion_pwconv_stat_tiles)(cout, cin, L)
+    stats = torch.empty((b, cout, tiles, 2), device=x.device, dtype=torch.float32) if want_stats else None
     pa = pb = None
     if pro is not None:
         pa, pb = pro[0].contiguous(), pro[1].contiguous()
     bias = conv.bias.detach().contiguous() if conv.bias is not None else None
-    _lib.check(lib.lion_pwconv_forward(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), b, cin, cout, L,
-                                       _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats),
-                                       _lib.stream_ptr(x.device)), "pwconv_forward")
+    fwd = lib.lion_pwconv_split_forward if use_split else lib.lion_pwconv_forward
+    _lib.check(fwd(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), b, cin, cout, L,
+                   _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(stats),
+                   _lib.stream_ptr(x.device)), "pwconv_split_forward" if use_split else "pwconv_forward")
     return y, stats
 
 

@@ -504,7 +504,7 @@ def test_pwconv_matches_fp64_reference(cin, cout, L, pro):
     if pro:
         xin = _swish64(xin * A.double()[:, :, None] + Bs.double()[:, :, None])
     ref = torch.einsum("oc,bcl->bol", conv.weight.double()[:, :, 0], xin) + conv.bias.double()[None, :, None]
-    y, st = fo.pwconv_fused(x, conv, (A, Bs) if pro else None)
+    y, st = fo.pwconv_fused(x, conv, (A, Bs) if pro else None, split=False)   # the split kernel: test_pwconv_split_gpu.py
     scale = ref.abs().max().item()
     assert (y.double() - ref).abs().max().item() / scale < 1e-5
     sums = st.double().sum(2)  # [B, Cout, 2] over the column tiles
@@ -526,8 +526,8 @@ def test_pwconv_any_cout_and_short_rows(cin, cout, L):
     assert fo.pw_supported(conv, x)
     ref = torch.einsum("oc,bcl->bol", conv.weight.double()[:, :, 0], x.double()) + conv.bias.double()[None, :, None]
     with torch.no_grad():
-        y, st = fo.pwconv_fused(x, conv, None)
-        y2, st2 = fo.pwconv_fused(x, conv, None, want_stats=False)
+        y, st = fo.pwconv_fused(x, conv, None, split=False)
+        y2, st2 = fo.pwconv_fused(x, conv, None, want_stats=False, split=False)
     assert st2 is None and torch.equal(y, y2) and tuple(y.shape) == (B, cout, L)
     scale = ref.abs().max().item()
     assert (y.double() - ref).abs().max().item() / scale < 1e-5

@@ -1,0 +1,57 @@
+"""Furthest-point sampling on a side stream beside the LDS-DMA convolution kernel, captured in one hipGraph and replayed:
+per replay, how many of the B x M sample indices differ from the stand-alone result, and how many conv outputs differ.
+The register FPS kernel of round 1 trusted one barrier and one unchecked LDS read per round and returned 300-1800 wrong
+indices of 2048 in nearly every replay (never eagerly, never beside the fp32 or the register-staged kernels); with the
+checked reads of csrc/sampling.hip every replay matches.  usage: fps_under_dma.py [C] [R]   (conv C->C at R^3, default 32 32)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lion_amd.conv_ops import conv3d_k3
+from lion_amd.functional import backend as _bk
+
+
+def run(C=32, R=32, B=2, replays=20, split=True):
+    torch.manual_seed(0)
+    side = torch.cuda.Stream(priority=-1)
+    pts = torch.randn(B, 3, 2048, device="cuda")
+    conv = torch.nn.Conv3d(C, C, 3, padding=1).cuda()
+    x = torch.randn(B, C, R, R, R, device="cuda")
+    with torch.no_grad():
+        ref = _bk._backend.furthest_point_sampling(pts, 1024).clone()
+        yref = x
+        for _ in range(6):
+            yref = conv3d_k3(yref, conv.weight, conv.bias, split=split)
+        yref = yref.clone()
+
+        def fwd():
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                idx = _bk._backend.furthest_point_sampling(pts, 1024)
+            y = x
+            for _ in range(6):
+                y = conv3d_k3(y, conv.weight, conv.bias, split=split)
+            main.wait_stream(side)
+            return idx, y
+        fwd()
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            idx, y = fwd()
+        res = []
+        for _ in range(replays):
+            g.replay()
+            torch.cuda.synchronize()
+            res.append((int((idx != ref).sum().item()), int((y != yref).sum().item())))
+    return res
+
+
+if __name__ == "__main__":
+    C = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    print(f"conv {C}->{C} @ {R}^3: (wrong FPS indices, wrong conv outputs) per replay:", run(C, R))
