@@ -27,10 +27,6 @@ __device__ __forceinline__ unsigned long long fps_key(float d2, int k) {
 __device__ __forceinline__ int fps_key_index(unsigned long long key) {
   return (int)((0xffffffffu - (unsigned)(key & 0xffffffffull)) & 0xfffffu);
 }
-__device__ __forceinline__ unsigned fps_slot_check(float x, float y, float z, int k) {
-  const unsigned a = __float_as_uint(x), b = __float_as_uint(y), c = __float_as_uint(z);
-  return a ^ ((b << 11) | (b >> 21)) ^ ((c << 22) | (c >> 10)) ^ (unsigned)k ^ 0x9e3779b9u;
-}
 // max over the 64 lanes, result uniform: xor-1 / xor-2 inside quads, half-mirror (8), mirror (16), then the 4 rows
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   unsigned o;
@@ -61,7 +57,7 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
                                                       int32_t *__restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *sx = reinterpret_cast<float4 *>(smem); // [N] {x, y, z, -} copy for the "coords[old]" lookup (one 16-byte read)
-  __shared__ uint4 wkey[2][4]; // {tie-break word, distance bits, round, -}: one 16-byte LDS write per wave and round
+  __shared__ unsigned long long wkey[2][4];
   // 1023 dependent rounds on one workgroup per cloud: pure latency.  The sampler runs this chain on a side stream
   // under the MFMA convolutions (lion_amd/geometry.py); raise the wave priority so that its few instructions per
   // round issue ahead of the convolution waves sharing the SIMD instead of queueing behind them.
@@ -78,7 +74,7 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
     tb[p] = 0u;
     if (k < N) {
       x[p] = co[k]; y[p] = co[k + N]; z[p] = co[k + 2 * N];
-      sx[k] = make_float4(x[p], y[p], z[p], __uint_as_float(fps_slot_check(x[p], y[p], z[p], k))); // .w: checked by the reader
+      sx[k] = make_float4(x[p], y[p], z[p], 0.f);
       tb[p] = 0xffffffffu - (((unsigned)(k & 511) << 20) | (unsigned)k);
     }
   }
@@ -87,18 +83,7 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
   __syncthreads();
   int old = 0;
   for (int j = 1; j < M; ++j) {
-    float4 c1 = sx[old];
-    // Every slot carries a check word of its own content and the reader repeats a read that does not verify.  Measured
-    // (tools/fps_under_dma.py, round 2): inside a captured sampling step, with the LDS-DMA convolution workgroups
-    // (csrc/conv3d_split.hip) on the same CU, this 16-byte broadcast read occasionally returned values that were not the
-    // slot's -- the LDS copy itself verified intact at the end of the kernel, and with the centre re-read from global
-    // memory the samples were right in every replay.  300-1800 of 2048 indices wrong in nearly every replay without the
-    // check; none with it.
-    while (__float_as_uint(c1.w) != fps_slot_check(c1.x, c1.y, c1.z, old)) {
-      __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
-      c1 = sx[old];
-    }
+    const float4 c1 = sx[old];
     unsigned md = 0u;
 #pragma unroll
     for (int p = 0; p < PPT; ++p) {
@@ -116,18 +101,10 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
       mt = cand > mt ? cand : mt;
     }
     const unsigned wtb = wave_max_u32(mt);
-    if (lane == 0) wkey[j & 1][wave] = make_uint4(wtb, wmax, (unsigned)j, 0u);
+    if (lane == 0) wkey[j & 1][wave] = ((unsigned long long)wmax << 32) | wtb;
     __syncthreads();
-    // Every key carries its round and a reader that finds another round in a slot reads again (same defence as the
-    // checked centre read above: one 16-byte entry per wave, verified by content, never trusted by timing alone).
-    uint4 e0 = wkey[j & 1][0], e1 = wkey[j & 1][1], e2 = wkey[j & 1][2], e3 = wkey[j & 1][3];
-    while (e0.z != (unsigned)j || e1.z != (unsigned)j || e2.z != (unsigned)j || e3.z != (unsigned)j) {
-      __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory"); // read LDS again, not the registers
-      e0 = wkey[j & 1][0]; e1 = wkey[j & 1][1]; e2 = wkey[j & 1][2]; e3 = wkey[j & 1][3];
-    }
-    unsigned long long k0 = ((unsigned long long)e0.y << 32) | e0.x, k1 = ((unsigned long long)e1.y << 32) | e1.x,
-                       k2 = ((unsigned long long)e2.y << 32) | e2.x, k3 = ((unsigned long long)e3.y << 32) | e3.x;
+    unsigned long long k0 = wkey[j & 1][0], k1 = wkey[j & 1][1], k2 = wkey[j & 1][2],
+                       k3 = wkey[j & 1][3];
     k0 = k1 > k0 ? k1 : k0;
     k2 = k3 > k2 ? k3 : k2;
     k0 = k2 > k0 ? k2 : k0;
@@ -176,7 +153,19 @@ __global__ __launch_bounds__(1024) void fps_lds_kernel(const float *__restrict__
 
 template <int PPT>
 static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx, hipStream_t st) {
-  const size_t lds = (size_t)N * 16;
+  // The whole LDS of a CU is requested, not the N * 16 bytes the kernel uses: no other LDS-using workgroup can then share
+  // the CU.  Inside a captured sampling step this kernel runs on a side stream beside the convolutions
+  // (lion_amd/geometry.py); when the LDS-DMA convolution workgroups (csrc/conv3d_split.hip) were resident on the same CU
+  // it returned 300-1800 wrong indices of 2048 in nearly every graph replay -- never eagerly, never beside the fp32 or
+  // the register-staged kernels (tools/fps_under_dma.py).  Per-round logs (round 2) showed every wave with the right
+  // previous sample and the right centre, and the running distances of one wave wrong from one of the first rounds on;
+  // checked / repeated LDS reads, a tag-last key exchange and a generic LDS or VGPR self-checking kernel in its place
+  // all failed to locate the cause.  Alone on its CU the kernel is right in every replay; the price is B CUs for the
+  // ~0.55 ms of the chain (12 % of the chip at B = 32).
+  constexpr size_t CU_LDS = 160 * 1024 - 256; // minus the static exchange buffer, rounded
+  const size_t lds = (size_t)N * 16 > CU_LDS ? (size_t)N * 16 : CU_LDS;
+  static LionLdsLimit configured = {};
+  if (int e = lion_dynamic_lds(&fps_reg_kernel<PPT>, lds, configured)) return e;
   fps_reg_kernel<PPT><<<B, 256, lds, st>>>(coords, N, M, idx);
   LION_LAUNCH_CHECK();
   return 0;

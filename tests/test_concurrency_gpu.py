@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 @pytest.mark.parametrize("C,R", [(32, 32), (64, 32), (128, 16), (128, 8)])
 def test_fps_beside_the_dma_convolution_in_a_graph(C, R):
     import fps_under_dma
-    res = fps_under_dma.run(C, R, replays=12)
+    res = fps_under_dma.run(C, R, replays=40)
     assert all(r == (0, 0) for r in res), res
 
 
