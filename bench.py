@@ -432,7 +432,7 @@ def main():
                     conv = m
                     break
             xin = torch.randn(B, 64, 32, 32, 32, device=dev)
-            from lion_amd import conv_ops
+            from lion_amd import conv_ops, fused_ops
             flops = 2.0 * 27 * 64 * 64 * 32 ** 3 * B
             t32 = ev_time(lambda: conv_ops.conv3d_k3(xin, conv.weight, conv.bias, split=False), 20, warm=5)
             roof32 = {"kernel": "conv3d_k3_kernel: Conv3d 3x3x3 64->64 @32^3, B=32, exact-fp32 MFMA implicit GEMM "
@@ -467,8 +467,10 @@ def main():
             "metric": "shapes/sec @1000-step DDIM, Bx2048pts", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (3x3x3 voxel-conv operands cut into fp16 hi/lo pairs on the 16-bit MFMA pipe with f32 "
-                      "accumulation -- fp32-accurate, tests/test_conv_split_gpu.py; everything else f32)")
+            "dtype": ("f32 (operands of the 3x3x3 voxel convolutions" +
+                      (" and of the long 1x1 convolutions" if fused_ops.PW_SPLIT else "") +
+                      " cut into fp16 hi/lo pairs on the 16-bit MFMA pipe with f32 accumulation -- fp32-accurate, "
+                      "tests/test_conv_split_gpu.py, tests/test_pwconv_split_gpu.py; everything else f32)")
                      if conv_ops.SPLIT else "f32",
             "data": "synthetic",
             "config": {"workload": "configs[1]: unconditional airplane prior sampling, 1000-step DDIM chain "
@@ -483,6 +485,8 @@ def main():
                        "sparse_voxel_convs": not args.no_sparse,
                        "voxel_conv_kernel": "fp16x2 split operands (LION_CONV_SPLIT=0 selects exact-fp32 MFMA)"
                                             if conv_ops.SPLIT else "exact-fp32 MFMA",
+                       "pointwise_conv_kernel": "fp16x2 split operands for B*L >= 8192 columns (LION_PW_SPLIT=0: fp32 MFMA)"
+                                                if fused_ops.PW_SPLIT else "fp32 MFMA",
                        "ms_per_step_dense_convs": ms_dense,
                        "note": "step = one DDIM step of BOTH priors; with random-init weights the latents drift and "
                                "the exact empty-tile skip saves a trajectory-dependent share of the conv work: "
