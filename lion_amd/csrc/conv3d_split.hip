@@ -218,12 +218,25 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     for (int i = 0; i < NI; ++i) {
       const int item = tid + TM * i;
       const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1));
+      // the 8 channels' prologue scalars: three pairs of 16-byte broadcast reads per item (wave-uniform address) instead
+      // of 24 dword reads, and the activation computed unconditionally with a select behind it -- `gok ? act : 0` had
+      // become one branch per value (ISA: 56 s_cbranch_execz per chunk)
+      float pa8[8], pb8[8], pc8[8];
+      if (PRO) {
+        const int c0 = q * KS + ig * 8;
+        const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), a1 = *reinterpret_cast<const float4 *>(spa + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(spb + c0), b1 = *reinterpret_cast<const float4 *>(spb + c0 + 4);
+        const float4 c4 = *reinterpret_cast<const float4 *>(spc + c0), c5 = *reinterpret_cast<const float4 *>(spc + c0 + 4);
+        pa8[0] = a0.x; pa8[1] = a0.y; pa8[2] = a0.z; pa8[3] = a0.w; pa8[4] = a1.x; pa8[5] = a1.y; pa8[6] = a1.z; pa8[7] = a1.w;
+        pb8[0] = b0.x; pb8[1] = b0.y; pb8[2] = b0.z; pb8[3] = b0.w; pb8[4] = b1.x; pb8[5] = b1.y; pb8[6] = b1.z; pb8[7] = b1.w;
+        pc8[0] = c4.x; pc8[1] = c4.y; pc8[2] = c4.z; pc8[3] = c4.w; pc8[4] = c5.x; pc8[5] = c5.y; pc8[6] = c5.z; pc8[7] = c5.w;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = v[i][j];
         if (PRO) { // zero padding stays zero; delta mode stages the deviation from the per-channel constant
-          const int c = q * KS + ig * 8 + j;
-          t = gok[i] ? pro_act(t, spa[c], spb[c]) - spc[c] : 0.f;
+          const float act = pro_act(t, pa8[j], pb8[j]) - pc8[j];
+          t = gok[i] ? act : 0.f;
           v[i][j] = t;
         }
         const unsigned a = __float_as_uint(t) & 0x7fffffffu; // |t| as ordered bits; inf / nan do not set the scale:
@@ -575,12 +588,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int ig = __builtin_amdgcn_readfirstlane((tid + TM * i) / HP);
+      float pa8[8], pb8[8];
+      if (PRO) { // see conv3d_split_kernel: vector broadcast reads, unconditional activation + select
+        const int c0 = q * KS + ig * 8;
+        const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), a1 = *reinterpret_cast<const float4 *>(spa + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(spb + c0), b1 = *reinterpret_cast<const float4 *>(spb + c0 + 4);
+        pa8[0] = a0.x; pa8[1] = a0.y; pa8[2] = a0.z; pa8[3] = a0.w; pa8[4] = a1.x; pa8[5] = a1.y; pa8[6] = a1.z; pa8[7] = a1.w;
+        pb8[0] = b0.x; pb8[1] = b0.y; pb8[2] = b0.z; pb8[3] = b0.w; pb8[4] = b1.x; pb8[5] = b1.y; pb8[6] = b1.z; pb8[7] = b1.w;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = v[i][j];
         if (PRO) {
-          const int c = q * KS + ig * 8 + j;
-          t = gok[i] ? pro_act(t, spa[c], spb[c]) : 0.f;
+          const float act = pro_act(t, pa8[j], pb8[j]);
+          t = gok[i] ? act : 0.f;
           v[i][j] = t;
         }
         const unsigned a = __float_as_uint(t) & 0x7fffffffu;
