@@ -29,6 +29,7 @@
 // History: tools/exp/split_*.hip (inner product 400 TF fp32-equivalent; whole layer 779 us vs 1973 us of the fp32
 // kernel with statistics at B=32, 64->64, r=32).
 #include "split_ops.h"
+#include <cstdlib>
 
 namespace {
 
@@ -493,30 +494,40 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
 //     below are the operations this wave is known to have issued behind the awaited DMA -- at least DMA_MIN weight
 //     instructions per group and the NI*8 operand loads -- so they can only be too strict, never too lax);
 //   * fragments of tap t+1 are read from LDS in front of the MFMAs of tap t.
-// Voxel -> lane: a column block of 32 voxels is 8 w x {h, h+4, h+1, h+5}: 16 consecutive lanes read two halo rows whose
-// 16-byte slots differ by 40 = 8 (mod 16) -- conflict-free ds_read_b128 with the 10-wide halo rows of an 8-wide tile.
+// Two facts measured in round 2 shape the workgroup (tools/exp/lds_b128_probe.hip, s_memtime): ONE wave reads LDS at
+// 32 B/clk and issues a 32x32x16 MFMA every ~64 cycles, whatever else the CU does -- four waves x (32 channels x 64
+// voxels: 6 fragment reads per 6 MFMAs) sit on both limits (taps: 331 cycles per tap round for 192 of MFMA).  So the
+// default is EIGHT waves (two per SIMD) x one column block: 4 reads per 3 MFMAs and wave, 255 B/clk of LDS with the
+// conflict-free row order below, 54 -> 48 us at 128 -> 128, B = 32 (LION_CONV_R8_WAVES=4 selects the 4-wave form).
+// Voxel -> lane: a column block of 32 voxels is 8 w x 4 halo rows chosen so that a 32-lane group of a ds_read_b128
+// touches every 16-byte slot of the 512-byte LDS window once: rows {h, h+2, h+4, h+6} at row stride 12 (8 waves), rows
+// {h, h+4, h+1, h+5} at stride 10 (4 waves: conflict free in 16-lane groups at the 128 B/clk four waves can draw).
 // Dense only (the sparse plan starts at r = 16), prologue and statistics as conv3d_split_kernel, no delta mode.
-template <bool PRO, bool STATS>
-__global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
+template <bool PRO, bool STATS, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
                                                                   const float *__restrict__ wtail,
                                                                   const float *__restrict__ bias, float *__restrict__ y,
                                                                   int Cin, int Cout, const float *__restrict__ pro_a,
                                                                   const float *__restrict__ pro_b,
                                                                   float *__restrict__ stats) {
-  constexpr int r = 8, r3 = 512, TD = 4, TH = 8, TW = 8, VB = 2, COT = 32, TM = 256;
-  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW; // 600
-  constexpr int HP = (HALO + 63) / 64 * 64;                                 // 640
-  constexpr int NI = 2 * HP / TM;                                           // 5 staging items per thread
+  // NW = 4 waves x 2 column blocks or NW = 8 waves x 1 (two waves per SIMD: see the comment above).  Halo row stride HW:
+  // 10 for NW = 4 (block rows {h, h+4, h+1, h+5}), 12 for NW = 8 (block rows {h, h+2, h+4, h+6}: 24 / 48 / 72 = 24, 16, 8
+  // mod 32 -- the four rows of a 32-lane group fall into four different quarters of the 512-byte LDS window)
+  constexpr int r = 8, r3 = 512, TD = 4, TH = 8, TW = 8, VB = 8 / NW, COT = 32, TM = 64 * NW;
+  static_assert(NW == 4 || NW == 8, "4 waves x 2 column blocks or 8 waves x 1");
+  constexpr int HD = TD + 2, HH = TH + 2, HW = NW == 8 ? TW + 4 : TW + 2, HALO = HD * HH * HW; // 600 / 720
+  constexpr int HP = (HALO + 63) / 64 * 64;                                 // 640 / 768
+  constexpr int NI = 2 * HP / TM;                                           // 5 / 3 staging items per thread
   static_assert(2 * HP % TM == 0, "whole staging rounds");
   constexpr int WPL = 4 * COT, TG = 9, NG = 27 / TG;                        // 128 u4 per tap slice; groups of 9 taps
-  constexpr int DMA_PER_GROUP = TG * WPL / 64, DMA_MIN = DMA_PER_GROUP / 4; // 18 wave instructions over 4 waves
+  constexpr int DMA_PER_GROUP = TG * WPL / 64, DMA_MIN = DMA_PER_GROUP / NW; // 18 wave instructions over the waves
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u4 *sx = reinterpret_cast<u4 *>(smem);      // [2][piece][half][HP]
   u4 *sw = sx + 2 * 4 * HP;                   // [3][TG][piece][half][COT]
   float *sbias = reinterpret_cast<float *>(sw + 3 * TG * WPL);
   const int npro = PRO ? ((Cin + 63) & ~63) : 0;
   float *spa = sbias + COT, *spb = spa + npro;
-  float *sred = spb + npro;                   // [4][COT][2]
+  float *sred = spb + npro;                   // [NW][COT][2]
   __shared__ unsigned s_max[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 5, l32 = lane & 31;
@@ -537,19 +548,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int p = (tid + TM * i) % HP;
-    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW; // hw >= TW + 2: padding of the row stride
     const int gd = d0 - 1 + hd, gh = hh - 1, gw = hw - 1;
-    gok[i] = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+    gok[i] = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r; // gw < r excludes the padding
     goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
   }
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
-  // this lane's voxel in column block vbk = wave * VB + vb: d = vbk / 2, w = l % 8, h = 2 (vbk % 2) + {0, 4, 1, 5}[l / 8]
+  // this lane's voxel in column block vbk = wave * VB + vb: d = vbk / 2, w = l % 8,
+  // h = 2 (vbk % 2) + {0, 4, 1, 5}[l / 8] (NW = 4) or (vbk % 2) + {0, 2, 4, 6}[l / 8] (NW = 8)
   int xbase[VB], vox[VB];
 #pragma unroll
   for (int vb = 0; vb < VB; ++vb) {
     const int vbk = wave * VB + vb;
-    const int d = vbk >> 1, w = l32 & 7, h = (vbk & 1) * 2 + ((l32 >> 4) & 1) + 4 * ((l32 >> 3) & 1);
+    const int d = vbk >> 1, w = l32 & 7;
+    const int h = NW == 8 ? (vbk & 1) + 2 * (l32 >> 3) : (vbk & 1) * 2 + ((l32 >> 4) & 1) + 4 * ((l32 >> 3) & 1);
     xbase[vb] = (d * HH + h) * HW + w;
     vox[vb] = ((d0 + d) * r + h) * r + w;
   }
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
   auto weights_dma = [&](int sg) { // group sg (chunk sg / 3, taps 9 (sg % 3) ..) -> ring slot sg % 3
     const u4 *src = wp + (size_t)sg * TG * 4 * Cout + co0;
     const uint32_t dst0 = sw_lds + (uint32_t)((sg % 3) * TG * WPL * 16);
-    for (int i = wave; i < DMA_PER_GROUP; i += 4) { // instruction i: tap i / 2, planes 2 (i % 2) + {0, 1}, 32 channels each
+    for (int i = wave; i < DMA_PER_GROUP; i += NW) { // instruction i: tap i / 2, planes 2 (i % 2) + {0, 1}, 32 channels each
       const u4 *gp = src + (size_t)((i >> 1) * 4 + (i & 1) * 2 + g) * Cout + l32;
       const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + (uint32_t)(i * 1024));
       unsigned keep;
@@ -728,7 +741,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
     if (tid < COT) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
+      for (int w = 0; w < NW; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
       float *o = stats + (((size_t)b * Cout + co0 + tid) * (r / TD) + tile) * 2;
       o[0] = s1;
       o[1] = s2;
@@ -741,17 +754,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_split_pipe_kernel(const float *
 #endif
 }
 
+template <int NW>
 static int launch_split_pipe(const float *x, const u4 *wp, const float *wtail, const float *bias, float *y, int B, int Cin,
                              int Cout, const float *pa, const float *pb, float *stats, hipStream_t st) {
-  constexpr int HP = 640, COT = 32;
+  constexpr int HP = NW == 8 ? 768 : 640, COT = 32;
   const dim3 grid(B, 2, Cout / COT);
   const size_t LDS = (size_t)(2 * 4 * HP + 3 * 9 * 4 * COT) * 16 +
-                     (size_t)(COT + (pa ? 2 * ((Cin + 63) & ~63) : 0) + 4 * COT * 2) * 4;
+                     (size_t)(COT + (pa ? 2 * ((Cin + 63) & ~63) : 0) + NW * COT * 2) * 4;
 #define LION_PIPE_GO(PRO_, ST_)                                                                              \
   {                                                                                                          \
     static LionLdsLimit cfg = {};                                                                            \
-    if (int e = lion_dynamic_lds(&conv3d_split_pipe_kernel<PRO_, ST_>, LDS, cfg)) return e;                  \
-    conv3d_split_pipe_kernel<PRO_, ST_><<<grid, 256, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, pa, pb, stats); \
+    if (int e = lion_dynamic_lds(&conv3d_split_pipe_kernel<PRO_, ST_, NW>, LDS, cfg)) return e;              \
+    conv3d_split_pipe_kernel<PRO_, ST_, NW><<<grid, 64 * NW, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, pa, pb, stats); \
   }
   if (pa && stats) LION_PIPE_GO(true, true)
   else if (pa) LION_PIPE_GO(true, false)
@@ -831,7 +845,9 @@ int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float
   const float *wtail = reinterpret_cast<const float *>(wp + split_piece_halfs(Cout, Cin));
   if (r == 8) {
     if (tconst) return LION_EUNSUPPORTED;
-    return launch_split_pipe(x, w4, wtail, bias, y, B, Cin, Cout, pro_a, pro_b, stats, st);
+    static const bool w8 = getenv("LION_CONV_R8_WAVES") ? atoi(getenv("LION_CONV_R8_WAVES")) == 8 : true; // A/B switch
+    return w8 ? launch_split_pipe<8>(x, w4, wtail, bias, y, B, Cin, Cout, pro_a, pro_b, stats, st)
+              : launch_split_pipe<4>(x, w4, wtail, bias, y, B, Cin, Cout, pro_a, pro_b, stats, st);
   }
 #define LION_SPLIT_TILE(R_, VB_, CB_, TD_, TH_, TW_, OCC_)                                                  \
   if (r == R_ && p.vb == VB_ && p.cb == CB_)                                                                \

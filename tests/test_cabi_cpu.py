@@ -114,6 +114,12 @@ def test_host_side_plan_functions():
     assert lib.lion_pwconv_stat_tiles(256, 320, 8192) == 8192 // 512        # 256 / 128 rows x 320 k do not fit LDS: 64-row tiles
     assert lib.lion_pwconv_stat_tiles(4, 128, 2048) == 2048 // 32           # <= 4096 columns: the K-split kernel, 32-column tiles
     assert lib.lion_pwconv_stat_tiles(128, 256, 64) == 2
+    # split-operand 1x1 kernel: 4 waves x VB x 32 columns per workgroup, VB = 1 / 2 / 2 for channel tiles of 128 / 64 / 32
+    assert lib.lion_pwconv_split_stat_tiles(128, 192, 2048) == 2048 // 128
+    assert lib.lion_pwconv_split_stat_tiles(64, 35, 32768) == 32768 // 256
+    assert lib.lion_pwconv_split_stat_tiles(96, 16, 1000) == -(-1000 // 256)
+    assert lib.lion_pwconv_split_packed_halfs(128, 35) == 3 * 4 * 128 * 8 + 8      # ceil16(35) = 3 chunks + the scale tail
+    assert lib.lion_conv3d_split_stat_tiles(8, 128) == 2 and lib.lion_conv3d_split_stat_tiles(32, 64) == 128
     assert lib.lion_pwconv_packed_floats(64, 35) == 36 * 64 and lib.lion_pwconv_packed_floats(4, 128) == 128 * 64
     # skinny GEMM: split K until ~256 workgroups, >= 8 k-steps per wave
     assert lib.lion_skinny_splits(2048, 2048) == 4

@@ -7,6 +7,11 @@ python bench.py --mode train_vae > $O/${TAG}_bench_train_vae.json 2>> $O/${TAG}_
 python bench.py --mode train_prior > $O/${TAG}_bench_train_prior.json 2>> $O/${TAG}_bench_default.err
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-dense-check > $O/${TAG}_bench_steps20_line.json 2> /dev/null )
 python tools/kstats.py $O/step_trace 70 > $O/${TAG}_bench_steps20_kernel_stats.txt 2>&1
+python tools/trace_gaps.py $O/step_trace begin_step_kernel --top 45 --last 9 > $O/${TAG}_bench_steps20_timeline.txt 2>&1
+python tools/conv_split_bench.py > $O/${TAG}_conv_split_bench.txt 2>/dev/null
+python tools/pw_bench.py > $O/${TAG}_pw_bench.txt 2>/dev/null
+python tools/fps_under_dma.py > $O/${TAG}_fps_under_dma.txt 2>/dev/null
+./tools/exp/lds_probe > $O/${TAG}_exp_lds_b128_probe.txt 2>/dev/null
 cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
 bash tools/prof_traffic.sh vox_64_2048_32 vox_fused -- python tools/one_vox.py 64 2048 32 > /dev/null 2>&1
 bash tools/prof_traffic.sh devox_64_2048_32 devox -- python tools/one_devox.py 64 2048 32 > /dev/null 2>&1

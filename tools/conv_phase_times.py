@@ -10,7 +10,7 @@ lib.lion_debug_split_phases.restype = ctypes.c_int
 lib.lion_debug_split_phases.argtypes = [ctypes.c_void_p, ctypes.c_int]
 names = ["item prologue", "barrier A (chunk start)", "loads + wait + activate + max", "barrier B (max)", "cut + LDS write",
          "group barrier (weights)", "taps of a group", "epilogue"]
-for cin, cout, r in [(128, 128, 8), (256, 128, 8), (64, 64, 32)]:
+for cin, cout, r in [(128, 128, 8), (64, 64, 32)]:
     conv = torch.nn.Conv3d(cin, cout, 3, padding=1).cuda(); x = torch.randn(32, cin, r, r, r, device="cuda")
     with torch.no_grad():
         for _ in range(3): conv3d_k3(x, conv.weight, conv.bias, split=True)

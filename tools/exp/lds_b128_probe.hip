@@ -36,6 +36,7 @@ int main() {
   mk("8-wide rows, stride 10 (h, h+1, h+2, h+3), planes +640", [](int l) { return (l & 7) + ((l >> 3) & 3) * 10 + (l >> 5) * 640; });
   mk("8-wide rows h, h+4, h+1, h+5 (stride 10), planes +640", [](int l) { return (l & 7) + (((l >> 4) & 1) + 4 * ((l >> 3) & 1)) * 10 + (l >> 5) * 640; });
   mk("8-wide rows h, h+4, h+1, h+5 (stride 10), planes +648", [](int l) { return (l & 7) + (((l >> 4) & 1) + 4 * ((l >> 3) & 1)) * 10 + (l >> 5) * 648; });
+  mk("8-wide rows h, h+2, h+4, h+6 (stride 12), planes +768", [](int l) { return (l & 7) + ((l >> 3) & 3) * 24 + (l >> 5) * 768; });
   mk("8-wide rows stride 10, planes +644", [](int l) { return (l & 7) + ((l >> 3) & 3) * 10 + (l >> 5) * 644; });
   mk("8-wide rows stride 12, planes +640", [](int l) { return (l & 7) + ((l >> 3) & 3) * 12 + (l >> 5) * 640; });
   mk("8-wide rows stride 12, planes +648", [](int l) { return (l & 7) + ((l >> 3) & 3) * 12 + (l >> 5) * 648; });
@@ -50,7 +51,7 @@ int main() {
   const int iters = 2000;
   for (int nthreads = 64; nthreads <= 512; nthreads *= 2)
   for (auto &p : ps) {
-    if (nthreads > 64 && &p != &ps[0] && &p != &ps[6] && &p != &ps[5]) continue;
+    if (nthreads > 64 && &p != &ps[0] && &p != &ps[6] && &p != &ps[5] && &p != &ps[8]) continue;
     (void)hipMemcpy(dp, p.v.data(), 256, hipMemcpyHostToDevice);
     unsigned long long best = ~0ull;
     for (int rep = 0; rep < 3; ++rep) {
