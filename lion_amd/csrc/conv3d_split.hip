@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   const int ntw = r / TW, nth = r / TH;
   const int d0 = (tile / (ntw * nth)) * TD, h0 = ((tile / ntw) % nth) * TH, w0 = (tile % ntw) * TW;
   const int r3 = r * r * r;
-  const bool delta = PRO && tconst != nullptr;
-  if (PRO) {
+  const bool pro_on = PRO && pro_a != nullptr; // the PRO instantiation also serves launches without a prologue (see
+  const bool delta = pro_on && tconst != nullptr; // launch_split_t: its register allocation is the better one)
+  if (pro_on) {
     for (int c = tid; c < Cin; c += TM) {
       const float pa = pro_a[(size_t)b * Cin + c], pb = pro_b[(size_t)b * Cin + c];
       spa[c] = pa;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       // of 24 dword reads, and the activation computed unconditionally with a select behind it -- `gok ? act : 0` had
       // become one branch per value (ISA: 56 s_cbranch_execz per chunk)
       float pa8[8], pb8[8], pc8[8];
-      if (PRO) {
+      if (pro_on) {
         const int c0 = q * KS + ig * 8;
         const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), a1 = *reinterpret_cast<const float4 *>(spa + c0 + 4);
         const float4 b0 = *reinterpret_cast<const float4 *>(spb + c0), b1 = *reinterpret_cast<const float4 *>(spb + c0 + 4);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = v[i][j];
-        if (PRO) { // zero padding stays zero; delta mode stages the deviation from the per-channel constant
+        if (pro_on) { // zero padding stays zero; delta mode stages the deviation from the per-channel constant
           const float act = pro_act(t, pa8[j], pb8[j]) - pc8[j];
           t = gok[i] ? act : 0.f;
           v[i][j] = t;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       const int e = scale_exp(__uint_as_float(mbits));
       if (e < E) { // the tile's maximum grew: bring what has been accumulated onto the new (smaller) scale first
         if (E != 127) {
-          const float f = pow2f(max(e - SPLIT_HEADROOM - E, -126));
+          const float f = pow2f(max(e - CONV_SPLIT_HEADROOM - E, -126));
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
               for (int i = 0; i < 16; ++i) { acc[cb][vb][i] *= f; cor[cb][vb][i] *= f; }
         }
-        E = e - SPLIT_HEADROOM;
+        E = e - CONV_SPLIT_HEADROOM;
       }
     }
     const float xs = E == 127 ? 1.0f : pow2f(E);
@@ -464,8 +465,13 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
   const long items = (long)B * tiles * (Cout / COT);
   const long resident = (long)OCC * cu_count[dev];
   const dim3 grid = occ ? dim3((unsigned)(items < resident ? items : resident)) : dim3(B, tiles, Cout / COT);
+  // (PRO = false, STATS = true) of the 64-channel tile gets 556-568 bytes of scratch from the register allocator where
+  // (true, true) gets 304-360: launches with statistics and without a prologue run on the PRO instantiation with the
+  // prologue switched off at run time (pro_a == nullptr); LION_CONV_PRO_INST=0 restores the separate instantiation
+  static const bool pro_inst_env = getenv("LION_CONV_PRO_INST") ? atoi(getenv("LION_CONV_PRO_INST")) != 0 : true;
+  const bool pro_inst = pa != nullptr || (pro_inst_env && stats != nullptr && CB == 2 && Cin <= 256);
   const size_t LDS = (size_t)(4 * HP + 2 * 3 * 4 * COT) * 16 + // planes + two groups of 3 taps of weight slices
-                     (size_t)(COT + (pa ? 3 * ((Cin + 63) & ~63) : 0) + 4 * COT * 2) * 4;
+                     (size_t)(COT + (pro_inst ? 3 * ((Cin + 63) & ~63) : 0) + 4 * COT * 2) * 4;
 #define LION_SPLIT_GO(PRO_, ST_)                                                                             \
   {                                                                                                          \
     static LionLdsLimit cfg = {};                                                                            \
@@ -473,7 +479,7 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
     conv3d_split_kernel<TD, TH, TW, CB, VB, PRO_, ST_, OCC><<<grid, 256, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, r, pa, pb, \
                                                                               pbias, tconst, stats, occ, B, tiles); \
   }
-  if (pa && stats) LION_SPLIT_GO(true, true)
+  if (pro_inst && stats) LION_SPLIT_GO(true, true)
   else if (pa) LION_SPLIT_GO(true, false)
   else if (stats) LION_SPLIT_GO(false, true)
   else LION_SPLIT_GO(false, false)
@@ -630,13 +636,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
       const int e = scale_exp(__uint_as_float(mbits));
       if (e < E) {
         if (E != 127) {
-          const float f = pow2f(max(e - SPLIT_HEADROOM - E, -126));
+          const float f = pow2f(max(e - CONV_SPLIT_HEADROOM - E, -126));
 #pragma unroll
           for (int vb = 0; vb < VB; ++vb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc[vb][i] *= f; cor[vb][i] *= f; }
         }
-        E = e - SPLIT_HEADROOM;
+        E = e - CONV_SPLIT_HEADROOM;
       }
     }
     const float xs = E == 127 ? 1.0f : pow2f(E);

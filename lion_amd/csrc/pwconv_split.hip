@@ -158,13 +158,13 @@ __global__ __launch_bounds__(256, 2) void pwconv_split_kernel(const float *__res
         const int e = scale_exp(__uint_as_float(m));
         if (e < E[vb]) { // the column's maximum grew: bring its accumulators onto the new (smaller) scale first
           if (E[vb] != 127) {
-            const float f = pow2f(max(e - SPLIT_HEADROOM - E[vb], -126));
+            const float f = pow2f(max(e - PW_SPLIT_HEADROOM - E[vb], -126));
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
               for (int i = 0; i < 16; ++i) { acc[cb][vb][i] *= f; cor[cb][vb][i] *= f; }
           }
-          E[vb] = e - SPLIT_HEADROOM;
+          E[vb] = e - PW_SPLIT_HEADROOM;
         }
       }
       const float xs = E[vb] == 127 ? 1.0f : pow2f(E[vb]);

@@ -21,11 +21,14 @@ __device__ __forceinline__ int scale_exp(float m) {
   const int e = 13 - ex;
   return e > 100 ? 100 : e;
 }
-// A running block scale 2^E is set SPLIT_HEADROOM binades below the cut's ceiling (max * 2^E in [2^9, 2^10) when it is
-// chosen) and only replaced when a later maximum reaches 2^14: growth by less than 2^4..2^5 costs no accumulator
-// rescale.  Nothing is lost: fp16 is normal down to 2^-14, i.e. 2^-23 of the block maximum, and subnormal steps below
-// that are 2^-33 of it.
-constexpr int SPLIT_HEADROOM = 4;
+// A running block scale 2^E may be set H binades below the cut's ceiling (max * 2^E in [2^(13-H), 2^(14-H)) when it
+// is chosen) and is only replaced when a later maximum reaches 2^14: growth by less than 2^H costs no accumulator
+// rescale.  Nothing is lost: fp16 is normal down to 2^-14, i.e. 2^-23 of the block maximum at H = 4, and subnormal
+// steps below that are 2^-33 of it.  The 1x1 kernel (one scale per COLUMN: some column of a wave grows in most chunks)
+// uses H = 4; the 3x3x3 kernels (one scale per workgroup tile: growth is rare) keep H = 0 -- with H = 4 the register
+// allocation of the 32-channel tile variant went from 156 to 380 bytes of scratch and the layer from 296 to 400 us.
+constexpr int PW_SPLIT_HEADROOM = 4;
+constexpr int CONV_SPLIT_HEADROOM = 0;
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); } // -126 <= e <= 127
 __device__ __forceinline__ void cut(float v, unsigned short &hi, unsigned short &lo) {
   const _Float16 h = (_Float16)v;
