@@ -17,6 +17,7 @@
 // tie-break word among the lanes that hold the maximum) instead of 64-bit xor-shuffles, which go through the LDS
 // crossbar (ds_bpermute, ~12 dependent LDS round trips per round).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -160,10 +161,13 @@ static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx
   // the register-staged kernels (tools/fps_under_dma.py).  Per-round logs (round 2) showed every wave with the right
   // previous sample and the right centre, and the running distances of one wave wrong from one of the first rounds on;
   // checked / repeated LDS reads, a tag-last key exchange and a generic LDS or VGPR self-checking kernel in its place
-  // all failed to locate the cause.  Alone on its CU the kernel is right in every replay; the price is B CUs for the
-  // ~0.55 ms of the chain (12 % of the chip at B = 32).
+  // all failed to locate the cause; of the kernels it overlaps with only conv3d_split_kernel triggers it (the split 1x1
+  // kernel and the row-gather devoxelize, LDS-DMA users too, do not: LION_FPS_SHARE_CU=1 tools/fps_under_dma.py <kernel>).
+  // Alone on its CU the kernel is right in every replay; the price is B CUs for the ~0.55 ms of the chain (12 % of the
+  // chip at B = 32).
   constexpr size_t CU_LDS = 160 * 1024 - 256; // minus the static exchange buffer, rounded
-  const size_t lds = (size_t)N * 16 > CU_LDS ? (size_t)N * 16 : CU_LDS;
+  static const bool share_cu = getenv("LION_FPS_SHARE_CU") != nullptr; // experiment switch: the round-1 launch (N * 16 bytes)
+  const size_t lds = ((size_t)N * 16 > CU_LDS || share_cu) ? (size_t)N * 16 : CU_LDS;
   static LionLdsLimit configured = {};
   if (int e = lion_dynamic_lds(&fps_reg_kernel<PPT>, lds, configured)) return e;
   fps_reg_kernel<PPT><<<B, 256, lds, st>>>(coords, N, M, idx);
