@@ -183,7 +183,11 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   const uint32_t sw_lds = (uint32_t)(uintptr_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw) + (uint32_t)wave * 1024u;
   auto weights_dma = [&](int sg) { // group sg of the K walk (chunk sg / 9, taps (sg % 9) * TG ..) -> buffer sg & 1
+#ifdef SPLIT_EXP_NO_DMA /* SPLIT_EXP_NO_*: builds for tools/fps_under_dma.py (which part of this kernel disturbs a CU neighbour) */
+    if (false) {
+#else
     if (w_thread) {                // wave uniform: WPL is a multiple of 64
+#endif
 #pragma unroll
       for (int t = 0; t < TG; ++t) {
         const u4 *gp = wp + ((size_t)sg * TG + t) * 4 * Cout + we_g;
@@ -246,7 +250,11 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       }
     }
     mloc = wave_max_u32_lane63(mloc);
+#ifdef SPLIT_EXP_NO_ATOMIC
+    if (lane == 63 && mloc) s_max[q & 1] = mloc;
+#else
     if (lane == 63 && mloc) atomicMax(&s_max[q & 1], mloc);
+#endif
     PH_MARK(2);
     __syncthreads(); // the chunk's maximum is complete
     PH_MARK(3);
@@ -304,7 +312,11 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       __syncthreads();
       PH_MARK(5);
       if (sg + 1 < nchunks * (27 / TG)) weights_dma(sg + 1);
+#ifdef SPLIT_EXP_NO_TAPS
+      if (false) {
+#else
       if (wave_on) {
+#endif
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
           const int tap = grp * TG + t;
@@ -313,18 +325,34 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
           u4 wf[CB][2], xf[VB][2];
 #pragma unroll
           for (int pc = 0; pc < 2; ++pc) {
+#ifdef SPLIT_EXP_NO_FRAG_READS /* experiment: MFMAs on register constants, no LDS fragment reads */
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) wf[cb][pc] = u4{(unsigned)tap, 0x3c003c00u, (unsigned)pc, 0x3c003c00u};
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = u4{0x3c003c00u, (unsigned)toff, 0x3c003c00u, (unsigned)vb};
+            (void)swb;
+#else
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) wf[cb][pc] = swb[(pc * 2 + g) * COT + cb * 32 + l32];
 #pragma unroll
             for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = sx[(pc * 2 + g) * HP + xbase[vb] + toff];
+#endif
           }
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int vb = 0; vb < VB; ++vb) {
+#ifdef SPLIT_EXP_NO_MFMA /* experiment: the fragment reads are consumed by VALU adds, no MFMA */
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                acc[cb][vb][i] += __uint_as_float(wf[cb][0][i] ^ xf[vb][0][i]);
+                cor[cb][vb][i] += __uint_as_float(wf[cb][1][i] ^ xf[vb][1][i]);
+              }
+#else
               acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
               cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
               cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
+#endif
             }
         }
       }
@@ -859,6 +887,9 @@ int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float
   if (r == R_ && p.vb == VB_ && p.cb == CB_)                                                                \
     return launch_split_t<TD_, TH_, TW_, CB_, VB_, OCC_>(x, w4, wtail, bias, y, B, Cin, Cout, r, pro_a, pro_b, pro_bias, tconst, \
                                                    stats, occ, st);
+#ifdef LION_EXP_CONV_OCC1
+  if (getenv("LION_EXP_CONV_OCC1")) { LION_SPLIT_TILE(32, 2, 1, 2, 4, 32, 1) } // experiment: all 512 registers, no spills
+#endif
   LION_SPLIT_TILE(32, 2, 2, 2, 4, 32, 2)
   LION_SPLIT_TILE(32, 2, 1, 2, 4, 32, 2)
   LION_SPLIT_TILE(16, 2, 2, 4, 4, 16, 2)

@@ -161,8 +161,10 @@ static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx
   // the register-staged kernels (tools/fps_under_dma.py).  Per-round logs (round 2) showed every wave with the right
   // previous sample and the right centre, and the running distances of one wave wrong from one of the first rounds on;
   // checked / repeated LDS reads, a tag-last key exchange and a generic LDS or VGPR self-checking kernel in its place
-  // all failed to locate the cause; of the kernels it overlaps with only conv3d_split_kernel triggers it (the split 1x1
-  // kernel and the row-gather devoxelize, LDS-DMA users too, do not: LION_FPS_SHARE_CU=1 tools/fps_under_dma.py <kernel>).
+  // all failed to locate the cause.  What is known: of the kernels it overlaps with only
+  // conv3d_split_kernel triggers it, and of that kernel only the tap loop's dense v_mfma_f32_32x32x16_f16 stream --
+  // with the MFMAs compiled out (the LDS reads kept) FPS is right in every replay, with only the MFMAs left (no LDS
+  // reads, no DMA, no atomics, no stores, no spills) it is wrong in every replay.
   // Alone on its CU the kernel is right in every replay; the price is B CUs for the ~0.55 ms of the chain (12 % of the
   // chip at B = 32).
   constexpr size_t CU_LDS = 160 * 1024 - 256; // minus the static exchange buffer, rounded
