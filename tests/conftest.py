@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """No test may hang a run: 600 s per test (the first GPU test pays the 1-2 min first `import torch` of a fresh box),
+    enforced by pytest-timeout's thread method -- it dumps every thread's stack and ends the process, which also gets
+    out of a wait inside a native call.  (One full GPU run at the end of round 2 sat silent for 1000 s.)"""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure; never imported by lion_amd)."""
