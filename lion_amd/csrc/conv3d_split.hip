@@ -190,11 +190,17 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #endif
 #pragma unroll
       for (int t = 0; t < TG; ++t) {
+        // the BUILTIN, not inline asm: the compiler must know that three more VM operations are in flight.  With an asm
+        // DMA its wait for the scratch reloads of the tap loop's addresses (issued in front of the barrier, waited for
+        // at first use) was vmcnt(0), which -- memory operations retire in order -- also waited for the DMA: 27 of the
+        // 30 DMA instructions of this kernel were drained before the first MFMA of their group, every group began with
+        // the round trip of the NEXT group's slices (tools/dma_drain_check.py; found statically at the end of round 2,
+        // NOT yet measured on the GPU).  With the builtin the same wait is vmcnt(3) and the DMA flies under the taps.
         const u4 *gp = wp + ((size_t)sg * TG + t) * 4 * Cout + we_g;
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(sw_lds + (uint32_t)(((sg & 1) * TG + t) * WPL * 16));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef __attribute__((address_space(1))) const void glb_void;
+        lds_void *dstp = (lds_void *)(uintptr_t)__builtin_amdgcn_readfirstlane(sw_lds + (uint32_t)(((sg & 1) * TG + t) * WPL * 16));
+        __builtin_amdgcn_global_load_lds((glb_void *)gp, dstp, 16, 0, 0);
       }
     }
   };
