@@ -420,12 +420,17 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   // (i&3) + 8*(i>>2) + 4*(l>>5), voxel column l&31.
   float *yb = y + ((size_t)b * Cout + co0) * r3;
   const float us_x = E == 127 ? 1.0f : pow2f(-E), us_w = wscale_inv; // exact powers of two
+  // two passes: every output value first (the accumulators become the outputs), then NOTHING BUT stores.  In one loop
+  // the compiler reloaded spilled values between the stores and waited for each reload with vmcnt(0|1) -- which also
+  // waits for the stores issued before it: 18-23 store / wait / store sequences per epilogue (tools/store_wait_scan.py),
+  // each a round trip to memory.
+  int gvv[VB];
 #pragma unroll
   for (int vb = 0; vb < VB; ++vb) {
     const int v = (wave * VB + vb) * 32 + l32;
     const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
     const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
-    const int gv = (gd * r + gh) * r + gw;
+    gvv[vb] = (gd * r + gh) * r + gw;
     const int cfg = (((gd == 0 ? 0 : gd == r - 1 ? 2 : 1) * 3 + (gh == 0 ? 0 : gh == r - 1 ? 2 : 1)) * 3 +
                      (gw == 0 ? 0 : gw == r - 1 ? 2 : 1));
     const float *addv = delta ? sT + cfg * COT : sbias;
@@ -434,18 +439,26 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
-        const float o = ((acc[cb][vb][i] + cor[cb][vb][i] * (1.f / 2048.f)) * us_x) * us_w + addv[co];
-        acc[cb][vb][i] = o;
+        acc[cb][vb][i] = ((acc[cb][vb][i] + cor[cb][vb][i] * (1.f / 2048.f)) * us_x) * us_w + addv[co];
+      }
+  }
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+        const float o = acc[cb][vb][i];
 #ifdef SPLIT_EXP_NO_STORE
         if (o == 1.2345e30f)
 #endif
 #ifdef SPLIT_Y_NT
-        __builtin_nontemporal_store(o, &yb[(size_t)co * r3 + gv]);
+        __builtin_nontemporal_store(o, &yb[(size_t)co * r3 + gvv[vb]]);
 #else
-        yb[(size_t)co * r3 + gv] = o;
+        yb[(size_t)co * r3 + gvv[vb]] = o;
 #endif
       }
-  }
   if (STATS) { // per-tile channel sums, as csrc/conv3d.hip
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)

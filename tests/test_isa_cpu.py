@@ -87,3 +87,22 @@ def test_tap_loops_do_not_touch_scratch_between_mfmas(conv_split_listing):
             elif ln.startswith('scratch_') and 0 < run < per_group:
                 bad += 1
         assert bad == 0, (name, bad)
+
+
+def test_epilogue_stores_are_not_serialized_by_reload_waits(conv_split_listing):
+    """Round 2: with the output computed and stored in one loop the compiler reloaded spilled values between the stores
+    and waited for every reload with vmcnt(0|1) -- which also waits for the stores before it: 18-23 store / wait / store
+    sequences (each a round trip to memory) per epilogue.  With a compute pass and a store pass there are none."""
+    for name, body in list(_kernels(conv_split_listing, "conv3d_split_kernelILi")) + \
+            list(_kernels(conv_split_listing, "conv3d_split_pipe_kernel")):
+        seq = state = 0
+        for ln in body:
+            if re.match(r'(global|buffer|flat)_store', ln):
+                if state == 2:
+                    seq += 1
+                state = 1
+            elif ln.startswith('s_waitcnt') and re.search(r'vmcnt\((0|1)\)', ln) and state == 1:
+                state = 2
+            elif ln.startswith('s_barrier') or ln.startswith('s_endpgm'):
+                state = 0
+        assert seq <= 3, (name, seq)
