@@ -12,8 +12,22 @@ and additionally call ``invalidate_all()``, which advances a process-wide genera
 object: ``StylePlan``, ``GraphedDenoiser``) is validated against; code outside the package that pokes ``.data`` must
 call ``lion_amd.invalidate_weight_caches()`` itself."""
 from collections import OrderedDict
+from contextlib import contextmanager
 
 _GENERATION = 0
+_PIN_LISTS = []   # active `pinning()` lists: every cache value handed out meanwhile is appended to each of them
+
+
+@contextmanager
+def pinning(keep: list):
+    """While active, every value a WeightCache hands out is also appended to `keep`.  A captured graph bakes in raw
+    pointers to the packed / mirrored copies its warm-up and capture passes obtained here; holding `keep` for the graph's
+    lifetime keeps that memory alive (and its addresses unreusable) even after the LRU has evicted the entries."""
+    _PIN_LISTS.append(keep)
+    try:
+        yield keep
+    finally:
+        _PIN_LISTS.remove(keep)
 
 
 def generation() -> int:
@@ -44,8 +58,12 @@ class WeightCache:
         hit = self._entries.get(key)
         if hit is not None and hit[0] == (weight._version, _GENERATION):
             self._entries.move_to_end(key)
+            for keep in _PIN_LISTS:
+                keep.append(hit[2])
             return hit[2]
         value = self._build(weight)
+        for keep in _PIN_LISTS:
+            keep.append(value)
         self._entries[key] = ((weight._version, _GENERATION), weight, value)
         self._entries.move_to_end(key)
         while len(self._entries) > self._capacity:

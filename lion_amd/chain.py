@@ -23,6 +23,15 @@ from . import _lib, _wcache
 DDIM, DDPM = 0, 1
 
 
+def policy_key() -> tuple:
+    """The module-level switches that decide WHICH kernels a forward launches: a captured graph is only valid for the
+    setting it was captured under (flipping one of them re-captures instead of silently replaying the old launches)."""
+    from . import conv_ops, fused_ops
+    from .models import pvcnn2_ada
+    return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, conv_ops.SPLIT,
+            fused_ops.PW_SPLIT)
+
+
 class GraphedChain:
     def __init__(self, model, num_samples, shape, condition_input, clip_feat, device, mode, capacity, warmup=2,
                  record_noise=False):
@@ -39,7 +48,13 @@ class GraphedChain:
         self.seed = torch.zeros(2, dtype=torch.int32, device=dev)   # two 32-bit words of the Philox key
         self.cur = torch.zeros(8, device=dev)
         self.z = torch.zeros(size, device=dev) if record_noise else None   # tests: the noise each step used
-        self.table[:, 0] = 1.0
+        # identity rows until run() uploads a schedule: the warm-up / capture passes must run on finite values (an
+        # all-zero DDPM row is 0/0 -> the second warm-up forward would voxelize NaN latents)
+        self.table[:, 0] = 1.0   # t_model
+        self.table[:, 1] = 1.0   # a0: x passes through
+        self.table[:, 3] = 1.0   # a2: DDPM divisor (DDIM: z has weight 1 -- finite)
+        self.policy = policy_key()
+        self.pinned = []         # strong references to every packed / mirrored weight the captured launches point at
         lib = _lib.load()
 
         def step():
@@ -55,18 +70,20 @@ class GraphedChain:
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(warmup):   # first calls pack weights, set kernel attributes, fill caches
+        with _wcache.pinning(self.pinned):
+            with torch.no_grad(), torch.cuda.stream(side):
+                for _ in range(warmup):   # first calls pack weights, set kernel attributes, fill caches
+                    step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
                 step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            step()
+        self.pinned = list({id(v): v for v in self.pinned}.values())   # one reference per distinct object
 
     def matches(self, condition_input, clip_feat):
         same = lambda buf, new: (buf is None) == (new is None) and (buf is None or buf.shape == new.shape)
         return same(self.cond, condition_input) and same(self.clip, clip_feat) \
-            and self.fingerprint == _wcache.fingerprint(self.model)
+            and self.fingerprint == _wcache.fingerprint(self.model) and self.policy == policy_key()
 
     @torch.no_grad()
     def run(self, x_init, table: np.ndarray, seed: int, condition_input=None, clip_feat=None, trajectory=None,

@@ -72,9 +72,11 @@ def packed_weight(weight):
     return _PACK_CACHE.get(weight)
 
 
-def conv3d_k3(x, weight, bias=None, split=None):
+def conv3d_k3(x, weight, bias=None, split=None, packed=None):
     """x [B,Cin,r,r,r] fp32 -> [B,Cout,r,r,r]; Cin is zero-padded to a multiple of 4 if needed.
-    split: None = the module default (SPLIT), False = the exact-fp32 MFMA kernel, True = split operands if supported."""
+    split: None = the module default (SPLIT), False = the exact-fp32 MFMA kernel, True = split operands if supported.
+    packed: callable(kind) -> the packed copy of `weight` for kind in ("split", "f32"), for callers whose `weight` is a
+    derived temporary and who cache its packed forms under the ORIGINAL parameter (the data-gradient path)."""
     _lib.require_cuda(x)
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = weight.shape[0]
@@ -82,7 +84,7 @@ def conv3d_k3(x, weight, bias=None, split=None):
         x = x.contiguous()
         y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
         bias_c = bias.detach().contiguous() if bias is not None else None
-        wp = split_packed_weight(weight)
+        wp = packed("split") if packed is not None else split_packed_weight(weight)
         _lib.check(_lib.load().lion_conv3d_k3_split_forward(
             _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias_c), b, cin, cout, r, None, None, None, None, _lib.ptr(y), None,
             None, _lib.stream_ptr(x.device)), "conv3d_k3_split_forward")
@@ -94,7 +96,7 @@ def conv3d_k3(x, weight, bias=None, split=None):
     else:
         cin_p = cin
     x = x.contiguous()
-    wp = packed_weight(weight)
+    wp = packed("f32") if packed is not None else packed_weight(weight)
     y = torch.empty((b, cout, r, r, r), device=x.device, dtype=torch.float32)
     bias_c = bias.detach().contiguous() if bias is not None else None
     _lib.check(_lib.load().lion_conv3d_k3_forward(
@@ -120,6 +122,21 @@ def dgrad_weight(weight):
     convolution with the channels swapped and the taps mirrored); its output channels (= Cin) are zero-padded to a
     multiple of 32, the kernel's channel tile (callers slice); cached per (storage, version)."""
     return _DGRAD_CACHE.get(weight)
+
+
+# Packed forms of the MIRROR, cached under the original parameter: keyed on the mirror tensor itself (a temporary that is
+# rebuilt at a new address after every optimizer step) each step would leave one dead mirror + packed entry per layer in
+# the LRU, pinned in HBM until 256 newer entries pushed it out.
+_DGRAD_SPLIT_CACHE = WeightCache(lambda w: _split_pack(dgrad_weight(w)))
+_DGRAD_PACK_CACHE = WeightCache(lambda w: _pack(dgrad_weight(w)))
+
+
+def conv3d_k3_dgrad(gy, weight):
+    """grad_x (with Cin padded to a multiple of 32, callers slice) = conv3d_k3(gy, mirror(weight)); every derived tensor
+    is cached under `weight` (storage, version, generation) and replaced in place when the parameter changes."""
+    wt = dgrad_weight(weight)
+    return conv3d_k3(gy, wt, None,
+                     packed=lambda kind: (_DGRAD_SPLIT_CACHE if kind == "split" else _DGRAD_PACK_CACHE).get(weight))
 
 
 def conv3d_k3_wgrad(x, gy, weight_shape):
@@ -164,7 +181,7 @@ class _Conv3dK3(torch.autograd.Function):
                 gy, x, weight, [weight.shape[0]] if ctx.has_bias else None,
                 [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, lib_mask)
         if own_dgrad:
-            gx = conv3d_k3(gy, dgrad_weight(weight), None)
+            gx = conv3d_k3_dgrad(gy, weight)
             if gx.shape[1] != cin:
                 gx = gx[:, :cin].contiguous()
         if own_wgrad:

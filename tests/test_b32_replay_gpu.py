@@ -1,0 +1,150 @@
+"""-m gpu: the configuration bench.py measures -- B = 32 shapes, hipGraph replay, geometry-prefetch and point-branch side
+streams on, all 256 CUs filled with convolution workgroups -- checked end to end (the B = 2 replay tests of
+test_concurrency_gpu.py / test_chain_gpu.py leave almost every CU to one kernel at a time):
+
+* the whole local denoiser captured once and replayed 40 times == its eager forward, bit for bit;
+* the product sampling chain (lion_amd/chain.py: [begin_step, forward, update + Philox noise] per replay) at B = 32:
+  every replayed step == the eager step on the same state and the same noise, for both priors;
+* one B = 32 PVCNN2Prior forward on the HIP path against the same module evaluated on the host with PyTorch-CPU dense
+  layers and the C oracle's operators (oracle.TorchBackend), at the bound the golden-model tests use.
+Reference: trainers/train_2prior.py:50-127, utils/diffusion_pvd.py:390-473, models/latent_points_ada_localprior.py:72."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fill_
+
+pytestmark = pytest.mark.gpu
+B = 32
+
+
+@pytest.fixture(scope="module")
+def lion32():
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models.lion import LION
+    torch.manual_seed(5)
+    lion = LION(released_prior_cfg("airplane"))
+    lion.priors.eval()
+    lion.vae.eval()
+    return lion
+
+
+def _flat_latents(shape, gen):
+    """latent points squeezed like an airplane (most voxel tiles empty): the sparse plan -- occupancy lists, work queue,
+    wave masks, constant + delta -- does real skipping, as it does on the benchmark's trajectory"""
+    x = torch.randn([B] + shape, device="cuda", generator=gen)
+    v = x.view(B, -1, 4)                           # [B, 2048, 3 coords + 1 feature]
+    v[:, :, 1] *= 0.15
+    v[:, :, 2] *= 0.6
+    return x
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_local_prior_b32_graph_replay_equals_eager(lion32, flat):
+    from lion_amd.models import pvcnn2_ada
+    assert pvcnn2_ada.OVERLAP_POINT_BRANCH and pvcnn2_ada.SPARSE_CONV1 and pvcnn2_ada.FUSE_INFERENCE
+    lion = lion32
+    sh = lion.vae.latent_shape()
+    prior = lion.priors[1]
+    gen = torch.Generator(device="cuda").manual_seed(17 + flat)
+    with torch.no_grad():
+        style = lion.vae.global2style(torch.randn([B] + sh[0], device="cuda", generator=gen))
+        x = _flat_latents(sh[1], gen) if flat else torch.randn([B] + sh[1], device="cuda", generator=gen)
+        tt = torch.full((B,), 500.0, device="cuda")
+
+        def f():
+            return prior(x=x, t=tt, condition_input=style, clip_feat=None).float()
+        ref = f().clone()
+        again = f().clone()
+        assert torch.equal(ref, again), "the eager forward is not deterministic"
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            f()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = f()
+        bad = []
+        for i in range(40):
+            g.replay()
+            torch.cuda.synchronize()
+            if not torch.equal(out, ref):
+                bad.append((i, int((out != ref).sum().item()), ((out - ref).abs().max() / ref.abs().max()).item()))
+        assert not bad, bad
+
+
+def test_sampling_chain_b32_graph_equals_eager_steps(lion32):
+    from lion_amd import chain, diffusion_ops
+    lion, d = lion32, lion32.diffusion
+    S = 4
+    sh = lion.vae.latent_shape()
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    with torch.no_grad():
+        style = lion.vae.global2style(torch.randn([B] + sh[0], device="cuda", generator=gen))
+        for prior, shape, cond in ((lion.priors[0], sh[0], None), (lion.priors[1], sh[1], style)):
+            steps = d.ddim_schedule(1000, S, 'uniform')
+            table = np.zeros((S, 8), np.float32)
+            for i, t in enumerate(steps):
+                table[i, :4] = (t + 1,) + d.ddim_coefficients(t, None if i == S - 1 else steps[i + 1], 1.0)
+            ch = chain.GraphedChain(prior, B, shape, cond, None, "cuda", chain.DDIM, 16, record_noise=True)
+            assert ch.pinned, "the captured chain holds no reference to the packed weights it points at"
+            x0 = torch.randn([B] + shape, device="cuda", generator=gen)
+            for rep in range(3):                     # the same chain three times: replays 1..12 of one capture
+                xs, zs = [], []
+                xf = ch.run(x0, table, 99 + rep, cond, None, trajectory=xs, noise_trajectory=zs)
+                assert len(xs) == S and torch.equal(xf, xs[-1])
+                x = x0
+                for i in range(S):
+                    tt = torch.full((B,), float(table[i, 0]), device="cuda")
+                    eps = prior(x=x, t=tt, condition_input=cond, clip_feat=None).float().contiguous()
+                    want = diffusion_ops.ddim_update(x, eps, zs[i], *[float(v) for v in table[i, 1:4]])
+                    err = (xs[i] - want).abs().max().item() / want.abs().max().item()
+                    assert err <= 2e-6, (rep, i, err)
+                    x = xs[i]
+
+
+def test_product_sampler_b32_runs_twice_identically(lion32):
+    """generate_samples_vada_2prior at B = 32 on the graphed path: same torch seed -> same start, same Philox key ->
+    the same clouds, and they are finite"""
+    from lion_amd.sampling import generate_samples_vada_2prior
+    lion, d = lion32, lion32.diffusion
+    sh = lion.vae.latent_shape()
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        p, _ = generate_samples_vada_2prior(sh, lion.priors, d, lion.vae, B, ddim_step=5)
+        outs.append(p.clone())
+    assert tuple(outs[0].shape) == (B, 2048, 3) and torch.isfinite(outs[0]).all()
+    assert (outs[0] - outs[1]).abs().max().item() <= 1e-3 * outs[0].abs().max().item()
+
+
+def test_local_prior_b32_forward_vs_oracle_backend():
+    """HIP path vs the same module on the host: PyTorch-CPU dense layers + the C oracle's point-voxel operators"""
+    import oracle
+    import lion_amd.functional.backend as bk
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models.latent_points_ada_localprior import PVCNN2Prior
+    cfg = released_prior_cfg("airplane")
+    torch.manual_seed(0)
+    m = PVCNN2Prior(cfg.sde, cfg.shapelatent.latent_dim, cfg)
+    fill_(m)
+    m.eval()
+    x = torch.randn(B, 8192, 1, 1)
+    style = torch.randn(B, 128, 1, 1)
+    t = torch.full((B,), 300.0)
+    saved = bk._backend
+    bk._backend = oracle.TorchBackend()              # the checker: CPU tensors through liboracle.so
+    try:
+        with torch.no_grad():
+            ref = m(x=x, t=t, condition_input=style, clip_feat=None).float().numpy()
+    finally:
+        bk._backend = saved
+    m.cuda()
+    with torch.no_grad():
+        got = m(x=x.cuda(), t=t.cuda(), condition_input=style.cuda(), clip_feat=None).float().cpu().numpy()
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= 2e-4 * max(np.abs(ref).max(), 1.0), (err, np.abs(ref).max())
