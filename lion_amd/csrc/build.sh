@@ -1,13 +1,20 @@
 #!/usr/bin/env bash
 # Builds liblion_hip.so for gfx950 (cross-compiles without a GPU).  -ffp-contract=off: the parity
 # contract is "one IEEE rounding per written operation", same as the oracle.
+# -fno-slp-vectorize: no packed fp32 VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) anywhere in the library.  Round 3
+# located the FPS failures of round 2 there: ONE float2 expression (8 packed instructions) in fps_reg_kernel makes it
+# return wrong samples in 37-40 of 40 graph replays when its waves share SIMDs with conv3d_split_kernel's dense
+# v_mfma_f32_32x32x16_f16 stream; the same kernel without packed fp32 -- with or without s_setprio, at 52, 200 or 256
+# registers -- is right in every one of 100+ replays (profiles/r03_fps_*).  The SLP vectoriser
+# bought nothing measurable anywhere (step, convolutions, 1x1 convolutions, operators: +-1 %) and had inflated
+# fps_reg_kernel<8> from 52 to 194 registers.  tests/test_isa_cpu.py keeps the instruction class out.
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
 OBJS=()
 PIDS=()
-for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise pwconv pwconv_split skinny attention "$@"; do
+for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_split_pc conv3d_wgrad pointwise pwconv pwconv_split skinny attention "$@"; do
   [ -f "$f.hip" ] || continue
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ split_ops.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
     rm -f "$f.o"   # a failed compile must not leave the previous object behind to be linked silently

@@ -17,7 +17,6 @@
 // tie-break word among the lanes that hold the maximum) instead of 64-bit xor-shuffles, which go through the LDS
 // crossbar (ds_bpermute, ~12 dependent LDS round trips per round).
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -59,8 +58,8 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *sx = reinterpret_cast<float4 *>(smem); // [N] {x, y, z, -} copy for the "coords[old]" lookup (one 16-byte read)
   __shared__ unsigned long long wkey[2][4];
-  // 1023 dependent rounds on one workgroup per cloud: pure latency.  The sampler runs this chain on a side stream
-  // under the MFMA convolutions (lion_amd/geometry.py); raise the wave priority so that its few instructions per
+  // 1023 dependent rounds on one workgroup per cloud: pure latency.  When the sampler runs this chain on a side stream
+  // under the MFMA convolutions (lion_amd/geometry.py, optional) the raised wave priority lets its few instructions per
   // round issue ahead of the convolution waves sharing the SIMD instead of queueing behind them.
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -154,22 +153,16 @@ __global__ __launch_bounds__(1024) void fps_lds_kernel(const float *__restrict__
 
 template <int PPT>
 static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx, hipStream_t st) {
-  // The whole LDS of a CU is requested, not the N * 16 bytes the kernel uses: no other LDS-using workgroup can then share
-  // the CU.  Inside a captured sampling step this kernel runs on a side stream beside the convolutions
-  // (lion_amd/geometry.py); when the LDS-DMA convolution workgroups (csrc/conv3d_split.hip) were resident on the same CU
-  // it returned 300-1800 wrong indices of 2048 in nearly every graph replay -- never eagerly, never beside the fp32 or
-  // the register-staged kernels (tools/fps_under_dma.py).  Per-round logs (round 2) showed every wave with the right
-  // previous sample and the right centre, and the running distances of one wave wrong from one of the first rounds on;
-  // checked / repeated LDS reads, a tag-last key exchange and a generic LDS or VGPR self-checking kernel in its place
-  // all failed to locate the cause.  What is known: of the kernels it overlaps with only
-  // conv3d_split_kernel triggers it, and of that kernel only the tap loop's dense v_mfma_f32_32x32x16_f16 stream --
-  // with the MFMAs compiled out (the LDS reads kept) FPS is right in every replay, with only the MFMAs left (no LDS
-  // reads, no DMA, no atomics, no stores, no spills) it is wrong in every replay.
-  // Alone on its CU the kernel is right in every replay; the price is B CUs for the ~0.55 ms of the chain (12 % of the
-  // chip at B = 32).
-  constexpr size_t CU_LDS = 160 * 1024 - 256; // minus the static exchange buffer, rounded
-  static const bool share_cu = getenv("LION_FPS_SHARE_CU") != nullptr; // experiment switch: the round-1 launch (N * 16 bytes)
-  const size_t lds = ((size_t)N * 16 > CU_LDS || share_cu) ? (size_t)N * 16 : CU_LDS;
+  // History.  Round 2: inside a captured sampling step this kernel ran on a side stream beside the
+  // convolutions and returned 300-1800 wrong indices of 2048 per graph replay whenever conv3d_split_kernel workgroups
+  // shared its CUs; it was then given a whole CU's LDS so that nothing could share.  Round 3 named the mechanism with
+  // builds that differ in one property each (tools/victims_beside_conv.py, profiles/r03_fps_variants.txt): the SLP
+  // vectoriser had turned the distance arithmetic into PACKED fp32 VALU (v_pk_add_f32 / v_pk_mul_f32); any build that
+  // contains them -- even a single float2 expression in an otherwise scalar kernel -- fails in 37-40 of 40 replays beside
+  // the fp16-MFMA stream, every build without them (52, 200 or 256 registers, with or without s_setprio) is exact in 100+.
+  // The library is compiled with -fno-slp-vectorize (csrc/build.sh, tests/test_isa_cpu.py), the kernel asks for the
+  // N * 16 bytes it uses, and it shares its CUs again (tests/test_concurrency_gpu.py replays it beside the convolution).
+  const size_t lds = (size_t)N * 16;
   static LionLdsLimit configured = {};
   if (int e = lion_dynamic_lds(&fps_reg_kernel<PPT>, lds, configured)) return e;
   fps_reg_kernel<PPT><<<B, 256, lds, st>>>(coords, N, M, idx);

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # A/B builds of liblion_hip.so: tools/exp/variants/liblion_NAME.so = the current library with some objects replaced.
-#   tools/build_variant.sh NAME  file[@gitrev][:extra hipcc flags]  ...
+#   tools/build_variant.sh NAME  file[@gitrev | =alternative/source.hip][:extra hipcc flags]  ...
 # e.g.  tools/build_variant.sh pre_blind conv3d_split@026d1c7        (that file as of an older commit)
 #       tools/build_variant.sh noslp 'sampling:-fno-slp-vectorize'    (the working-tree file with extra flags)
 # Select at run time with LION_HIP_SO=tools/exp/variants/liblion_NAME.so (lion_amd/_lib.py).  The built .so files are
@@ -19,8 +19,11 @@ PIDS=()
 for spec in "$@"; do
   extra=""; if [[ "$spec" == *:* ]]; then extra="${spec#*:}"; spec="${spec%%:*}"; fi
   rev=""; if [[ "$spec" == *@* ]]; then rev="${spec#*@}"; spec="${spec%%@*}"; fi
+  alt=""; if [[ "$spec" == *=* ]]; then alt="${spec#*=}"; spec="${spec%%=*}"; fi
   src="$TMP/$spec.hip"
-  if [ -n "$rev" ]; then git -C "$ROOT" show "$rev:lion_amd/csrc/$spec.hip" > "$src"; else cp "$CSRC/$spec.hip" "$src"; fi
+  if [ -n "$rev" ]; then git -C "$ROOT" show "$rev:lion_amd/csrc/$spec.hip" > "$src"
+  elif [ -n "$alt" ]; then cp "$alt" "$src"
+  else cp "$CSRC/$spec.hip" "$src"; fi
   # shellcheck disable=SC2086
   $HIPCC $FLAGS $extra -c "$src" -o "$TMP/$spec.o" &
   PIDS+=($!)
