@@ -322,6 +322,8 @@ def main():
                     help="DDIM steps per prior that are timed; 1000 = the metric's real chain (~17 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="shapes per GPU")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed K-step call is repeated this many times; the line reports the MEDIAN (and every run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager per-step launches instead of hipGraph replay")
     ap.add_argument("--no-sparse", action="store_true",
@@ -332,6 +334,7 @@ def main():
     args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn(args)
+    from lion_amd import geometry
     from lion_amd.models import pvcnn2_ada
     if args.no_sparse:
         pvcnn2_ada.SPARSE_CONV1 = False
@@ -381,11 +384,14 @@ def main():
     with torch.no_grad():
         # untimed: W warm-up steps per prior through the same call (captures the two chain graphs once)
         sample(max(W, 1), rank_seed(999, rank))
-        sync_all()
-        t0 = time.perf_counter()
-        pts = sample(K, rank_seed(1234, rank))          # K steps of each chain + one decode: the timed region
-        sync_all()
-        elapsed = time.perf_counter() - t0
+        runs = []
+        for _ in range(args.repeats):                   # the same K-step call, timed `repeats` times: median + spread
+            sync_all()
+            t0 = time.perf_counter()
+            pts = sample(K, rank_seed(1234, rank))      # K steps of each chain + one decode: the timed region
+            sync_all()
+            runs.append(time.perf_counter() - t0)
+        elapsed = sorted(runs)[len(runs) // 2]
         # the decode on its own (once per 1000 steps), to extrapolate honestly when K != 1000
         eps = [torch.randn([B] + shapes[0], device=dev), torch.randn([B] + shapes[1], device=dev)]
         lion.vae.sample(num_samples=B, decomposed_eps=eps)
@@ -397,9 +403,9 @@ def main():
     assert tuple(pts.shape) == (B, 2048, 3)
 
     if world > 1:
-        tt = torch.tensor([elapsed, decode_s], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed, decode_s] + runs, device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, decode_s = float(tt[0]), float(tt[1])
+        elapsed, decode_s, runs = float(tt[0]), float(tt[1]), [float(v) for v in tt[2:]]
     chain_s = max(elapsed - decode_s, 1e-9)
     ms_per_step = chain_s / K * 1e3
     value = world * B / elapsed if K == 1000 else world * B / (1000.0 * ms_per_step / 1e3 + decode_s)
@@ -479,6 +485,10 @@ def main():
                        "shapes_per_gpu": B, "points": 2048, "chain_steps": 1000,
                        "timed_steps_per_prior": K, "extrapolated": K != 1000, "decode_seconds": decode_s,
                        "timed_region_seconds": elapsed,
+                       "timed_region_seconds_all_runs": runs,
+                       "ms_per_step_all_runs": [max(r_ - decode_s, 1e-9) / K * 1e3 for r_ in runs],
+                       "streams": "one stream (geometry prefetch / point-branch side streams: %s / %s)"
+                                  % (geometry.ENABLED, pvcnn2_ada.OVERLAP_POINT_BRANCH),
                        "parallelism": f"{world} independent rank(s), no data-path collective",
                        "launch": "hipGraph replay of [step prologue, denoiser forward, update + Philox noise]" if graph
                                  else "eager",

@@ -26,10 +26,10 @@ DDIM, DDPM = 0, 1
 def policy_key() -> tuple:
     """The module-level switches that decide WHICH kernels a forward launches: a captured graph is only valid for the
     setting it was captured under (flipping one of them re-captures instead of silently replaying the old launches)."""
-    from . import conv_ops, fused_ops
+    from . import conv_ops, fused_ops, geometry
     from .models import pvcnn2_ada
-    return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, conv_ops.SPLIT,
-            fused_ops.PW_SPLIT)
+    return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, geometry.ENABLED,
+            conv_ops.SPLIT, fused_ops.PW_SPLIT)
 
 
 class GraphedChain:

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Builds liblion_hip.so for gfx950 (cross-compiles without a GPU).  -ffp-contract=off: the parity
 # contract is "one IEEE rounding per written operation", same as the oracle.
-# -fno-slp-vectorize: no packed fp32 VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) anywhere in the library.  Round 3
+# -fno-slp-vectorize -fno-vectorize: no packed fp32 VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) anywhere in the library.  Round 3
 # located the FPS failures of round 2 there: ONE float2 expression (8 packed instructions) in fps_reg_kernel makes it
 # return wrong samples in 37-40 of 40 graph replays when its waves share SIMDs with conv3d_split_kernel's dense
 # v_mfma_f32_32x32x16_f16 stream; the same kernel without packed fp32 -- with or without s_setprio, at 52, 200 or 256
@@ -11,10 +11,10 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
 OBJS=()
 PIDS=()
-for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_split_pc conv3d_wgrad pointwise pwconv pwconv_split skinny attention "$@"; do
+for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise pwconv pwconv_split skinny attention "$@"; do
   [ -f "$f.hip" ] || continue
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ split_ops.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
     rm -f "$f.o"   # a failed compile must not leave the previous object behind to be linked silently

@@ -46,6 +46,388 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
   wp[((base + 2 + g) * Cout + co) * 8 + j] = lo;
 }
 
+// "// @phase N" comments mark the phase boundaries that tools/build_timing_lib.sh turns into s_memtime counters in an
+// instrumented COPY of this file (0 item prologue, 1 waits at barriers, 2 load issue + wait + activate + max, 3 max barrier,
+// 4 cut + LDS write, 5 weight hand-off, 6 taps, 7 epilogue); the product build carries no instrumentation and no switches.
+
+template <int TD, int TH, int TW, int CB, int VB, bool PRO, bool STATS, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
+                                                              const float *__restrict__ wtail,
+                                                              const float *__restrict__ bias, float *__restrict__ y,
+                                                              int Cin, int Cout, int r,
+                                                              const float *__restrict__ pro_a,
+                                                              const float *__restrict__ pro_b,
+                                                              const float *__restrict__ pro_bias,
+                                                              const float *__restrict__ tconst,
+                                                              float *__restrict__ stats, int32_t *__restrict__ occ,
+                                                              int B, int ntiles) {
+  constexpr int TM = 256, COT = 32 * CB;
+  static_assert(TD * TH * TW == 4 * VB * 32, "tile voxels = 4 waves x VB column blocks x 32");
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
+  constexpr int HP = (HALO + 63) / 64 * 64;   // plane stride: whole waves, so a staging wave never straddles two planes
+  constexpr int NI = (2 * HP + TM - 1) / TM;  // staging items (k-half, halo position) per thread
+  constexpr int WPL = 4 * COT;                // u4 per weight slice (one tap of one chunk, this channel tile)
+  constexpr int TG = 3;                       // taps per barrier: the weight slices of a (kd, kh) row of taps travel together
+  static_assert(WPL <= TM, "one u4 of a tap's weight slice per thread");
+  static_assert(27 % TG == 0, "whole groups per chunk");
+  static_assert(27 * COT * 4 <= 4 * HP * 16, "the response table must fit the operand planes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u4 *sx = reinterpret_cast<u4 *>(smem);      // [piece][half][HP]
+  u4 *sw = sx + 4 * HP;                       // [2][TG taps][piece][half][COT]
+  float *sbias = reinterpret_cast<float *>(sw + 2 * TG * WPL); // [COT]
+  const int npro = PRO ? ((Cin + 63) & ~63) : 0;
+  float *spa = sbias + COT, *spb = spa + npro, *spc = spb + npro; // prologue scalars / activated constant per channel
+  float *sred = spc + npro;                   // [4][COT][2]
+  float *sT = reinterpret_cast<float *>(sx);  // [27][COT] constant response (delta mode), loaded after the K loop
+  __shared__ int s_work;
+  __shared__ unsigned s_max[2];               // bits of the chunk's max |activation| (double buffered over chunks)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, l32 = lane & 31;
+  const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_wscale_kernel)
+  const bool queued = occ != nullptr;
+  const int ncz = Cout / COT;
+  // @phase-init
+  for (int iter = 0;; ++iter) {
+  int b, tile, co0;
+  if (queued) { // see csrc/conv3d.hip: occ = [B*tiles wave masks][B*tiles list, occupied tiles first][queue counter]
+    __syncthreads();
+    if (tid == 0) s_work = atomicAdd(occ + 2 * B * ntiles, 1);
+    __syncthreads();
+    const int work = s_work;
+    if (work >= B * ntiles * ncz) break;
+    const int item = work / ncz;
+    b = item % B;
+    tile = occ[B * ntiles + b * ntiles + item / B];
+    co0 = (work % ncz) * COT;
+  } else {
+    if (iter) break;
+    b = blockIdx.x;
+    tile = blockIdx.y;
+    co0 = blockIdx.z * COT;
+  }
+  const int ntw = r / TW, nth = r / TH;
+  const int d0 = (tile / (ntw * nth)) * TD, h0 = ((tile / ntw) % nth) * TH, w0 = (tile % ntw) * TW;
+  const int r3 = r * r * r;
+  const bool pro_on = PRO && pro_a != nullptr; // the PRO instantiation also serves launches without a prologue (see
+  const bool delta = pro_on && tconst != nullptr; // launch_split_t: its register allocation is the better one)
+  if (pro_on) {
+    for (int c = tid; c < Cin; c += TM) {
+      const float pa = pro_a[(size_t)b * Cin + c], pb = pro_b[(size_t)b * Cin + c];
+      spa[c] = pa;
+      spb[c] = pb;
+      spc[c] = delta ? pro_act(pro_bias ? pro_bias[c] : 0.f, pa, pb) : 0.f;
+    }
+  }
+  for (int c = tid; c < COT; c += TM) sbias[c] = bias ? bias[co0 + c] : 0.f;
+  if (tid < 2) s_max[tid] = 0u;
+  int E = 127; // exponent of the tile's activation scale 2^E; 127 = none yet (everything staged so far was zero)
+
+  // staging items: item = tid + 256 i -> k-half item / HP (wave uniform), halo position item % HP.  Positions past
+  // HALO are padding; positions outside the grid carry an offset beyond num_records, for which buffer loads return 0.
+  int goff[NI];
+  bool gok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int item = tid + TM * i, p = item % HP;
+    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+    const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+    gok[i] = item < 2 * HP && p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+    goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
+
+  // halo position of this lane's voxel in each of the wave's column blocks (v = (wave*VB + vb)*32 + lane%32)
+  int xbase[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    const int v = (wave * VB + vb) * 32 + l32;
+    const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+    xbase[vb] = (d * HH + h) * HW + w;
+  }
+  f32x16 acc[CB][VB], cor[CB][VB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][vb][i] = cor[cb][vb][i] = 0.f;
+
+  const int wmask = queued ? occ[b * ntiles + tile] : 0xf;
+  const bool empty = wmask == 0;
+  const bool wave_on = (wmask >> wave) & 1;
+  const int nchunks = empty ? 0 : Cin / KS;
+  // this thread's u4 of a weight slice: element (pg, co) of the tile <- global [pg][Cout] at co0 + co
+  const int we_g = (tid / COT) * Cout + co0 + (tid % COT);
+  const bool w_thread = tid < WPL;
+  // weight slices travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction lands at
+  // M0 + lane * 16), one group of TG taps ahead of their use, into the buffer the group before last was read from.  No
+  // registers and no VALU on the way: the register ring this replaces cost 12 VGPRs at the 256-register limit (87
+  // spills), and the compiler was free to sink its loads next to their LDS writes (s_memtime phase counters: 29 % of a
+  // wave's cycles went into waiting for them).  The DMA is issued right behind the group barrier and awaited (vmcnt 0)
+  // in front of the next one.
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const uint32_t sw_lds = (uint32_t)(uintptr_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw) + (uint32_t)wave * 1024u;
+  auto weights_dma = [&](int sg) { // group sg of the K walk (chunk sg / 9, taps (sg % 9) * TG ..) -> buffer sg & 1
+    if (w_thread) {                // wave uniform: WPL is a multiple of 64
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        // the BUILTIN, not inline asm: the compiler must know that three more VM operations are in flight.  With an asm
+        // DMA its wait for the scratch reloads of the tap loop's addresses (issued in front of the barrier, waited for
+        // at first use) was vmcnt(0), which -- memory operations retire in order -- also waited for the DMA: 27 of the
+        // 30 DMA instructions of this kernel were drained before the first MFMA of their group, every group began with
+        // the round trip of the NEXT group's slices (tools/dma_drain_check.py; found statically at the end of round 2,
+        // NOT yet measured on the GPU).  With the builtin the same wait is vmcnt(3) and the DMA flies under the taps.
+        const u4 *gp = wp + ((size_t)sg * TG + t) * 4 * Cout + we_g;
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef __attribute__((address_space(1))) const void glb_void;
+        lds_void *dstp = (lds_void *)(uintptr_t)__builtin_amdgcn_readfirstlane(sw_lds + (uint32_t)(((sg & 1) * TG + t) * WPL * 16));
+        __builtin_amdgcn_global_load_lds((glb_void *)gp, dstp, 16, 0, 0);
+      }
+    }
+  };
+  if (nchunks) weights_dma(0);
+  // @phase 0
+  for (int q = 0; q < nchunks; ++q) {
+    __syncthreads(); // the previous chunk's planes are no longer read (and the prologue scalars are visible)
+    // @phase 1
+    {
+    // all loads of the chunk first (one memory round trip per chunk), then activate, agree on the scale, cut + write
+    float v[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int ig = __builtin_amdgcn_readfirstlane(min((tid + TM * i) / HP, 1));
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, goff[i], (q * KS + ig * 8 + j) * r3 * 4, 0));
+    }
+    unsigned mloc = 0u;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = tid + TM * i;
+      const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1));
+      // the 8 channels' prologue scalars: three pairs of 16-byte broadcast reads per item (wave-uniform address) instead
+      // of 24 dword reads, and the activation computed unconditionally with a select behind it -- `gok ? act : 0` had
+      // become one branch per value (ISA: 56 s_cbranch_execz per chunk)
+      float pa8[8], pb8[8], pc8[8];
+      if (pro_on) {
+        const int c0 = q * KS + ig * 8;
+        const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), a1 = *reinterpret_cast<const float4 *>(spa + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(spb + c0), b1 = *reinterpret_cast<const float4 *>(spb + c0 + 4);
+        const float4 c4 = *reinterpret_cast<const float4 *>(spc + c0), c5 = *reinterpret_cast<const float4 *>(spc + c0 + 4);
+        pa8[0] = a0.x; pa8[1] = a0.y; pa8[2] = a0.z; pa8[3] = a0.w; pa8[4] = a1.x; pa8[5] = a1.y; pa8[6] = a1.z; pa8[7] = a1.w;
+        pb8[0] = b0.x; pb8[1] = b0.y; pb8[2] = b0.z; pb8[3] = b0.w; pb8[4] = b1.x; pb8[5] = b1.y; pb8[6] = b1.z; pb8[7] = b1.w;
+        pc8[0] = c4.x; pc8[1] = c4.y; pc8[2] = c4.z; pc8[3] = c4.w; pc8[4] = c5.x; pc8[5] = c5.y; pc8[6] = c5.z; pc8[7] = c5.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = v[i][j];
+        if (pro_on) { // zero padding stays zero; delta mode stages the deviation from the per-channel constant
+          const float act = pro_act(t, pa8[j], pb8[j]) - pc8[j];
+          t = gok[i] ? act : 0.f;
+          v[i][j] = t;
+        }
+        const unsigned a = __float_as_uint(t) & 0x7fffffffu; // |t| as ordered bits; inf / nan do not set the scale:
+        mloc = (item < 2 * HP && a > mloc && a <= 0x7f7fffffu) ? a : mloc; // they pass through the cut as inf / nan
+      }
+    }
+    mloc = wave_max_u32_lane63(mloc);
+    if (lane == 63 && mloc) atomicMax(&s_max[q & 1], mloc);
+    // @phase 2
+    __syncthreads(); // the chunk's maximum is complete
+    // @phase 3
+    const unsigned mbits = s_max[q & 1];
+    if (tid == 0) s_max[(q + 1) & 1] = 0u; // its last readers passed the barrier at the top of this chunk
+    if (mbits) {
+      const int e = scale_exp(__uint_as_float(mbits));
+      if (e < E) { // the tile's maximum grew: bring what has been accumulated onto the new (smaller) scale first
+        if (E != 127) {
+          const float f = pow2f(max(e - CONV_SPLIT_HEADROOM - E, -126));
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) { acc[cb][vb][i] *= f; cor[cb][vb][i] *= f; }
+        }
+        E = e - CONV_SPLIT_HEADROOM;
+      }
+    }
+    const float xs = E == 127 ? 1.0f : pow2f(E);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = tid + TM * i;
+      const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1)), p = item - ig * HP;
+      unsigned short hi[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cut(v[i][j] * xs, hi[j], lo[j]);
+      u4 ph, pl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ph[k] = (unsigned)hi[2 * k] | ((unsigned)hi[2 * k + 1] << 16);
+        pl[k] = (unsigned)lo[2 * k] | ((unsigned)lo[2 * k + 1] << 16);
+      }
+      if (item < 2 * HP) { // wave uniform
+        sx[(0 + ig) * HP + p] = ph;
+        sx[(2 + ig) * HP + p] = pl;
+      }
+    }
+    }
+    // @phase 4
+    // 27 taps in 9 groups of TG, ONE barrier per group: behind it the group's weight slices (DMA issued a group ago,
+    // awaited just before) and -- for the first group -- the chunk's operand planes are visible, and the buffer of the
+    // group before is free for the DMA of the next one.
+#pragma unroll
+    for (int grp = 0; grp < 27 / TG; ++grp) {
+      const int sg = q * (27 / TG) + grp;
+      const u4 *swg = sw + (sg & 1) * TG * WPL;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // @phase 1
+      __syncthreads();
+      // @phase 5
+      if (sg + 1 < nchunks * (27 / TG)) weights_dma(sg + 1);
+      if (wave_on) {
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          const int tap = grp * TG + t;
+          const u4 *swb = swg + t * WPL;
+          const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+          u4 wf[CB][2], xf[VB][2];
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) wf[cb][pc] = swb[(pc * 2 + g) * COT + cb * 32 + l32];
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = sx[(pc * 2 + g) * HP + xbase[vb] + toff];
+          }
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) {
+              acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
+              cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
+              cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
+            }
+        }
+      }
+      // @phase 6
+    }
+  }
+
+  if (delta) {
+    __syncthreads(); // the last tap's LDS reads are done: the operand planes become the response table
+    for (int e = tid; e < 27 * COT; e += TM) sT[e] = tconst[((size_t)b * 27 + e / COT) * Cout + co0 + e % COT];
+    __syncthreads();
+  } else if (empty) {
+    __syncthreads(); // sbias was written by other threads and no barrier of the K loop ran
+  }
+  // epilogue: D = main + corr/2048 (+ bias | constant response), NCDHW store.  acc register i of lane l: channel row
+  // (i&3) + 8*(i>>2) + 4*(l>>5), voxel column l&31.
+  float *yb = y + ((size_t)b * Cout + co0) * r3;
+  const float us_x = E == 127 ? 1.0f : pow2f(-E), us_w = wscale_inv; // exact powers of two
+  // two passes: every output value first (the accumulators become the outputs), then NOTHING BUT stores.  In one loop
+  // the compiler reloaded spilled values between the stores and waited for each reload with vmcnt(0|1) -- which also
+  // waits for the stores issued before it: 18-23 store / wait / store sequences per epilogue (tools/store_wait_scan.py),
+  // each a round trip to memory.
+  int gvv[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    const int v = (wave * VB + vb) * 32 + l32;
+    const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+    const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
+    gvv[vb] = (gd * r + gh) * r + gw;
+    const int cfg = (((gd == 0 ? 0 : gd == r - 1 ? 2 : 1) * 3 + (gh == 0 ? 0 : gh == r - 1 ? 2 : 1)) * 3 +
+                     (gw == 0 ? 0 : gw == r - 1 ? 2 : 1));
+    const float *addv = delta ? sT + cfg * COT : sbias;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+        acc[cb][vb][i] = ((acc[cb][vb][i] + cor[cb][vb][i] * (1.f / 2048.f)) * us_x) * us_w + addv[co];
+      }
+  }
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+        const float o = acc[cb][vb][i];
+        yb[(size_t)co * r3 + gvv[vb]] = o;
+      }
+  if (STATS) { // per-tile channel sums, as csrc/conv3d.hip
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float s1 = acc[cb][0][i], s2 = acc[cb][0][i] * acc[cb][0][i];
+#pragma unroll
+        for (int vb = 1; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
+        s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+        s1 = row_pair_sum_odd_rows(s1); s2 = row_pair_sum_odd_rows(s2);
+        if (l32 == 16) { // the row pair's sum lives in the odd rows
+          const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+          sred[(wave * COT + co) * 2] = s1;
+          sred[(wave * COT + co) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < COT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
+      float *o = stats + (((size_t)b * Cout + co0 + tid) * ntiles + tile) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+  // @phase 7
+  } // work loop
+  // @phase-flush
+}
+
+template <int TD, int TH, int TW, int CB, int VB, int OCC>
+static int launch_split_t(const float *x, const u4 *wp, const float *wtail, const float *bias, float *y, int B, int Cin,
+                          int Cout, int r,
+                          const float *pa, const float *pb, const float *pbias, const float *tconst, float *stats,
+                          int32_t *occ, hipStream_t st) {
+  constexpr int COT = 32 * CB;
+  constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2), HP = (HALO + 63) / 64 * 64;
+  const int tiles = (r / TD) * (r / TH) * (r / TW);
+  static int cu_count[LION_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (int e = lion_current_device(&dev)) return e;
+  if (!cu_count[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LION_EINVAL;
+    cu_count[dev] = prop.multiProcessorCount;
+  }
+  const long items = (long)B * tiles * (Cout / COT);
+  const long resident = (long)OCC * cu_count[dev];
+  const dim3 grid = occ ? dim3((unsigned)(items < resident ? items : resident)) : dim3(B, tiles, Cout / COT);
+  // (PRO = false, STATS = true) of the 64-channel tile gets 556-568 bytes of scratch from the register allocator where
+  // (true, true) gets 304-360: launches with statistics and without a prologue run on the PRO instantiation with the
+  // prologue switched off at run time (pro_a == nullptr)
+  const bool pro_inst = pa != nullptr || (stats != nullptr && CB == 2 && Cin <= 256);
+  const size_t LDS = (size_t)(4 * HP + 2 * 3 * 4 * COT) * 16 + // planes + two groups of 3 taps of weight slices
+                     (size_t)(COT + (pro_inst ? 3 * ((Cin + 63) & ~63) : 0) + 4 * COT * 2) * 4;
+#define LION_SPLIT_GO(PRO_, ST_)                                                                             \
+  {                                                                                                          \
+    static LionLdsLimit cfg = {};                                                                            \
+    if (int e = lion_dynamic_lds(&conv3d_split_kernel<TD, TH, TW, CB, VB, PRO_, ST_, OCC>, LDS, cfg)) return e;   \
+    conv3d_split_kernel<TD, TH, TW, CB, VB, PRO_, ST_, OCC><<<grid, 256, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, r, pa, pb, \
+                                                                              pbias, tconst, stats, occ, B, tiles); \
+  }
+  if (pro_inst && stats) LION_SPLIT_GO(true, true)
+  else if (pa) LION_SPLIT_GO(true, false)
+  else if (stats) LION_SPLIT_GO(false, true)
+  else LION_SPLIT_GO(false, false)
+#undef LION_SPLIT_GO
+  LION_LAUNCH_CHECK();
+  return 0;
+}
 
 // ---- r = 8: the pipelined form -------------------------------------------------------------------------------------
 // A sample has only 512 voxels, so B * Cout / 32 half-sample tiles (256 voxels x 32 channels) are all the work there is:
@@ -103,6 +485,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
   if (tid < COT) sbias[tid] = bias ? bias[co0 + tid] : 0.f;
   if (tid < 2) s_max[tid] = 0u;
   int E = 127;
+  // @phase-init
 
   int goff[NI];
   bool gok[NI];
@@ -225,6 +608,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
   issue_loads(0);
   __syncthreads(); // prologue scalars, s_max = 0
   stage(0);
+  // @phase 0
   for (int q = 0; q < nchunks; ++q) {
     const u4 *sxq = sx + (q & 1) * 4 * HP;
     const bool more = q + 1 < nchunks;
@@ -236,7 +620,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
       const bool dma_behind = sg + 1 < ngroups;
       if (grp == 0 || !more) { if (dma_behind) wait_vm<DMA_MIN>(); else wait_vm<0>(); }
       else { if (dma_behind) wait_vm<DMA_MIN + NI * 8>(); else wait_vm<NI * 8>(); }
+      // @phase 1
       __syncthreads(); // slices of group sg and (grp 0) the planes of chunk q visible; ring slot of group sg - 1 free
+      // @phase 5
       if (sg + 2 < ngroups) weights_dma(sg + 2);
       if (grp == 0 && more) issue_loads(q + 1);
       const u4 *swg = sw + (sg % 3) * TG * WPL;
@@ -264,8 +650,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      // @phase 6
     }
     if (more) stage(q + 1); // plane buffer (q + 1) & 1: last read by the taps of chunk q - 1, two barriers ago
+    // @phase 4
   }
 
   float *yb = y + ((size_t)b * Cout + co0) * r3;
@@ -303,6 +691,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
       o[1] = s2;
     }
   }
+  // @phase 7
+  // @phase-flush
 }
 
 template <int NW>
@@ -363,11 +753,11 @@ int lion_conv3d_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *
   return 0;
 }
 
+// @phase-reader
 
 int lion_conv3d_split_stat_tiles(int r, int Cout) {
   if (r != 8 && r != 16 && r != 32) return 0;
-  const int tiles = split_plan(r, Cout).tiles;
-  return r == 8 ? tiles : 4 * tiles; // r >= 16 (csrc/conv3d_split_pc.hip): one entry per (tile, wave quarter of 64 voxels)
+  return split_plan(r, Cout).tiles;
 }
 
 // Arguments exactly as lion_conv3d_k3_fused_forward (include/lion_hip.h), wp from lion_conv3d_split_pack_weights;
@@ -392,7 +782,16 @@ int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float
     if (tconst) return LION_EUNSUPPORTED;
     return launch_split_pipe<8>(x, w4, wtail, bias, y, B, Cin, Cout, pro_a, pro_b, stats, st);
   }
-  return lion_split_pc_launch(x, wp, wtail, bias, y, B, Cin, Cout, r, pro_a, pro_b, pro_bias, tconst, stats, occ, st);
+#define LION_SPLIT_TILE(R_, VB_, CB_, TD_, TH_, TW_, OCC_)                                                  \
+  if (r == R_ && p.vb == VB_ && p.cb == CB_)                                                                \
+    return launch_split_t<TD_, TH_, TW_, CB_, VB_, OCC_>(x, w4, wtail, bias, y, B, Cin, Cout, r, pro_a, pro_b, pro_bias, tconst, \
+                                                   stats, occ, st);
+  LION_SPLIT_TILE(32, 2, 2, 2, 4, 32, 2)
+  LION_SPLIT_TILE(32, 2, 1, 2, 4, 32, 2)
+  LION_SPLIT_TILE(16, 2, 2, 4, 4, 16, 2)
+  LION_SPLIT_TILE(16, 2, 1, 4, 4, 16, 2)
+#undef LION_SPLIT_TILE
+  return LION_EUNSUPPORTED;
 }
 
 } // extern "C"

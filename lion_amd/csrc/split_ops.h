@@ -4,13 +4,6 @@
 #pragma once
 #include "common.h"
 
-// the r >= 16 kernel lives in its own translation unit (csrc/conv3d_split_pc.hip); the C entry point in conv3d_split.hip
-__attribute__((visibility("hidden"))) int lion_split_pc_launch(const float *x, const void *wp, const float *wtail,
-                                                               const float *bias, float *y, int B, int Cin, int Cout, int r,
-                                                               const float *pa, const float *pb, const float *pbias,
-                                                               const float *tconst, float *stats, int32_t *occ,
-                                                               hipStream_t st);
-
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));

@@ -23,8 +23,9 @@ from .. import fused_ops
 FUSE_INFERENCE = True  # module-level switch (tests compare the fused and the layer-by-layer paths)
 # conv1 of a PVConv reads the voxelised grid: skip (exactly) the tiles whose halo holds no point
 SPARSE_CONV1 = True
-# run the point branch of a PVConv on a second stream, concurrently with its voxel branch (inference)
-OVERLAP_POINT_BRANCH = os.environ.get("LION_OVERLAP_POINT_BRANCH", "1") != "0"
+# run the point branch of a PVConv on a second stream, concurrently with its voxel branch (inference).  Off by default:
+# as a parallel branch of the captured step it costs 0.5 ms per step (lion_amd/geometry.py has the measurements)
+OVERLAP_POINT_BRANCH = os.environ.get("LION_OVERLAP_POINT_BRANCH", "0") != "0"
 _POINT_STREAMS = {}
 
 

@@ -1,6 +1,7 @@
-"""-m gpu: the configuration bench.py measures -- B = 32 shapes, hipGraph replay, geometry-prefetch and point-branch side
-streams on, all 256 CUs filled with convolution workgroups -- checked end to end (the B = 2 replay tests of
-test_concurrency_gpu.py / test_chain_gpu.py leave almost every CU to one kernel at a time):
+"""-m gpu: the configuration bench.py measures -- B = 32 shapes, hipGraph replay, all 256 CUs filled with convolution
+workgroups -- checked end to end, on one stream (the default since round 3) AND with the geometry-prefetch and
+point-branch side streams on (the B = 2 replay tests of test_concurrency_gpu.py / test_chain_gpu.py leave almost every CU
+to one kernel at a time):
 
 * the whole local denoiser captured once and replayed 40 times == its eager forward, bit for bit;
 * the product sampling chain (lion_amd/chain.py: [begin_step, forward, update + Philox noise] per replay) at B = 32:
@@ -39,10 +40,23 @@ def _flat_latents(shape, gen):
     return x
 
 
-@pytest.mark.parametrize("flat", [False, True])
-def test_local_prior_b32_graph_replay_equals_eager(lion32, flat):
+@pytest.fixture(params=[False, True], ids=["one-stream", "side-streams"])
+def streams(request):
+    """False: the default (and benchmarked) configuration, every kernel of the step on one stream; True: geometry
+    prefetch + point branch on side streams (LION_GEOMETRY_PREFETCH=1 LION_OVERLAP_POINT_BRANCH=1) -- FPS, ball query,
+    grouping and the 1x1 convolutions then run BESIDE the fp16-MFMA convolutions and share their CUs"""
+    from lion_amd import geometry
     from lion_amd.models import pvcnn2_ada
-    assert pvcnn2_ada.OVERLAP_POINT_BRANCH and pvcnn2_ada.SPARSE_CONV1 and pvcnn2_ada.FUSE_INFERENCE
+    saved = (geometry.ENABLED, pvcnn2_ada.OVERLAP_POINT_BRANCH)
+    geometry.ENABLED = pvcnn2_ada.OVERLAP_POINT_BRANCH = request.param
+    yield request.param
+    geometry.ENABLED, pvcnn2_ada.OVERLAP_POINT_BRANCH = saved
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_local_prior_b32_graph_replay_equals_eager(lion32, flat, streams):
+    from lion_amd.models import pvcnn2_ada
+    assert pvcnn2_ada.SPARSE_CONV1 and pvcnn2_ada.FUSE_INFERENCE
     lion = lion32
     sh = lion.vae.latent_shape()
     prior = lion.priors[1]
@@ -76,7 +90,7 @@ def test_local_prior_b32_graph_replay_equals_eager(lion32, flat):
         assert not bad, bad
 
 
-def test_sampling_chain_b32_graph_equals_eager_steps(lion32):
+def test_sampling_chain_b32_graph_equals_eager_steps(lion32, streams):
     from lion_amd import chain, diffusion_ops
     lion, d = lion32, lion32.diffusion
     S = 4

@@ -1,14 +1,34 @@
 #!/usr/bin/env bash
-# tools/exp/liblion_timing.so = liblion_hip.so with the s_memtime phase counters of the split-operand kernels compiled in
-# (-DSPLIT_EXP_TIMING: csrc/conv3d_split.hip, -DPWS_TIMING: csrc/pwconv_split.hip).  Run the readers with
+# tools/exp/liblion_timing.so = liblion_hip.so with s_memtime phase counters compiled into an instrumented COPY of
+# csrc/conv3d_split.hip (the product file only carries "// @phase N" comments at the phase boundaries) and the -DPWS_TIMING
+# build of csrc/pwconv_split.hip.  Run the readers with
 #   LION_HIP_SO=$PWD/tools/exp/liblion_timing.so python tools/conv_phase_times.py | tools/pw_phase_times.py
 # The counters stay in registers until a workgroup ends: a memory operation per mark would sit in front of every vmcnt wait
 # of the kernel and be measured instead of it.
 set -euo pipefail
-cd "$(dirname "$0")/../lion_amd/csrc"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$ROOT/lion_amd/csrc"
 bash build.sh > /dev/null
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I../../include"
-/opt/rocm/bin/hipcc $F -DSPLIT_EXP_TIMING -c conv3d_split.hip -o /tmp/lion_cs_timing.o
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -munsafe-fp-atomics -I../../include -I."
+python3 - <<'PY'
+import re
+s = open("conv3d_split.hip").read()
+hdr = '''
+__device__ unsigned long long g_split_phase[8];
+#define PH_MARK(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); ph_acc[k] += (unsigned)(n_ - t_ph); t_ph = n_; } while (0)
+'''
+s = s.replace('namespace {\n', 'namespace {\n' + hdr, 1)
+s = s.replace('// @phase-init', 'unsigned long long t_ph = __builtin_readcyclecounter(); unsigned ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};')
+s = s.replace('// @phase-flush', 'if (tid == 0) for (int kk_ = 0; kk_ < 8; ++kk_) atomicAdd(&g_split_phase[kk_], (unsigned long long)ph_acc[kk_]);')
+s = re.sub(r'// @phase (\d)', r'PH_MARK(\1);', s)
+s = s.replace('// @phase-reader', '''int lion_debug_split_phases(unsigned long long *host8, int reset) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_split_phase), 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_phase), z, 64) != hipSuccess) return -1; }
+  return 0;
+}''')
+open("/tmp/lion_conv3d_split_timing.hip", "w").write(s)
+PY
+/opt/rocm/bin/hipcc $F -c /tmp/lion_conv3d_split_timing.hip -o /tmp/lion_cs_timing.o
 /opt/rocm/bin/hipcc $F -DPWS_TIMING -c pwconv_split.hip -o /tmp/lion_pws_timing.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/liblion_timing.so \
   $(ls *.o | grep -v -e '^conv3d_split.o$' -e '^pwconv_split.o$') /tmp/lion_cs_timing.o /tmp/lion_pws_timing.o

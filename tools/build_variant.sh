@@ -13,7 +13,7 @@ NAME="$1"; shift
 OUT="$ROOT/tools/exp/variants"; mkdir -p "$OUT"
 TMP="$(mktemp -d)"; trap 'rm -rf "$TMP"' EXIT
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I$ROOT/include -I$CSRC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -munsafe-fp-atomics -I$ROOT/include -I$CSRC -Wall -Wno-unused-function"
 declare -A REPL
 PIDS=()
 for spec in "$@"; do

@@ -65,7 +65,7 @@ struct PcCtl {
 // and the quarter's GroupNorm sums.  acc register i of lane l: channel row (i & 3) + 8 (i >> 2) + 4 (l >> 5), voxel
 // column l & 31.  ZERO: a tile without points -- the accumulators are zero by definition, the output is the addend.
 // addend(cfg, co): bias[co] or the constant response of border configuration cfg (delta mode).
-template <int TD, int TH, int TW, int CB, bool STATS, bool ZERO, typename Addend>
+template <int TD, int TH, int TW, int CB, bool STATS, bool ZERO, bool STORE = true, typename Addend>
 __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[CB][2], f32x16 (&cor)[CB][2], float us_x, float us_w, Addend addend,
                                             int wq, int lane, float *__restrict__ yb, int r, int d0, int h0, int w0,
                                             float *__restrict__ st, int st_cstride) {
@@ -130,13 +130,15 @@ __device__ __forceinline__ void pc_epilogue(f32x16 (&acc)[CB][2], f32x16 (&cor)[
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (STORE) {
 #pragma unroll
-    for (int vb = 0; vb < 2; ++vb)
+      for (int vb = 0; vb < 2; ++vb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float *yc = yb + (size_t)(cb * 32 + (i & 3) + 8 * (i >> 2)) * r3; // uniform
-        yc[voff[vb]] = acc[cb][vb][i];
-      }
+        for (int i = 0; i < 16; ++i) {
+          float *yc = yb + (size_t)(cb * 32 + (i & 3) + 8 * (i >> 2)) * r3; // uniform
+          yc[voff[vb]] = acc[cb][vb][i];
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -216,50 +218,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_split_pc_kernel(const float *__
     bool ended = false;    // the ring walk has reached the end-of-stream entry
     int npop = 0;          // pops done (static work assignment)
     bool pop_done = false; // the leader has published the end of the stream
+    bool pending = false;  // the loads of job pj are in flight (requested at the end of the previous step)
     // current item of the staging (valid while q < nchunks)
     int ib = 0, itile = 0, ico0 = 0, q = nchunks, d0 = 0, h0 = 0, w0 = 0, E = 127;
-    float v[NI][8][4]; // [item][channel][position]: loaded in slice 0, activated in slices 2-5, cut in slices 6-8
+    float v[NI][8][4]; // [item][channel][voxel of the group]
     const int rt_entry = rt;
     for (int s = 0;; ++s) {
       if (s >= ctl->exit_step) break;
-      const int tail = ctl->tail;
       // everything derived from the thread index is recomputed per step from an opaque copy: hoisted to the kernel entry
       // it would stay alive through the consumers' code as well (one register allocation for both roles)
       int rt = rt_entry;
       asm volatile("" : "+v"(rt));
-      // ---- slice 0: next job -> item prologue, addresses, all loads of the chunk
-      bool have = false;
-      if (q < nchunks) have = true;
-      else if (!ended) {
-        // walk to the next non-empty entry (the tiles without points passed on the way are written in slice 1, one per
-        // step, behind the fill head pf)
-        while (ph < tail && pc_ring_read(ring, ph).wmask == 0) ++ph;
-        if (ph < tail) {
-          const PcItem it = pc_ring_read(ring, ph);
-          if (it.wmask < 0) ended = true;
-          else {
-            ib = it.b; itile = it.tile; ico0 = it.co0; q = 0; E = 127; ++ph;
-            d0 = (itile / (ntw * nth)) * TD; h0 = ((itile / ntw) % nth) * TH; w0 = (itile % ntw) * TW;
-            have = true;
-            if (pro_on)
-              for (int c = rt; c < Cin; c += TM) {
-                const float pa = pro_a[(size_t)ib * Cin + c], pb = pro_b[(size_t)ib * Cin + c];
-                spa[c] = pa;
-                spb[c] = pb;
-                spc[c] = delta ? pro_act(pro_bias ? pro_bias[c] : 0.f, pa, pb) : 0.f;
-              }
-            float *sa = sadd + (nitem % 3) * add_rows * COT; // read by the consumers' epilogue >= 1 step later
-            for (int e = rt; e < add_rows * COT; e += TM)
-              sa[e] = delta ? tconst[((size_t)ib * 27 + e / COT) * Cout + ico0 + e % COT] : (bias ? bias[ico0 + e] : 0.f);
-            ++nitem;
-          }
-        }
-      }
-      if (have && rt == 0) ctl->planned = pj + 1;
       // item = rt + 256 i -> k-half item / IH (wave uniform), row (item % IH) / GR, group (item % IH) % GR.  Rows outside
       // the grid carry an offset beyond num_records: the loads return 0.
-      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float *>(x + (size_t)ib * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
       struct Geo { int ig, p0, goff; bool live, rowok; };
       auto geo = [&](int i) {
         const int item = rt + TM * i;
@@ -274,27 +245,124 @@ __global__ __launch_bounds__(512, 2) void conv3d_split_pc_kernel(const float *__
         gq.goff = gq.rowok ? ((gd * r + gh) * r + grp * 4) * 4 : 0x7fffff00;
         return gq;
       };
-      auto issue = [&](int i) { // the 8 channels x 4 voxels of item i
-        const Geo gq = geo(i);
+      const bool have = pending;
+      u4 *dst = sx + (pj & 1) * 4 * HP;
+      // ---- slices 0-5: activation (AdaGN + Swish of the previous convolution, delta form) and the chunk maximum, the 16
+      // (item, channel) rows of 4 voxels dealt 3 3 3 3 2 2 over the slices -- each lighter than the consumers' three taps
+      // between two barriers, so that the matrix pipe does not wait for a slice (the loads were requested a step ago)
+      unsigned mloc = 0u;
+      auto activate = [&](int row0, int row1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const u4 t4 = __builtin_amdgcn_raw_buffer_load_b128(xrs, gq.goff, (q * KS + gq.ig * 8 + j) * r3 * 4, 0);
+        for (int rw = row0; rw < row1; ++rw) {
+          const int i = rw / 8, j = rw % 8;
+          const Geo gq = geo(i);
+          float pa = 0.f, pb = 0.f, pc = 0.f;
+          if (pro_on) { // broadcast reads of the channel's prologue scalars (wave-uniform address)
+            const int c = q * KS + gq.ig * 8 + j;
+            pa = spa[c]; pb = spb[c]; pc = spc[c];
+          }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[i][j][k] = __uint_as_float(t4[k]);
+          for (int k = 0; k < 4; ++k) {
+            // zero padding stays zero; delta mode stages the deviation from the per-channel constant; the activation
+            // unconditionally with a select behind it (a branch per value otherwise)
+            const float t = pro_on ? pro_act(v[i][j][k], pa, pb) - pc : v[i][j][k];
+            const float u = gq.rowok ? t : 0.f;
+            v[i][j][k] = u;
+            const unsigned a = __float_as_uint(u) & 0x7fffffffu; // |u| as ordered bits; inf / nan do not set the scale:
+            mloc = (a > mloc && a <= 0x7f7fffffu) ? a : mloc;    // they pass through the cut as inf / nan
+          }
         }
       };
-      if (have) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) issue(i); // all 16 loads of the chunk at once: two slices of latency cover
-      }
+      if (have) activate(0, 3);
       pc_barrier(); // 0
-      // ---- slice 1: the queue (leader wave) and one tile without points, under the loads' latency
-      if (wave == 4 && !pop_done) {
+      if (have) activate(3, 6);
+      pc_barrier(); // 1
+      if (have) activate(6, 9);
+      pc_barrier(); // 2
+      if (have) activate(9, 12);
+      pc_barrier(); // 3
+      if (have) activate(12, 14);
+      pc_barrier(); // 4
+      if (have) {
+        activate(14, 16);
+        mloc = wave_max_u32_lane63(mloc);
+        if (lane_p == 63 && mloc) atomicMax(&ctl->smax[pj & 1], mloc);
+      }
+      pc_barrier(); // 5: the chunk's maximum is complete
+      float xs = 1.f;
+      if (have) {
+        const unsigned mbits = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl->smax[pj & 1]);
+        if (mbits) {
+          const int e = scale_exp(__uint_as_float(mbits));
+          if (e < E) E = e - CONV_SPLIT_HEADROOM;
+        }
+        if (rt == 0) { ctl->E[pj & 1] = E; ctl->smax[(pj + 1) & 1] = 0u; } // the other slot: last read in step s - 1
+        xs = E == 127 ? 1.0f : pow2f(E);
+      }
+      // ---- slices 6-8: cut into hi / lo pieces at the tile's scale, planes of buffer pj & 1 (3 + 3 + 2 voxels); the queue
+      // and the tiles without points ride in slices 6 and 7
+      auto cutwrite = [&](int i, int k0, int k1) { // voxels k0 .. k1 - 1 of item i
+        const Geo gq = geo(i);
+#pragma unroll
+        for (int k = k0; k < k1; ++k) {
+          unsigned short hi[8], lo[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cut(v[i][j][k] * xs, hi[j], lo[j]);
+          u4 ph4, pl4;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            ph4[m] = (unsigned)hi[2 * m] | ((unsigned)hi[2 * m + 1] << 16);
+            pl4[m] = (unsigned)lo[2 * m] | ((unsigned)lo[2 * m + 1] << 16);
+          }
+          if (gq.live) {
+            dst[(0 + gq.ig) * HP + gq.p0 + k] = ph4;
+            dst[(2 + gq.ig) * HP + gq.p0 + k] = pl4;
+          }
+        }
+      };
+      if (have) cutwrite(0, 0, 3);
+      {
+        // one tile without points per step: every producer wave writes its quarter (64 voxels x COT channels of bias |
+        // constant response).  Statistics: the consumers' epilogue with zero accumulators and no stores -- the same tree,
+        // so the sums are bit-identical to the dense evaluation of such a tile; stores: 16 bytes per lane.
+        while (pf < ph && pc_ring_read(ring, pf).wmask != 0) ++pf;
+        if (pf < ph) {
+          const PcItem it = pc_ring_read(ring, pf);
+          ++pf;
+          const int fd0 = (it.tile / (ntw * nth)) * TD, fh0 = ((it.tile / ntw) % nth) * TH, fw0 = (it.tile % ntw) * TW;
+          const float *ga = delta ? tconst + (size_t)it.b * 27 * Cout + it.co0 : (bias ? bias + it.co0 : nullptr);
+          const int gs = delta ? Cout : 0;
+          float *yb = y + ((size_t)it.b * Cout + it.co0) * r3;
+          if (STATS) {
+            f32x16 za[CB][2], zc[CB][2];
+            pc_epilogue<TD, TH, TW, CB, true, true, false>(
+                za, zc, 1.f, 1.f, [&](int cfg, int co) { return ga ? ga[cfg * gs + co] : 0.f; }, wq, lane_p, yb, r, fd0, fh0, fw0,
+                stats + (((size_t)it.b * Cout + it.co0) * st_tiles + it.tile * 4 + wq) * 2, st_tiles * 2);
+          }
+          // lane -> (channel of a group of four, quad of voxels): quad qd = lane % 16 of the quarter's 16, channel lane / 16
+          const int qd = lane_p & 15, v0 = wq * 64 + qd * 4;
+          const int vd = v0 / (TH * TW), vh = (v0 / TW) % TH, vw = v0 % TW; // TW % 4 == 0: a quad stays inside a row
+          const int gd = fd0 + vd, gh = fh0 + vh, gw = fw0 + vw;
+          const int crow = ((gd == 0 ? 0 : gd == r - 1 ? 2 : 1) * 3 + (gh == 0 ? 0 : gh == r - 1 ? 2 : 1)) * 3;
+          const int cfg0 = crow + (gw == 0 ? 0 : 1), cfg3 = crow + (gw + 3 == r - 1 ? 2 : 1), cfgm = crow + 1;
+          float *yq = yb + (size_t)((gd * r + gh) * r + gw);
+#pragma unroll 4
+          for (int cc = 0; cc < COT / 4; ++cc) {
+            const int co = cc * 4 + (lane_p >> 4);
+            const float a0 = ga ? ga[cfg0 * gs + co] : 0.f, am = ga ? ga[cfgm * gs + co] : 0.f, a3 = ga ? ga[cfg3 * gs + co] : 0.f;
+            *reinterpret_cast<float4 *>(yq + (size_t)co * r3) = make_float4(a0, am, am, a3);
+          }
+        }
+      }
+      pc_barrier(); // 6
+      if (have) { cutwrite(0, 3, 4); cutwrite(1, 0, 2); }
+      const int tail0 = ctl->tail;
+      if (wave == 4 && !pop_done) { // the leader refills the ring (visible to the walk below, behind barrier 7)
         const int chead = ctl->chead;
         const int low = min(chead, pf);
         // pop when the walk is about to run dry, in small lots: what a workgroup has popped it must finish, and the tail
         // of the launch is only as balanced as the lots are small
-        if (tail - ph < PC_POP && tail - low <= PC_RING - PC_POP) {
+        if (tail0 - ph < PC_POP && tail0 - low <= PC_RING - PC_POP) {
           long work;
           if (queued) {
             int base = 0;
@@ -314,114 +382,63 @@ __global__ __launch_bounds__(512, 2) void conv3d_split_pc_kernel(const float *__
               it.co0 = (int)(work % ncz) * COT;
               it.wmask = queued ? occ[it.b * ntiles + it.tile] : 0xf;
             }
-            ring[(tail + lane_p) & (PC_RING - 1)] = it;
+            ring[(tail0 + lane_p) & (PC_RING - 1)] = it;
           }
           const long last = queued ? (long)__builtin_amdgcn_readfirstlane((int)work) + PC_POP - 1
                                    : (long)blockIdx.x + (long)((npop - 1) * PC_POP + PC_POP - 1) * gridDim.x;
           if (last >= total_work) pop_done = true;
-          if (lane_p == 0) ctl->tail = tail + PC_POP;
+          if (lane_p == 0) ctl->tail = tail0 + PC_POP;
         }
       }
-      {
-        // one tile without points per step: every producer wave writes its quarter (same arithmetic and statistics tree as
-        // the consumers' epilogue with zero accumulators: bit-identical to the dense evaluation of such a tile)
-        while (pf < ph && pc_ring_read(ring, pf).wmask != 0) ++pf;
-        if (pf < ph) {
-          const PcItem it = pc_ring_read(ring, pf);
-          ++pf;
-          f32x16 za[CB][2], zc[CB][2];
-          const int fd0 = (it.tile / (ntw * nth)) * TD, fh0 = ((it.tile / ntw) % nth) * TH, fw0 = (it.tile % ntw) * TW;
-          const float *ga = delta ? tconst + (size_t)it.b * 27 * Cout + it.co0 : (bias ? bias + it.co0 : nullptr);
-          const int gs = delta ? Cout : 0;
-          pc_epilogue<TD, TH, TW, CB, STATS, true>(
-              za, zc, 1.f, 1.f, [&](int cfg, int co) { return ga ? ga[cfg * gs + co] : 0.f; }, wq, lane_p,
-              y + ((size_t)it.b * Cout + it.co0) * r3, r, fd0, fh0, fw0,
-              STATS ? stats + (((size_t)it.b * Cout + it.co0) * st_tiles + it.tile * 4 + wq) * 2 : nullptr, st_tiles * 2);
-        }
-      }
-      pc_barrier(); // 1
-      // ---- slices 2-5: activation (AdaGN + Swish of the previous convolution, delta form) and the chunk maximum; one
-      // slice = 4 channels x 4 positions of one item
-      u4 *dst = sx + (pj & 1) * 4 * HP;
-      unsigned mloc = 0u;
-      auto activate = [&](int i, int jh) { // channels 4 jh .. 4 jh + 3 of item i
-        const Geo gq = geo(i);
-        float pa4[4], pb4[4], pc4[4];
-        if (pro_on) { // 16-byte broadcast reads of the prologue scalars (wave-uniform address)
-          const int c0 = q * KS + gq.ig * 8 + jh * 4;
-          const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), b0 = *reinterpret_cast<const float4 *>(spb + c0);
-          const float4 c4 = *reinterpret_cast<const float4 *>(spc + c0);
-          pa4[0] = a0.x; pa4[1] = a0.y; pa4[2] = a0.z; pa4[3] = a0.w;
-          pb4[0] = b0.x; pb4[1] = b0.y; pb4[2] = b0.z; pb4[3] = b0.w;
-          pc4[0] = c4.x; pc4[1] = c4.y; pc4[2] = c4.z; pc4[3] = c4.w;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool ok = gq.rowok;
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int j = jh * 4 + jj;
-            // zero padding stays zero; delta mode stages the deviation from the per-channel constant; the activation
-            // unconditionally with a select behind it (a branch per value otherwise)
-            const float t = pro_on ? pro_act(v[i][j][k], pa4[jj], pb4[jj]) - pc4[jj] : v[i][j][k];
-            const float u = ok ? t : 0.f;
-            v[i][j][k] = u;
-            const unsigned a = __float_as_uint(u) & 0x7fffffffu; // |u| as ordered bits; inf / nan do not set the scale:
-            mloc = (a > mloc && a <= 0x7f7fffffu) ? a : mloc;    // they pass through the cut as inf / nan
-          }
-        }
-      };
-      if (have) activate(0, 0);
-      pc_barrier(); // 2
-      if (have) activate(0, 1);
-      pc_barrier(); // 3
-      if (have) activate(1, 0);
-      pc_barrier(); // 4
-      if (have) {
-        activate(1, 1);
-        mloc = wave_max_u32_lane63(mloc);
-        if (lane_p == 63 && mloc) atomicMax(&ctl->smax[pj & 1], mloc);
-      }
-      pc_barrier(); // 5: the chunk's maximum is complete
-      float xs = 1.f;
-      if (have) {
-        const unsigned mbits = (unsigned)__builtin_amdgcn_readfirstlane((int)ctl->smax[pj & 1]);
-        if (mbits) {
-          const int e = scale_exp(__uint_as_float(mbits));
-          if (e < E) E = e - CONV_SPLIT_HEADROOM;
-        }
-        if (rt == 0) { ctl->E[pj & 1] = E; ctl->smax[(pj + 1) & 1] = 0u; } // the other slot: last read in step s - 1
-        xs = E == 127 ? 1.0f : pow2f(E);
-      }
-      // ---- slices 6-8: cut into hi / lo pieces at the tile's scale, planes of buffer pj & 1
-      auto cutwrite = [&](int i, int k0, int k1) { // positions k0 .. k1 - 1 of item i
-        const Geo gq = geo(i);
-#pragma unroll
-        for (int k = k0; k < k1; ++k) {
-          unsigned short hi[8], lo[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) cut(v[i][j][k] * xs, hi[j], lo[j]);
-          u4 ph4, pl4;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            ph4[m] = (unsigned)hi[2 * m] | ((unsigned)hi[2 * m + 1] << 16);
-            pl4[m] = (unsigned)lo[2 * m] | ((unsigned)lo[2 * m + 1] << 16);
-          }
-          if (gq.live) {
-            dst[(0 + gq.ig) * HP + gq.p0 + k] = ph4;
-            dst[(2 + gq.ig) * HP + gq.p0 + k] = pl4;
-          }
-        }
-      };
-      if (have) { cutwrite(0, 0, 3); }
-      pc_barrier(); // 6
-      if (have) { cutwrite(0, 3, 4); cutwrite(1, 0, 2); }
       pc_barrier(); // 7
       if (have) {
         cutwrite(1, 2, 4);
         if (rt == 0) ctl->staged = pj + 1;
         ++pj;
         ++q;
+      }
+      // ---- the next job: the tile's next chunk, or the next non-empty ring entry (tiles without points on the way are left
+      // to the fill head); its loads are requested NOW and land under slices 0-5 of the step that activates them
+      pending = false;
+      if (q < nchunks) pending = true;
+      else if (!ended) {
+        const int tail = ctl->tail;
+        while (ph < tail && pc_ring_read(ring, ph).wmask == 0) ++ph;
+        if (ph < tail) {
+          const PcItem it = pc_ring_read(ring, ph);
+          if (it.wmask < 0) ended = true;
+          else {
+            ib = it.b; itile = it.tile; ico0 = it.co0; q = 0; E = 127; ++ph;
+            d0 = (itile / (ntw * nth)) * TD; h0 = ((itile / ntw) % nth) * TH; w0 = (itile % ntw) * TW;
+            pending = true;
+            if (pro_on) // (their last readers passed barrier 5 of this step)
+              for (int c = rt; c < Cin; c += TM) {
+                const float pa = pro_a[(size_t)ib * Cin + c], pb = pro_b[(size_t)ib * Cin + c];
+                spa[c] = pa;
+                spb[c] = pb;
+                spc[c] = delta ? pro_act(pro_bias ? pro_bias[c] : 0.f, pa, pb) : 0.f;
+              }
+            float *sa = sadd + (nitem % 3) * add_rows * COT; // read by the consumers' epilogue >= 2 steps later
+            for (int e = rt; e < add_rows * COT; e += TM)
+              sa[e] = delta ? tconst[((size_t)ib * 27 + e / COT) * Cout + ico0 + e % COT] : (bias ? bias[ico0 + e] : 0.f);
+            ++nitem;
+          }
+        }
+      }
+      if (pending) {
+        if (rt == 0) ctl->planned = pj + 1;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + (size_t)ib * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { // the 8 channels x 4 voxels of each item: 16 loads of 16 bytes per thread
+          const Geo gq = geo(i);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const u4 t4 = __builtin_amdgcn_raw_buffer_load_b128(xrs, gq.goff, (q * KS + gq.ig * 8 + j) * r3 * 4, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][j][k] = __uint_as_float(t4[k]);
+          }
+        }
       }
       // end of the stream: everything popped has been walked, every tile without points written, the last job staged (it
       // is multiplied in step s + 1)

@@ -3,7 +3,7 @@
 # resource remarks (-Rpass-analysis=kernel-resource-usage).  No GPU needed.  usage: tools/kernel_resources.sh > profiles/<tag>_kernel_resources.txt
 set -euo pipefail
 cd "$(dirname "$0")/../lion_amd/csrc"
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -I../../include"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -munsafe-fp-atomics -I../../include"
 printf "%-18s %-78s %5s %5s %8s %4s %8s\n" file kernel VGPR AGPR scratch occ LDS_static
 for f in *.hip; do
   /opt/rocm/bin/hipcc $F -c "$f" -Rpass-analysis=kernel-resource-usage -o /tmp/_kr.o 2>&1 | python3 -c '
