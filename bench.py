@@ -193,8 +193,9 @@ def train_bench(args, rank, world, dev, backend):
     from lion_amd.dist import BucketedGradAverager, broadcast_params
     from lion_amd import training
     vae_mode = args.mode == "train_vae"
-    cfg = released_prior_cfg("chair" if vae_mode else "car")
-    B = args.batch if args.batch_given else 32
+    clip_mode = args.mode == "train_prior_clip"
+    cfg = released_prior_cfg("chair" if vae_mode else "car", clip=clip_mode)
+    B = args.batch if args.batch_given else (8 if clip_mode else 32)   # configs[4]: B = 64 over 8 GPUs
     K, W = (args.steps if args.steps_given else 20), args.warmup
     torch.manual_seed(0)
     use_graph = world == 1 and not args.no_graph
@@ -211,13 +212,16 @@ def train_bench(args, rank, world, dev, backend):
             p_.requires_grad_(False)
         model = lion.priors.train()
         params = list(model.parameters())
-        name = "configs[3]: train_2prior step (frozen VAE encode + global + local denoiser), car, B=256 over 8 GPUs"
+        name = ("configs[4]: CLIP-conditioned train_2prior step (train_prior_clip.sh: PriorSEClip + AdaGN-conditioned local "
+                "denoiser, synthetic [B, 512] CLIP feature), B=64 over 8 GPUs" if clip_mode else
+                "configs[3]: train_2prior step (frozen VAE encode + global + local denoiser), car, B=256 over 8 GPUs")
     if world > 1:
         broadcast_params(params)
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), capturable=use_graph)
     averager = BucketedGradAverager(params)
     torch.manual_seed(1234 + rank)
     x = torch.randn(B, 2048, 3, device=dev)
+    clip_feat = torch.randn(B, 512, device=dev) if clip_mode else None   # the CLIP encoder itself is out of scope
     static_loss = [None]
 
     def step():
@@ -226,7 +230,7 @@ def train_bench(args, rank, world, dev, backend):
             loss, _ = training.vae_train_step(model, opt, x, step=0, averager=averager, distributed=world > 1)
         else:
             loss, _ = training.prior_train_step(lion.vae, model, lion.diffusion, opt, x, averager=averager,
-                                                distributed=world > 1)
+                                                distributed=world > 1, clip_feat=clip_feat)
         static_loss[0] = loss
         return loss
 
@@ -315,9 +319,9 @@ def train_bench(args, rank, world, dev, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--mode", choices=["sample", "demo", "train_vae", "train_prior"], default="sample",
+    ap.add_argument("--mode", choices=["sample", "demo", "train_vae", "train_prior", "train_prior_clip"], default="sample",
                     help="sample (default): the BASELINE metric; demo: configs[0] as a latency line (1 shape, 100 DDIM "
-                         "steps); train_*: one training step of configs[2] / configs[3]")
+                         "steps); train_*: one training step of configs[2] / configs[3] / configs[4]")
     ap.add_argument("--steps", type=int, default=1000,
                     help="DDIM steps per prior that are timed; 1000 = the metric's real chain (~17 s)")
     ap.add_argument("--warmup", type=int, default=3)

@@ -52,12 +52,18 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
-template <int PPT>
-__global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ coords, int N, int M,
-                                                      int32_t *__restrict__ idx) {
+// NW waves per cloud, PPT points per lane.  Four waves: eight (two per SIMD, half the arithmetic per wave, eight exchange
+// words) were measured in round 3 at 549 us against 530 us for 2048 -> 1024, B = 32 -- a round is bound by its chain of
+// dependent latencies (LDS lookup, two DPP reductions, exchange + barrier + LDS read: ~800 of 1250 cycles), not by
+// VALU issue.  With the sampling step on one stream (lion_amd/geometry.py) the chain is on the critical path of every
+// denoiser step (0.68 ms of 8.7).
+template <int PPT, int NW>
+__global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float *__restrict__ coords, int N, int M,
+                                                           int32_t *__restrict__ idx) {
+  constexpr int TPB = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *sx = reinterpret_cast<float4 *>(smem); // [N] {x, y, z, -} copy for the "coords[old]" lookup (one 16-byte read)
-  __shared__ unsigned long long wkey[2][4];
+  __shared__ unsigned long long wkey[2][NW];
   // 1023 dependent rounds on one workgroup per cloud: pure latency.  When the sampler runs this chain on a side stream
   // under the MFMA convolutions (lion_amd/geometry.py, optional) the raised wave priority lets its few instructions per
   // round issue ahead of the convolution waves sharing the SIMD instead of queueing behind them.
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
   unsigned tb[PPT]; // tie-break word of point k: larger wins, 0 for lanes past N (see fps_key)
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
-    const int k = tid + p * 256;
+    const int k = tid + p * TPB;
     x[p] = y[p] = z[p] = 0.f;
     td[p] = 1e38f; // sampling.cpp:53-54
     tb[p] = 0u;
@@ -103,11 +109,9 @@ __global__ __launch_bounds__(256) void fps_reg_kernel(const float *__restrict__ 
     const unsigned wtb = wave_max_u32(mt);
     if (lane == 0) wkey[j & 1][wave] = ((unsigned long long)wmax << 32) | wtb;
     __syncthreads();
-    unsigned long long k0 = wkey[j & 1][0], k1 = wkey[j & 1][1], k2 = wkey[j & 1][2],
-                       k3 = wkey[j & 1][3];
-    k0 = k1 > k0 ? k1 : k0;
-    k2 = k3 > k2 ? k3 : k2;
-    k0 = k2 > k0 ? k2 : k0;
+    unsigned long long k0 = wkey[j & 1][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { const unsigned long long kw = wkey[j & 1][w]; k0 = kw > k0 ? kw : k0; }
     old = fps_key_index(k0);
     if (tid == 0) out[j] = old;
   }
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(1024) void fps_lds_kernel(const float *__restrict__
   }
 }
 
-template <int PPT>
+template <int PPT, int NW>
 static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx, hipStream_t st) {
   // History.  Round 2: inside a captured sampling step this kernel ran on a side stream beside the
   // convolutions and returned 300-1800 wrong indices of 2048 per graph replay whenever conv3d_split_kernel workgroups
@@ -164,8 +168,8 @@ static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx
   // N * 16 bytes it uses, and it shares its CUs again (tests/test_concurrency_gpu.py replays it beside the convolution).
   const size_t lds = (size_t)N * 16;
   static LionLdsLimit configured = {};
-  if (int e = lion_dynamic_lds(&fps_reg_kernel<PPT>, lds, configured)) return e;
-  fps_reg_kernel<PPT><<<B, 256, lds, st>>>(coords, N, M, idx);
+  if (int e = lion_dynamic_lds(&fps_reg_kernel<PPT, NW>, lds, configured)) return e;
+  fps_reg_kernel<PPT, NW><<<B, 64 * NW, lds, st>>>(coords, N, M, idx);
   LION_LAUNCH_CHECK();
   return 0;
 }
@@ -178,11 +182,11 @@ extern "C" int lion_furthest_point_sampling(const float *coords, int B, int N, i
   if (M == 0) return 0;
   if (N > (1 << 20)) return LION_EUNSUPPORTED; // tie-break key holds 20 index bits
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (N <= 256) return launch_fps_reg<1>(coords, B, N, M, idx, st);
-  if (N <= 512) return launch_fps_reg<2>(coords, B, N, M, idx, st);
-  if (N <= 1024) return launch_fps_reg<4>(coords, B, N, M, idx, st);
-  if (N <= 2048) return launch_fps_reg<8>(coords, B, N, M, idx, st);
-  if (N <= 4096) return launch_fps_reg<16>(coords, B, N, M, idx, st);
+  if (N <= 256) return launch_fps_reg<1, 4>(coords, B, N, M, idx, st);
+  if (N <= 512) return launch_fps_reg<2, 4>(coords, B, N, M, idx, st);
+  if (N <= 1024) return launch_fps_reg<4, 4>(coords, B, N, M, idx, st);
+  if (N <= 2048) return launch_fps_reg<8, 4>(coords, B, N, M, idx, st);
+  if (N <= 4096) return launch_fps_reg<16, 4>(coords, B, N, M, idx, st);
   if (N <= 32768) {
     const size_t lds = (size_t)N * 4;
     static LionLdsLimit configured = {};

@@ -1,0 +1,60 @@
+"""-m gpu: bench.py itself -- the contract the driver depends on (one JSON line, the metric's keys, the roofline and
+cpu_baseline objects) at a reduced size, and the N > 1 launch path: `--gpus 2` starts its own two ranks, which here share
+the one device of the box and rendezvous over gloo (LION_BENCH_BACKEND=gloo; RCCL needs one device per rank).  What this
+covers of the 8-GPU run without 8 GPUs: rank discovery, per-rank seeding, the barrier + MAX-over-ranks timing, the
+bucketed gradient averager with its overlap hooks armed at world size 2, the whole-job aggregation of `value`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env=None, timeout=600):
+    e = dict(os.environ, **(env or {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                         timeout=timeout, env=e, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_sample_line_contract_single_rank():
+    d = _bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2", "--repeats", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert len(d["config"]["ms_per_step_all_runs"]) == 2 and "workload" in d["config"]
+
+
+def test_sample_two_ranks_share_the_device_over_gloo():
+    d = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--repeats", "1", "--no-dense-check",
+               env={"LION_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["shapes_per_gpu"] == 2
+    assert "2 independent rank(s)" in d["config"]["parallelism"]
+    # value is the whole job's: both ranks' shapes over the slower rank's time
+    per_step_s = d["ms_per_step"] / 1e3
+    assert abs(d["value"] - 2 * 2 / (1000.0 * per_step_s + d["config"]["decode_seconds"])) < 1e-6 * d["value"] + 1e-9
+
+
+def test_train_vae_two_ranks_bucketed_averaging_over_gloo():
+    d = _bench("--gpus", "2", "--mode", "train_vae", "--steps", "2", "--warmup", "1", "--batch", "2",
+               env={"LION_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["unit"] == "samples/s" and d["value"] > 0
+    assert "world 2" in d["config"]["gradient_averaging"] and d["config"]["launch"].startswith("eager")
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]  # not NaN
+
+
+def test_train_prior_clip_line():
+    d = _bench("--gpus", "1", "--mode", "train_prior_clip", "--steps", "2", "--warmup", "1", "--batch", "2")
+    assert "configs[4]" in d["config"]["workload"] and d["value"] > 0
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]
