@@ -12,13 +12,22 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -munsafe-fp-atomics -I../../include -Wall -Wno-unused-function"
+# An object is rebuilt when the hash of (compiler, flags, its source, the shared headers) differs from the one recorded
+# beside it (FILE.o.key) -- content, not mtime: a flag change, a checkout of an older file or a fresh clone with stale
+# objects all rebuild; LION_REBUILD=1 forces everything.
+HDRS="common.h split_ops.h ../../include/lion_hip.h"
+VER="$($HIPCC --version 2>/dev/null | head -3)"
 OBJS=()
 PIDS=()
+KEYS=()
 for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise pwconv pwconv_split skinny attention "$@"; do
   [ -f "$f.hip" ] || continue
-  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ common.h -nt "$f.o" ] || [ split_ops.h -nt "$f.o" ] || [ ../../include/lion_hip.h -nt "$f.o" ]; then
-    rm -f "$f.o"   # a failed compile must not leave the previous object behind to be linked silently
-    $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
+  # shellcheck disable=SC2086
+  key="$( { echo "$VER $FLAGS"; cat "$f.hip" $HDRS; } | sha256sum | cut -d' ' -f1)"
+  if [ -n "${LION_REBUILD:-}" ] || [ ! -f "$f.o" ] || [ ! -f "$f.o.key" ] || [ "$(cat "$f.o.key")" != "$key" ]; then
+    rm -f "$f.o" "$f.o.key"   # a failed compile must not leave the previous object behind to be linked silently
+    # shellcheck disable=SC2086
+    ( $HIPCC $FLAGS -c "$f.hip" -o "$f.o" && echo "$key" > "$f.o.key" ) &
     PIDS+=($!)
   fi
   OBJS+=("$f.o")

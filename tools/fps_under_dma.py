@@ -1,9 +1,10 @@
-"""Furthest-point sampling on a side stream beside the LDS-DMA convolution kernel, captured in one hipGraph and replayed:
-per replay, how many of the B x M sample indices differ from the stand-alone result, and how many conv outputs differ.
-The register FPS kernel of round 1 trusted one barrier and one unchecked LDS read per round and returned 300-1800 wrong
-indices of 2048 in nearly every replay (never eagerly, never beside the fp32 or the register-staged kernels); with the
-checked reads of csrc/sampling.hip every replay matches.  usage: fps_under_dma.py [C] [R] [conv|fp32|pw|devox|vox]   (conv C->C at R^3, default 32 32 conv); LION_FPS_SHARE_CU=1 launches
-FPS the round-1 way (it then shares its CU with the aggressor's workgroups)."""
+"""Furthest-point sampling on a side stream beside one of the kernels it can overlap, captured in one hipGraph and
+replayed: per replay, how many of the B x M sample indices differ from the stand-alone result, and how many conv outputs
+differ.  History: the round-2 build of fps_reg_kernel returned 300-1800 wrong indices of 2048 in nearly every replay
+beside conv3d_split_kernel (never eagerly, never beside the other kernels); round 3 located the cause in packed fp32
+VALU emitted by the SLP vectoriser and the library is built without it -- every replay matches.
+tools/victims_beside_conv.py is the B = 32, all-kernels successor of this script.
+usage: fps_under_dma.py [C] [R] [conv|fp32|pw|devox|vox]   (conv C->C at R^3, default 32 32 conv)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lion_amd.functional import backend as _bk

@@ -4,7 +4,8 @@ CUs saturated with fp16-MFMA workgroups) inside one hipGraph, replayed R times; 
 output differs from the victim run alone, and the number of wrong words.  The victims repeat themselves inside the graph
 until they span the convolutions' ~4 ms.
   usage: victims_beside_conv.py [--replays 100] [--B 32] [victim ...]     victims: fps bq nn group grouppts pw gnfold vox devox
-  LION_FPS_SHARE_CU=1: FPS launched without the whole-LDS request (it then shares CUs with the convolution)."""
+  (LION_FPS_SHARE_CU=1 only matters for builds of csrc/sampling.hip from before round 3's fix, selected with LION_HIP_SO:
+  those requested a whole CU's LDS unless it was set; the current kernel always shares CUs.)"""
 import argparse
 import os
 import sys
