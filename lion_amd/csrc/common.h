@@ -50,6 +50,12 @@ __device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, 
 // NOTE: __fsqrt_rn() lowers to a bare v_sqrt_f32 (1 ulp) on gfx950; sqrtf() gets the correctly
 // rounded refinement sequence under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
 __device__ __forceinline__ float sqrt_rn(float a) { return sqrtf(a); }
+// swish(t) = t * sigmoid(t) on the hardware's v_exp_f32 + v_rcp_f32 (1 ulp each).  ONE definition for every kernel that
+// applies it (conv / 1x1 prologues, affine_swish passes, the constant-response table): the delta decomposition of
+// csrc/conv3d*.hip needs the constant and the staged activation to come from the same arithmetic.  (Until round 3 this
+// was written __frcp_rn(1 + __expf(-t)), which compiles to the 10-instruction IEEE division sequence: the activation cost
+// 22 VALU issues per value, half the matrix time of a prologue convolution.)
+__device__ __forceinline__ float swish_fast(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
 
 // (a-b)^2 + (c-d)^2 + (e-f)^2 evaluated left to right without contraction.
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by,

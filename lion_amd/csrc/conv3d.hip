@@ -40,7 +40,7 @@ constexpr int KC = LION_CONV_KC;
 // constant-response decomposition below): ONE definition, so both see the same bits.
 __device__ __forceinline__ float pro_act(float v, float pa, float pb) {
   const float t = v * pa + pb;
-  return t * __frcp_rn(1.0f + __expf(-t)); // swish(t) = t * sigmoid(t): v_exp + v_rcp
+  return swish_fast(t);
 }
 
 template <int TD, int TH, int TW, int COT, int VB, bool PRO, bool STATS>

@@ -300,14 +300,20 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
             for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = sx[(pc * 2 + g) * HP + xbase[vb] + toff];
           }
+          // three sweeps over the (cb, vb) accumulators: the two MFMAs into one `cor` tuple are CB*VB issues apart
+          // (back to back, the second waits for the first's last pass)
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int vb = 0; vb < VB; ++vb) {
-              acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
-              cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
-              cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
-            }
+            for (int vb = 0; vb < VB; ++vb) acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
         }
       }
       // @phase 6
@@ -510,11 +516,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
     xbase[vb] = (d * HH + h) * HW + w;
     vox[vb] = ((d0 + d) * r + h) * r + w;
   }
-  f32x16 acc[VB], cor[VB];
+  f32x16 acc[VB], cor[VB], cor2[VB]; // cor += W_h X_l, cor2 += W_l X_h: no two consecutive MFMAs share an accumulator
 #pragma unroll
   for (int vb = 0; vb < VB; ++vb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[vb][i] = cor[vb][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[vb][i] = cor[vb][i] = cor2[vb][i] = 0.f;
 
   const int nchunks = Cin / KS, ngroups = nchunks * NG;
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
 #pragma unroll
           for (int vb = 0; vb < VB; ++vb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[vb][i] *= f; cor[vb][i] *= f; }
+            for (int i = 0; i < 16; ++i) { acc[vb][i] *= f; cor[vb][i] *= f; cor2[vb][i] *= f; }
         }
         E = e - CONV_SPLIT_HEADROOM;
       }
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
         for (int vb = 0; vb < VB; ++vb) {
           acc[vb] = mma(wf[t & 1][0], xf[t & 1][vb][0], acc[vb]);
           cor[vb] = mma(wf[t & 1][0], xf[t & 1][vb][1], cor[vb]);
-          cor[vb] = mma(wf[t & 1][1], xf[t & 1][vb][0], cor[vb]);
+          cor2[vb] = mma(wf[t & 1][1], xf[t & 1][vb][0], cor2[vb]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = (i & 3) + 8 * (i >> 2) + 4 * g;
-      const float o = ((acc[vb][i] + cor[vb][i] * (1.f / 2048.f)) * us_x) * us_w + sbias[co];
+      const float o = ((acc[vb][i] + (cor[vb][i] + cor2[vb][i]) * (1.f / 2048.f)) * us_x) * us_w + sbias[co];
       acc[vb][i] = o;
       yb[(size_t)co * r3 + vox[vb]] = o;
     }

@@ -10,7 +10,7 @@
 
 namespace {
 
-__device__ __forceinline__ float swishf(float t) { return t * __frcp_rn(1.0f + __expf(-t)); } // v_exp + v_rcp, as in the conv prologue
+__device__ __forceinline__ float swishf(float t) { return swish_fast(t); } // as in the conv prologue
 
 __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int L,
                                                         float *__restrict__ stats) {

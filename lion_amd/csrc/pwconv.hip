@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
           if (PRO) {
             const int kc = min(k, Cin - 1);
             const float t = v * spa[kc] + spb[kc];
-            v = t * __frcp_rn(1.0f + __expf(-t)); // swish
+            v = swish_fast(t);
           }
           v = (kok && cok[vb]) ? v : 0.f;
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void pwconv_small_kernel(const float *__restri
       if (PRO) {
         const int kc = min(k, Cin - 1);
         const float t = v * spa[kc] + spb[kc];
-        v = t * __frcp_rn(1.0f + __expf(-t)); // swish, as in pwconv_kernel
+        v = swish_fast(t); // as in pwconv_kernel
       }
       v = (s0 + u < s_hi && k < Cin && cok) ? v : 0.f;
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], v, acc[0], 0, 0, 0);

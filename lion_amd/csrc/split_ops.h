@@ -13,7 +13,7 @@ constexpr int KS = 16; // input channels per chunk = K of one MFMA
 
 __device__ __forceinline__ float pro_act(float v, float pa, float pb) { // == csrc/conv3d.hip
   const float t = v * pa + pb;
-  return t * __frcp_rn(1.0f + __expf(-t));
+  return swish_fast(t);
 }
 // exponent e with 2^13 <= m * 2^e < 2^14 for a finite m > 0 (from the float's exponent field; subnormal m -> +100)
 __device__ __forceinline__ int scale_exp(float m) {
