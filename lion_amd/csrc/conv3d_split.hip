@@ -124,27 +124,13 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 
   // staging items: item = tid + 256 i -> k-half item / HP (wave uniform), halo position item % HP.  Positions past
   // HALO are padding; positions outside the grid carry an offset beyond num_records, for which buffer loads return 0.
-  int goff[NI];
-  bool gok[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int item = tid + TM * i, p = item % HP;
-    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
-    const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-    gok[i] = item < 2 * HP && p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
-    goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
-  }
+  // Everything derived from the thread index (these offsets, the fragment bases of the tap loop) is RECOMPUTED per chunk
+  // from an opaque copy of it: computed once here it stays alive across the tap loop, where the allocator -- at the
+  // 256-register limit -- spills exactly such long-lived values, and the reloads (scratch loads wait with vmcnt, memory
+  // operations retire in order) then drain the operand loads they sit between.
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
 
-  // halo position of this lane's voxel in each of the wave's column blocks (v = (wave*VB + vb)*32 + lane%32)
-  int xbase[VB];
-#pragma unroll
-  for (int vb = 0; vb < VB; ++vb) {
-    const int v = (wave * VB + vb) * 32 + l32;
-    const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
-    xbase[vb] = (d * HH + h) * HW + w;
-  }
   f32x16 acc[CB][VB], cor[CB][VB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
@@ -167,7 +153,9 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   // wave's cycles went into waiting for them).  The DMA is issued right behind the group barrier and awaited (vmcnt 0)
   // in front of the next one.
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
-  const uint32_t sw_lds = (uint32_t)(uintptr_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw) + (uint32_t)wave * 1024u;
+  const uint32_t sw_lds0 = (uint32_t)(uintptr_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw);
+  const uint32_t sw_lds = sw_lds0 + (uint32_t)wave * 1024u;
+  const uint32_t sx_lds = (uint32_t)(uintptr_t)(lds_byte *)reinterpret_cast<unsigned char *>(sx);
   auto weights_dma = [&](int sg) { // group sg of the K walk (chunk sg / 9, taps (sg % 9) * TG ..) -> buffer sg & 1
     if (w_thread) {                // wave uniform: WPL is a multiple of 64
 #pragma unroll
@@ -186,49 +174,69 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       }
     }
   };
-  if (nchunks) weights_dma(0);
+  if (nchunks) { weights_dma(0); weights_dma(1); } // nchunks >= 1 -> at least 9 groups
   // @phase 0
-  for (int q = 0; q < nchunks; ++q) {
+  // One chunk of the K walk.  WORK = false is the copy run by a wave whose 64-voxel block sees no point (wave mask): it
+  // stages and takes part in every barrier and in the weight DMA, but owns no MFMA and no accumulator.  The two copies are
+  // separate LOOPS (the branch on wave_on sits outside them): with the branch inside the chunk -- per tap or around the
+  // 27 taps -- the register allocator split the accumulators' live ranges around the working path and parked five of
+  // the eight tuples in scratch across the staging of every chunk (684-792 bytes, 64->64 at 1070 us instead of 705).
+  auto chunk = [&](int q, auto work_c) {
+    constexpr bool WORK = decltype(work_c)::value;
     __syncthreads(); // the previous chunk's planes are no longer read (and the prologue scalars are visible)
     // @phase 1
     {
+    int rt = tid;
+    asm volatile("" : "+v"(rt));
+    int goff[NI];
+    bool gok[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int item = rt + TM * i, p = item % HP;
+      const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+      const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+      gok[i] = item < 2 * HP && p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+      goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
+    }
     // all loads of the chunk first (one memory round trip per chunk), then activate, agree on the scale, cut + write
     float v[NI][8];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int ig = __builtin_amdgcn_readfirstlane(min((tid + TM * i) / HP, 1));
+      const int ig = __builtin_amdgcn_readfirstlane(min((rt + TM * i) / HP, 1));
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, goff[i], (q * KS + ig * 8 + j) * r3 * 4, 0));
     }
     unsigned mloc = 0u;
+    if (pro_on) { // ONE uniform branch around the whole activation pass (inside the value loop it was a branch per value)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int item = tid + TM * i;
-      const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1));
-      // the 8 channels' prologue scalars: three pairs of 16-byte broadcast reads per item (wave-uniform address) instead
-      // of 24 dword reads, and the activation computed unconditionally with a select behind it -- `gok ? act : 0` had
-      // become one branch per value (ISA: 56 s_cbranch_execz per chunk)
-      float pa8[8], pb8[8], pc8[8];
-      if (pro_on) {
+      for (int i = 0; i < NI; ++i) {
+        const int ig = __builtin_amdgcn_readfirstlane(min((rt + TM * i) / HP, 1));
+        // the 8 channels' prologue scalars: three pairs of 16-byte broadcast reads per item (wave-uniform address); the
+        // activation is computed unconditionally with a select behind it (zero padding stays zero; delta mode stages the
+        // deviation from the per-channel constant)
         const int c0 = q * KS + ig * 8;
         const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), a1 = *reinterpret_cast<const float4 *>(spa + c0 + 4);
         const float4 b0 = *reinterpret_cast<const float4 *>(spb + c0), b1 = *reinterpret_cast<const float4 *>(spb + c0 + 4);
         const float4 c4 = *reinterpret_cast<const float4 *>(spc + c0), c5 = *reinterpret_cast<const float4 *>(spc + c0 + 4);
-        pa8[0] = a0.x; pa8[1] = a0.y; pa8[2] = a0.z; pa8[3] = a0.w; pa8[4] = a1.x; pa8[5] = a1.y; pa8[6] = a1.z; pa8[7] = a1.w;
-        pb8[0] = b0.x; pb8[1] = b0.y; pb8[2] = b0.z; pb8[3] = b0.w; pb8[4] = b1.x; pb8[5] = b1.y; pb8[6] = b1.z; pb8[7] = b1.w;
-        pc8[0] = c4.x; pc8[1] = c4.y; pc8[2] = c4.z; pc8[3] = c4.w; pc8[4] = c5.x; pc8[5] = c5.y; pc8[6] = c5.z; pc8[7] = c5.w;
+        const float pa8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float pb8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float pc8[8] = {c4.x, c4.y, c4.z, c4.w, c5.x, c5.y, c5.z, c5.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float act = pro_act(v[i][j], pa8[j], pb8[j]) - pc8[j];
+          v[i][j] = gok[i] ? act : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0); // one item at a time: interleaved, the items' temporaries pushed accumulators out
       }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bool real = rt + TM * i < 2 * HP;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float t = v[i][j];
-        if (pro_on) { // zero padding stays zero; delta mode stages the deviation from the per-channel constant
-          const float act = pro_act(t, pa8[j], pb8[j]) - pc8[j];
-          t = gok[i] ? act : 0.f;
-          v[i][j] = t;
-        }
-        const unsigned a = __float_as_uint(t) & 0x7fffffffu; // |t| as ordered bits; inf / nan do not set the scale:
-        mloc = (item < 2 * HP && a > mloc && a <= 0x7f7fffffu) ? a : mloc; // they pass through the cut as inf / nan
+        const unsigned a = __float_as_uint(v[i][j]) & 0x7fffffffu; // |t| as ordered bits; inf / nan do not set the scale:
+        mloc = (real && a > mloc && a <= 0x7f7fffffu) ? a : mloc;  // they pass through the cut as inf / nan
       }
     }
     mloc = wave_max_u32_lane63(mloc);
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     if (mbits) {
       const int e = scale_exp(__uint_as_float(mbits));
       if (e < E) { // the tile's maximum grew: bring what has been accumulated onto the new (smaller) scale first
-        if (E != 127) {
+        if (WORK && E != 127) {
           const float f = pow2f(max(e - CONV_SPLIT_HEADROOM - E, -126));
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     const float xs = E == 127 ? 1.0f : pow2f(E);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int item = tid + TM * i;
+      const int item = rt + TM * i;
       const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1)), p = item - ig * HP;
       unsigned short hi[8], lo[8];
 #pragma unroll
@@ -274,51 +282,96 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     }
     }
     // @phase 4
-    // 27 taps in 9 groups of TG, ONE barrier per group: behind it the group's weight slices (DMA issued a group ago,
-    // awaited just before) and -- for the first group -- the chunk's operand planes are visible, and the buffer of the
-    // group before is free for the DMA of the next one.
+    // The 27 taps.  Weight slices travel in groups of TG taps through two buffers (group k of chunk q = walk index
+    // sg = 9 q + k, buffer sg & 1).  Barrier k sits in front of the LAST tap of group k: by then every wave holds that
+    // tap's fragments in registers, so buffer sg & 1 is free for the DMA of group sg + 2, and group sg + 1 (requested one
+    // barrier earlier, awaited just before this one) is visible -- its first fragments are requested under the MFMAs of
+    // this last tap.  Fragments are double buffered in registers: the reads of tap t + 1 are spread, one at a time,
+    // between the MFMAs of tap t (a wave draws 1 KiB per 32 cycles from LDS at best; a burst of eight in front of a tap
+    // takes 256 cycles to land), and ONE counted lgkmcnt wait in front of a tap finds them there.  Round 2 read just in
+    // time -- five exposed LDS round trips per tap (`r6 wait M4 r wait M ...` in the ISA), as long as the MFMAs themselves.
+    {
+      const int par = q & 1;
+      typedef __attribute__((address_space(3))) const u4 lds_u4;
+      // opaque per-chunk base addresses: every fragment read = base + 16-bit immediate.  Left to itself the compiler
+      // hoists 27 tap offsets x (VB + CB) addresses out of the chunk loop and spills them.
+      uint32_t xq[VB], wq2[2];
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int g_ = ln >> 5, l32_ = ln & 31;
 #pragma unroll
-    for (int grp = 0; grp < 27 / TG; ++grp) {
-      const int sg = q * (27 / TG) + grp;
-      const u4 *swg = sw + (sg & 1) * TG * WPL;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // @phase 1
-      __syncthreads();
-      // @phase 5
-      if (sg + 1 < nchunks * (27 / TG)) weights_dma(sg + 1);
-      if (wave_on) {
-#pragma unroll
-        for (int t = 0; t < TG; ++t) {
-          const int tap = grp * TG + t;
-          const u4 *swb = swg + t * WPL;
+      for (int vb = 0; vb < VB; ++vb) { // halo position of this lane's voxel in the wave's column block vb
+        const int v = (wave * VB + vb) * 32 + l32_;
+        const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+        xq[vb] = sx_lds + (uint32_t)((g_ * HP + (d * HH + h) * HW + w) * 16);
+        asm volatile("" : "+v"(xq[vb]));
+      }
+      wq2[0] = sw_lds0 + (uint32_t)((par * TG * WPL + g_ * COT + l32_) * 16);
+      wq2[1] = sw_lds0 + (uint32_t)(((par ^ 1) * TG * WPL + g_ * COT + l32_) * 16);
+      asm volatile("" : "+v"(wq2[0]));
+      asm volatile("" : "+v"(wq2[1]));
+      u4 wf[2][CB][2], xf[2][VB][2];
+      constexpr int NR = 2 * VB + 2 * CB; // fragment reads per tap
+      auto frag = [&](int tap, int s_, int r_) {
+        if (r_ < 2 * VB) {
+          const int pc = r_ / VB, vb = r_ % VB;
           const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
-          u4 wf[CB][2], xf[VB][2];
-#pragma unroll
-          for (int pc = 0; pc < 2; ++pc) {
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) wf[cb][pc] = swb[(pc * 2 + g) * COT + cb * 32 + l32];
-#pragma unroll
-            for (int vb = 0; vb < VB; ++vb) xf[vb][pc] = sx[(pc * 2 + g) * HP + xbase[vb] + toff];
-          }
-          // three sweeps over the (cb, vb) accumulators: the two MFMAs into one `cor` tuple are CB*VB issues apart
-          // (back to back, the second waits for the first's last pass)
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int vb = 0; vb < VB; ++vb) acc[cb][vb] = mma(wf[cb][0], xf[vb][0], acc[cb][vb]);
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int vb = 0; vb < VB; ++vb) cor[cb][vb] = mma(wf[cb][0], xf[vb][1], cor[cb][vb]);
-#pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int vb = 0; vb < VB; ++vb) cor[cb][vb] = mma(wf[cb][1], xf[vb][0], cor[cb][vb]);
+          xf[s_][vb][pc] = *(lds_u4 *)(uintptr_t)(xq[vb] + (uint32_t)((pc * 2 * HP + toff) * 16));
+        } else {
+          const int pc = (r_ - 2 * VB) / CB, cb = (r_ - 2 * VB) % CB, k = tap / TG, t = tap % TG;
+          wf[s_][cb][pc] = *(lds_u4 *)(uintptr_t)(wq2[k & 1] + (uint32_t)((t * WPL + pc * 2 * COT + cb * 32) * 16));
         }
+      };
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // group 9 q (requested two barriers ago / in the item prologue)
+      // @phase 1
+      __syncthreads(); // the chunk's operand planes and the first weight group are visible
+      // @phase 5
+      // a wave whose 64-voxel block sees no point (wave mask) takes part in the barriers and the weight DMA only: its own
+      // copy of the walk, so that the working waves' 27 taps are straight-line code (one uniform branch per tap cost the
+      // register allocator 350 bytes of scratch)
+      auto group_barrier = [&](int k) {
+        const int sg = q * (27 / TG) + k;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // group sg + 1 has landed
+        // @phase 1
+        __syncthreads();
+        // @phase 5
+        if (sg + 2 < nchunks * (27 / TG)) weights_dma(sg + 2);
+      };
+      if constexpr (WORK) {
+#pragma unroll
+        for (int r_ = 0; r_ < NR; ++r_) frag(0, 0, r_);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          const int cur = tap & 1, nxt = cur ^ 1;
+          if (tap % TG == TG - 1) group_barrier(tap / TG);
+          // MFMA m of the tap: the CB VB main products, then the X_lo products, then the W_lo products (two MFMAs into one
+          // accumulator are CB VB issues apart)
+          auto mfma = [&](int m) {
+            const int kind = m / (CB * VB), cb = (m / VB) % CB, vb = m % VB;
+            if (kind == 0) acc[cb][vb] = mma(wf[cur][cb][0], xf[cur][vb][0], acc[cb][vb]);
+            else if (kind == 1) cor[cb][vb] = mma(wf[cur][cb][0], xf[cur][vb][1], cor[cb][vb]);
+            else cor[cb][vb] = mma(wf[cur][cb][1], xf[cur][vb][0], cor[cb][vb]);
+          };
+          constexpr int NM = 3 * CB * VB;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            if (m >= 1 && tap + 1 < 27) {
+#pragma unroll
+              for (int r_ = (m - 1) * NR / (NM - 1); r_ < m * NR / (NM - 1); ++r_) frag(tap + 1, nxt, r_);
+            }
+            mfma(m);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 27 / TG; ++k) group_barrier(k);
       }
       // @phase 6
     }
-  }
+  };
+  if (wave_on) { for (int q = 0; q < nchunks; ++q) chunk(q, BoolC<true>{}); }
+  else { for (int q = 0; q < nchunks; ++q) chunk(q, BoolC<false>{}); }
 
   if (delta) {
     __syncthreads(); // the last tap's LDS reads are done: the operand planes become the response table

@@ -10,6 +10,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 constexpr int KS = 16; // input channels per chunk = K of one MFMA
+template <bool V> struct BoolC { static constexpr bool value = V; }; // compile-time flag for generic lambdas
 
 __device__ __forceinline__ float pro_act(float v, float pa, float pb) { // == csrc/conv3d.hip
   const float t = v * pa + pb;
