@@ -47,8 +47,8 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
 }
 
 // "// @phase N" comments mark the phase boundaries that tools/build_timing_lib.sh turns into s_memtime counters in an
-// instrumented COPY of this file (0 item prologue, 1 waits at barriers, 2 load issue + wait + activate + max, 3 max barrier,
-// 4 cut + LDS write, 5 weight hand-off, 6 taps, 7 epilogue); the product build carries no instrumentation and no switches.
+// instrumented COPY of this file (0 item prologue, 1 waits at the chunk's two plane barriers, 2 load issue + wait + activate +
+// max, 3 max barrier, 4 cut + LDS write, 5 wait for the next weight group + group barrier, 6 taps, 7 epilogue); the product build carries no instrumentation and no switches.
 
 template <int TD, int TH, int TW, int CB, int VB, bool PRO, bool STATS, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   static_assert(TD * TH * TW == 4 * VB * 32, "tile voxels = 4 waves x VB column blocks x 32");
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
   constexpr int HP = (HALO + 63) / 64 * 64;   // plane stride: whole waves, so a staging wave never straddles two planes
-  constexpr int NI = (2 * HP + TM - 1) / TM;  // staging items (k-half, halo position) per thread
   constexpr int WPL = 4 * COT;                // u4 per weight slice (one tap of one chunk, this channel tile)
   constexpr int TG = 3;                       // taps per barrier: the weight slices of a (kd, kh) row of taps travel together
   static_assert(WPL <= TM, "one u4 of a tap's weight slice per thread");
@@ -122,12 +121,11 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   if (tid < 2) s_max[tid] = 0u;
   int E = 127; // exponent of the tile's activation scale 2^E; 127 = none yet (everything staged so far was zero)
 
-  // staging items: item = tid + 256 i -> k-half item / HP (wave uniform), halo position item % HP.  Positions past
-  // HALO are padding; positions outside the grid carry an offset beyond num_records, for which buffer loads return 0.
-  // Everything derived from the thread index (these offsets, the fragment bases of the tap loop) is RECOMPUTED per chunk
-  // from an opaque copy of it: computed once here it stays alive across the tap loop, where the allocator -- at the
+  // Everything derived from the thread index (the staging offsets, the fragment bases of the tap loop) is RECOMPUTED per
+  // chunk from an opaque copy of it: computed once here it stays alive across the tap loop, where the allocator -- at the
   // 256-register limit -- spills exactly such long-lived values, and the reloads (scratch loads wait with vmcnt, memory
-  // operations retire in order) then drain the operand loads they sit between.
+  // operations retire in order) then drain the operand loads they sit between.  Quads outside the grid carry an offset
+  // beyond num_records, for which buffer loads return 0.
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
 
@@ -186,35 +184,33 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     __syncthreads(); // the previous chunk's planes are no longer read (and the prologue scalars are visible)
     // @phase 1
     {
+    // Staging by aligned 16-byte row loads: thread rt owns one QUAD of a halo row -- 4 consecutive w of row (hd, hh),
+    // starting at w0 - 4 + 4 qd (the rows are read from w0 - 4 to w0 + TW + 3: 6 / 10 quads, of which the first and the
+    // last contribute one column each) -- for all 16 channels of the chunk: 16 dwordx4 loads per thread instead of 48
+    // dword gathers (per-lane dword gathers are bound by the texture-address path: ~13 k cycles per chunk).  r % 4 == 0 and
+    // w0 % 4 == 0: a quad lies entirely inside or entirely outside the grid.
+    constexpr int QR = (TW + 8) / 4, IPH = HD * HH * QR;
+    static_assert(IPH <= TM, "one quad per thread");
     int rt = tid;
     asm volatile("" : "+v"(rt));
-    int goff[NI];
-    bool gok[NI];
+    const int row = rt / QR, qd = rt - row * QR;
+    const int hd = row / HH, hh = row - hd * HH;
+    const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw0 = w0 - 4 + 4 * qd;
+    const bool gok = rt < IPH && gd >= 0 && gd < r && gh >= 0 && gh < r && gw0 >= 0 && gw0 < r;
+    const int goff = gok ? ((gd * r + gh) * r + gw0) * 4 : 0x7fffff00;
+    const int p0 = row * HW + 4 * qd - 3; // halo position of the quad's first column (column k is used iff 0 <= hw0 + k < HW)
+    const int hw0 = 4 * qd - 3;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v[2][8];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int item = rt + TM * i, p = item % HP;
-      const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
-      const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-      gok[i] = item < 2 * HP && p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
-      goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
-    }
-    // all loads of the chunk first (one memory round trip per chunk), then activate, agree on the scale, cut + write
-    float v[NI][8];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int ig = __builtin_amdgcn_readfirstlane(min((rt + TM * i) / HP, 1));
+    for (int ig = 0; ig < 2; ++ig)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, goff[i], (q * KS + ig * 8 + j) * r3 * 4, 0));
-    }
+        v[ig][j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff, (q * KS + ig * 8 + j) * r3 * 4, 0));
     unsigned mloc = 0u;
-    if (pro_on) { // ONE uniform branch around the whole activation pass (inside the value loop it was a branch per value)
+    if (pro_on) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int ig = __builtin_amdgcn_readfirstlane(min((rt + TM * i) / HP, 1));
-        // the 8 channels' prologue scalars: three pairs of 16-byte broadcast reads per item (wave-uniform address); the
-        // activation is computed unconditionally with a select behind it (zero padding stays zero; delta mode stages the
-        // deviation from the per-channel constant)
+      for (int ig = 0; ig < 2; ++ig) {
         const int c0 = q * KS + ig * 8;
         const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), a1 = *reinterpret_cast<const float4 *>(spa + c0 + 4);
         const float4 b0 = *reinterpret_cast<const float4 *>(spb + c0), b1 = *reinterpret_cast<const float4 *>(spb + c0 + 4);
@@ -224,20 +220,27 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         const float pc8[8] = {c4.x, c4.y, c4.z, c4.w, c5.x, c5.y, c5.z, c5.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float act = pro_act(v[i][j], pa8[j], pb8[j]) - pc8[j];
-          v[i][j] = gok[i] ? act : 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float act = pro_act(v[ig][j][k], pa8[j], pb8[j]) - pc8[j];
+            v[ig][j][k] = gok ? act : 0.f;
+          }
         }
-        __builtin_amdgcn_sched_barrier(0); // one item at a time: interleaved, the items' temporaries pushed accumulators out
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const bool real = rt + TM * i < 2 * HP;
+    for (int k = 0; k < 4; ++k) {
+      const bool used = rt < IPH && hw0 + k >= 0 && hw0 + k < HW;
+      unsigned mk = 0u;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned a = __float_as_uint(v[i][j]) & 0x7fffffffu; // |t| as ordered bits; inf / nan do not set the scale:
-        mloc = (real && a > mloc && a <= 0x7f7fffffu) ? a : mloc;  // they pass through the cut as inf / nan
-      }
+      for (int ig = 0; ig < 2; ++ig)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned a = __float_as_uint(v[ig][j][k]) & 0x7fffffffu; // |t| as ordered bits; inf / nan do not set the scale
+          mk = (a > mk && a <= 0x7f7fffffu) ? a : mk;
+        }
+      mloc = (used && mk > mloc) ? mk : mloc;
     }
     mloc = wave_max_u32_lane63(mloc);
     if (lane == 63 && mloc) atomicMax(&s_max[q & 1], mloc);
@@ -263,23 +266,17 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     }
     const float xs = E == 127 ? 1.0f : pow2f(E);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int item = rt + TM * i;
-      const int ig = __builtin_amdgcn_readfirstlane(min(item / HP, 1)), p = item - ig * HP;
-      unsigned short hi[8], lo[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cut(v[i][j] * xs, hi[j], lo[j]);
-      u4 ph, pl;
+    for (int ig = 0; ig < 2; ++ig)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        ph[k] = (unsigned)hi[2 * k] | ((unsigned)hi[2 * k + 1] << 16);
-        pl[k] = (unsigned)lo[2 * k] | ((unsigned)lo[2 * k + 1] << 16);
+        u4 ph, pl;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { unsigned h2, l2; cut2(v[ig][2 * m][k] * xs, v[ig][2 * m + 1][k] * xs, h2, l2); ph[m] = h2; pl[m] = l2; }
+        if (rt < IPH && hw0 + k >= 0 && hw0 + k < HW) {
+          sx[(0 + ig) * HP + p0 + k] = ph;
+          sx[(2 + ig) * HP + p0 + k] = pl;
+        }
       }
-      if (item < 2 * HP) { // wave uniform
-        sx[(0 + ig) * HP + p] = ph;
-        sx[(2 + ig) * HP + p] = pl;
-      }
-    }
     }
     // @phase 4
     // The 27 taps.  Weight slices travel in groups of TG taps through two buffers (group k of chunk q = walk index
@@ -323,16 +320,15 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         }
       };
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // group 9 q (requested two barriers ago / in the item prologue)
-      // @phase 1
       __syncthreads(); // the chunk's operand planes and the first weight group are visible
-      // @phase 5
+      // @phase 1
       // a wave whose 64-voxel block sees no point (wave mask) takes part in the barriers and the weight DMA only: its own
       // copy of the walk, so that the working waves' 27 taps are straight-line code (one uniform branch per tap cost the
       // register allocator 350 bytes of scratch)
       auto group_barrier = [&](int k) {
         const int sg = q * (27 / TG) + k;
+        // @phase 6
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // group sg + 1 has landed
-        // @phase 1
         __syncthreads();
         // @phase 5
         if (sg + 2 < nchunks * (27 / TG)) weights_dma(sg + 2);
@@ -648,15 +644,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
     for (int i = 0; i < NI; ++i) {
       const int item = tid + TM * i;
       const int ig = __builtin_amdgcn_readfirstlane(item / HP), p = item - ig * HP;
-      unsigned short hi[8], lo[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) cut(v[i][j] * xs, hi[j], lo[j]);
       u4 ph, pl;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ph[k] = (unsigned)hi[2 * k] | ((unsigned)hi[2 * k + 1] << 16);
-        pl[k] = (unsigned)lo[2 * k] | ((unsigned)lo[2 * k + 1] << 16);
-      }
+      for (int k = 0; k < 4; ++k) { unsigned h2, l2; cut2(v[i][2 * k] * xs, v[i][2 * k + 1] * xs, h2, l2); ph[k] = h2; pl[k] = l2; }
       dstp[(0 + ig) * HP + p] = ph;
       dstp[(2 + ig) * HP + p] = pl;
     }

@@ -168,14 +168,8 @@ __global__ __launch_bounds__(256, 2) void pwconv_split_kernel(const float *__res
         }
       }
       const float xs = E[vb] == 127 ? 1.0f : pow2f(E[vb]);
-      unsigned short hi[8], lo[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cut(t[j] * xs, hi[j], lo[j]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        xh[vb][k] = (unsigned)hi[2 * k] | ((unsigned)hi[2 * k + 1] << 16);
-        xl[vb][k] = (unsigned)lo[2 * k] | ((unsigned)lo[2 * k + 1] << 16);
-      }
+      for (int k = 0; k < 4; ++k) { unsigned h2, l2; cut2(t[2 * k] * xs, t[2 * k + 1] * xs, h2, l2); xh[vb][k] = h2; xl[vb][k] = l2; }
     }
     PWS_T(64 + q);
 #pragma unroll
