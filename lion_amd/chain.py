@@ -29,7 +29,7 @@ def policy_key() -> tuple:
     from . import conv_ops, fused_ops, geometry
     from .models import pvcnn2_ada
     return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, geometry.ENABLED,
-            conv_ops.SPLIT, fused_ops.PW_SPLIT)
+            geometry.SPLIT_GRAPH, conv_ops.SPLIT, fused_ops.PW_SPLIT)
 
 
 class GraphedChain:
@@ -68,17 +68,86 @@ class GraphedChain:
                                                    _lib.ptr(self.cur), _lib.ptr(self.seed), 0, _lib.ptr(self.x),
                                                    _lib.ptr(self.z), _lib.stream_ptr(dev)), "chain_update_noise")
 
+        # Split-graph geometry overlap (geometry.SPLIT_GRAPH, models with a geometry_source()): the FPS / ball-query chain of
+        # a step depends on the coordinates of x alone, is latency bound (0.7 ms on 32 CUs) and, on one stream, serial.
+        # A parallel BRANCH inside one hipGraph replays slower than one stream on ROCm 7.2 (geometry.py), but separate
+        # graphs on separate streams do overlap.  So a step becomes three single-branch graphs:
+        #     geometry stream:  [geo: coordinates of x -> FPS / ball-query chain]            (waits for the previous step)
+        #     main stream:      [A: step prologue, forward up to the first use of a geometry result]
+        #                       wait(geo)  [B: the rest of the forward, update + noise]
+        # ordered with two events per step.  Models without set abstraction never reach "first use": one graph, as before.
+        from . import geometry
+        src = getattr(model, "geometry_source", None)
+        self.geo_graph = self.graph_b = None
+        self.geo_plan = None
+        split = geometry.SPLIT_GRAPH and src is not None and not geometry.ENABLED
+        main = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+        side.wait_stream(main)
         with _wcache.pinning(self.pinned):
             with torch.no_grad(), torch.cuda.stream(side):
                 for _ in range(warmup):   # first calls pack weights, set kernel attributes, fill caches
                     step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph):
-                step()
+            main.wait_stream(side)
+            if split:
+                # NORMAL priority: on a high-priority stream (geometry._side_stream) the same three graphs take 15.3 ms per
+                # step instead of 7.4 -- the main stream's queue starves while the 0.7-ms FPS kernels run (measured, round 3)
+                self.geo_stream = torch.cuda.Stream(device=dev)
+                self.ev_geo, self.ev_step = torch.cuda.Event(), torch.cuda.Event()
+
+                def geo():
+                    mods, coords = src(self.x)
+                    return geometry.compute_chain(mods, coords)
+                self.geo_stream.wait_stream(main)
+                with torch.no_grad(), torch.cuda.stream(self.geo_stream):
+                    geo()
+                main.wait_stream(self.geo_stream)
+                torch.cuda.synchronize(dev)
+                self.geo_graph = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(self.geo_graph, stream=self.geo_stream):
+                    self.geo_plan = geo()
+                torch.cuda.synchronize(dev)
+                graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                used = []
+
+                def first_use():   # called inside the forward, on the capturing stream
+                    graph_a.capture_end()
+                    graph_b.capture_begin(pool=graph_a.pool())
+                    used.append(True)
+                cap = torch.cuda.Stream(device=dev)
+                cap.wait_stream(main)
+                with torch.no_grad(), torch.cuda.stream(cap), geometry.external(self.geo_plan, first_use):
+                    graph_a.capture_begin()
+                    try:
+                        step()
+                    finally:
+                        (graph_b if used else graph_a).capture_end()
+                main.wait_stream(cap)
+                self.graph = graph_a
+                if used:
+                    self.graph_b = graph_b
+                else:              # the forward never asked for a geometry result: one graph, no geometry stream
+                    self.geo_graph = self.geo_plan = None
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(self.graph):
+                    step()
         self.pinned = list({id(v): v for v in self.pinned}.values())   # one reference per distinct object
+
+    def replay(self):
+        """one chain step on the current stream (+ the geometry stream in split mode)"""
+        if self.graph_b is None:
+            self.graph.replay()
+            return
+        main = torch.cuda.current_stream(self.x.device)
+        self.ev_step.record(main)                 # x of this step is final (and last step's readers of the plan are done)
+        self.geo_stream.wait_event(self.ev_step)
+        with torch.cuda.stream(self.geo_stream):
+            self.geo_graph.replay()
+            self.ev_geo.record(self.geo_stream)
+        self.graph.replay()                       # A: overlaps the geometry chain
+        main.wait_event(self.ev_geo)
+        self.graph_b.replay()
 
     def matches(self, condition_input, clip_feat):
         same = lambda buf, new: (buf is None) == (new is None) and (buf is None or buf.shape == new.shape)
@@ -105,7 +174,7 @@ class GraphedChain:
         for i in range(S):
             if trajectory is not None and trajectory_before_last and i == S - 1:
                 trajectory.append(self.x.clone())
-            self.graph.replay()
+            self.replay()
             if noise_trajectory is not None and self.z is not None:
                 noise_trajectory.append(self.z.clone())
             if trajectory is not None and not (trajectory_before_last and i == S - 1):

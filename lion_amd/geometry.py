@@ -24,6 +24,10 @@ _SIDE = {}
 # count and CP-wait knobs do not change it; under rocprofv3 the branches do overlap and the step takes 9.1 ms).  Eager
 # launches gain 0.4 ms from the prefetch (9.2 -> 8.8 ms).  LION_GEOMETRY_PREFETCH=1 turns it on.
 ENABLED = __import__("os").environ.get("LION_GEOMETRY_PREFETCH", "0") != "0"
+# What does overlap: SEPARATE single-branch graphs on separate streams.  A captured sampling chain (lion_amd/chain.py) runs the
+# geometry chain of a step as its own graph on the geometry stream, beside the part of the forward that does not need it
+# yet (compute_chain / external below).  LION_GEOMETRY_SPLIT_GRAPH=0 keeps everything in one graph on one stream.
+SPLIT_GRAPH = __import__("os").environ.get("LION_GEOMETRY_SPLIT_GRAPH", "1") != "0"
 
 
 def _side_stream(device):
@@ -37,6 +41,11 @@ def _side_stream(device):
 
 def _take(entry):
     tensor, event = entry[-2], entry[-1]
+    if event is None:   # an entry of an external plan (split-graph chains): ordering is the plan owner's business
+        if _PLAN is not None and _PLAN.get("first_use") is not None:
+            cb, _PLAN["first_use"] = _PLAN["first_use"], None
+            cb()
+        return tensor
     cur = torch.cuda.current_stream(tensor.device)
     cur.wait_event(event)
     tensor.record_stream(cur)
@@ -57,36 +66,90 @@ def lookup_ball_query(centers, points, radius, num_neighbors):
     return None if hit is None else _take(hit)
 
 
+def compute_chain(sa_modules, coords, stream=None):
+    """FPS -> ball queries -> next FPS ... of the set-abstraction stages on `coords`, launched on the current stream.
+    With `stream` given an event is recorded behind every result (the in-forward prefetch); without, entries carry
+    None (external plans: a chain runner orders whole graphs instead)."""
+    from .functional.ball_query import _ball_query_compute
+    from .functional.sampling import _fps_compute
+    plan = {"fps": {}, "bq": {}, "root": coords}
+    cur = coords
+    for m in sa_modules:
+        if getattr(m, "num_centers", None) is None:
+            break
+        centers = _fps_compute(cur, m.num_centers)
+        ev = None
+        if stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        plan["fps"][(id(cur), int(m.num_centers))] = (cur, centers, ev)  # `cur` kept alive: its id is the key
+        for g in m.groupers:
+            idx = _ball_query_compute(centers, cur, g.radius, g.num_neighbors)
+            ev2 = None
+            if stream is not None:
+                ev2 = torch.cuda.Event()
+                ev2.record(stream)
+            plan["bq"][(id(centers), id(cur), float(g.radius), int(g.num_neighbors))] = (centers, cur, idx, ev2)
+        cur = centers
+    return plan
+
+
+_EXTERNAL = None
+
+
+@contextlib.contextmanager
+def external(plan, first_use=None):
+    """A chain runner (lion_amd/chain.py, split-graph mode) computed `plan` = compute_chain(...) on a static copy of the
+    coordinates the forward inside this context will see, in its own graph on its own stream.  The forward's
+    `prefetch()` then adopts it instead of launching anything; `first_use()` is called once, right before the first
+    result is handed to the forward (the runner ends its first graph / waits for the geometry stream there)."""
+    global _EXTERNAL
+    prev, _EXTERNAL = _EXTERNAL, (plan, first_use)
+    try:
+        yield
+    finally:
+        _EXTERNAL = prev
+
+
+def _adopt(ext, coords):
+    """the external plan, re-keyed on this forward's root tensor (every other key is a tensor of the plan itself)"""
+    plan, first_use = ext
+    root = plan["root"]
+    if tuple(root.shape) != tuple(coords.shape) or root.device != coords.device:
+        return None
+    out = {"fps": dict(plan["fps"]), "bq": dict(plan["bq"]), "first_use": first_use, "keep": coords}
+    for (cid, n), ent in plan["fps"].items():
+        if cid == id(root):
+            out["fps"][(id(coords), n)] = ent
+    for (ctr, pts, r, k), ent in plan["bq"].items():
+        if pts == id(root):
+            out["bq"][(ctr, id(coords), r, k)] = ent
+    return out
+
+
 @contextlib.contextmanager
 def prefetch(sa_modules, coords):
     """sa_modules: the PointNetSAModule of each stage, in order; coords f32[B,3,N] (the tensor object
     the first stage will receive)."""
     global _PLAN
+    if _EXTERNAL is not None and sa_modules and coords.is_cuda and not torch.is_grad_enabled():
+        adopted = _adopt(_EXTERNAL, coords)
+        if adopted is not None:
+            prev, _PLAN = _PLAN, adopted
+            try:
+                yield
+            finally:
+                _PLAN = prev
+            return
     if (not ENABLED or not sa_modules or not coords.is_cuda or torch.is_grad_enabled() or coords.dim() != 3
             or coords.shape[1] != 3 or not coords.is_contiguous() or coords.dtype != torch.float32):
         yield
         return
-    from .functional.ball_query import _ball_query_compute
-    from .functional.sampling import _fps_compute
     main = torch.cuda.current_stream(coords.device)
     side = _side_stream(coords.device)
     side.wait_stream(main)
-    plan = {"fps": {}, "bq": {}}
     with torch.cuda.stream(side):
-        cur = coords
-        for m in sa_modules:
-            if getattr(m, "num_centers", None) is None:
-                break
-            centers = _fps_compute(cur, m.num_centers)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            plan["fps"][(id(cur), int(m.num_centers))] = (cur, centers, ev)  # `cur` kept alive: its id is the key
-            for g in m.groupers:
-                idx = _ball_query_compute(centers, cur, g.radius, g.num_neighbors)
-                ev2 = torch.cuda.Event()
-                ev2.record(side)
-                plan["bq"][(id(centers), id(cur), float(g.radius), int(g.num_neighbors))] = (centers, cur, idx, ev2)
-            cur = centers
+        plan = compute_chain(sa_modules, coords, side)
     prev, _PLAN = _PLAN, plan
     try:
         yield

@@ -87,6 +87,10 @@ class PVCNN2Unet(nn.Module):
             emb = nn.functional.pad(emb, (0, 1), "constant", 0)
         return emb
 
+    def sa_modules(self):
+        """the PointNetSAModule of every set-abstraction stage, in order (lion_amd/geometry.py)"""
+        return [blk[-1] if isinstance(blk, nn.Sequential) else blk for blk in self.sa_layers]
+
     def forward(self, inputs, **kwargs):
         B = inputs.shape[0]
         coords = inputs[:, :self.input_dim, :].contiguous()
@@ -111,7 +115,7 @@ class PVCNN2Unet(nn.Module):
 
         if getattr(self, '_style_plan', None) is None:
             self._style_plan = StylePlan(self)
-        sa_mods = [blk[-1] if isinstance(blk, nn.Sequential) else blk for blk in self.sa_layers]
+        sa_mods = self.sa_modules()
         geo = geometry.prefetch(sa_mods, coords) if pvcnn2_ada.FUSE_INFERENCE and not self.training \
             else contextlib.nullcontext()
         # one GEMM for every AdaGN projection; FPS / ball-query chain on a side stream (inference)

@@ -35,6 +35,12 @@ class PVCNN2Prior(PVCNN2Unet):
             self.mixing_logit = None
         self.is_active = None
 
+    def geometry_source(self, x):
+        """(set-abstraction modules, coordinates f32[B,3,N]) exactly as forward() derives them from x: what a chain runner
+        needs to compute the FPS / ball-query chain of a step ahead of the forward (lion_amd/chain.py, geometry.py)"""
+        pts = x.view(-1, self.num_points, self.num_classes).permute(0, 2, 1).contiguous()
+        return self.sa_modules(), pts[:, :self.input_dim, :].contiguous()
+
     def forward(self, x, t, *args, **kwargs):
         """x: [B, N*D] or [B, N*D, 1, 1] -> same shape (predicted noise)."""
         assert 'condition_input' in kwargs, 'require condition_input'
