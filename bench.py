@@ -473,6 +473,27 @@ def main():
             td = ev_time(lambda: bk.trilinear_devoxelize_forward(r, False, nc, gridv), 20)
             dbytes = 4.0 * B * (3 * N + C * min(r ** 3, 8 * N) + C * N)       # 8 corners per point
             roofd = hbm_roofline("trilinear_devoxelize C=64 N=2048 r=32 (eval): devoxelize.hip", dbytes, td)
+            # backward scatters of the training path (K5, K8, K12-grad) at the largest shapes of a forward; algorithmic bytes =
+            # gradient in + indices / weights + dense gradient out, each once (tools/kbench.py --only bwd uses the same)
+            _, inds, wgts = bk.trilinear_devoxelize_forward(r, True, nc, gridv)
+            gyp = torch.randn(B, C, N, device=dev)
+            tk5 = ev_time(lambda: bk.trilinear_devoxelize_backward(gyp, inds, wgts, r), 10)
+            roofb = {"K5": hbm_roofline("trilinear_devoxelize_backward C=64 N=2048 r=32: devox_bwd_lds_kernel",
+                                        4.0 * B * (C * N + 16 * N + C * r ** 3), tk5)}
+            del gridv, inds, wgts, gyp
+            Cg, Ng, Mg = 35, 2048, 1024
+            gidx = torch.randint(0, Ng, (B, Mg, 32), device=dev, dtype=torch.int32)
+            gyg = torch.randn(B, Cg, Mg, 32, device=dev)
+            tk8 = ev_time(lambda: bk.grouping_backward(gyg, gidx, Ng), 10)
+            roofb["K8"] = hbm_roofline("grouping_backward C=35 N=2048 M=1024 U=32 (SA-0)", 4.0 * B * (Cg * Mg * 32 + Mg * 32 + Cg * Ng), tk8)
+            del gidx, gyg
+            Ci, Ni, Mi = 192, 2048, 1024
+            pts = torch.randn(B, 3, Ni, device=dev)
+            _, ii, iw = bk.three_nearest_neighbors_interpolate_forward(pts, pts[:, :, :Mi].contiguous(), torch.randn(B, Ci, Mi, device=dev))
+            gyi = torch.randn(B, Ci, Ni, device=dev)
+            tk12 = ev_time(lambda: bk.three_nearest_neighbors_interpolate_backward(gyi, ii, iw, Mi), 10)
+            roofb["K12g"] = hbm_roofline("three_nn_interpolate_backward C=192 N=2048 M=1024 (FP-0)", 4.0 * B * (Ci * Ni + 6 * Ni + Ci * Mi), tk12)
+            del pts, ii, iw, gyi
         out = {
             "metric": "shapes/sec @1000-step DDIM, Bx2048pts", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
@@ -506,6 +527,7 @@ def main():
                                "the exact empty-tile skip saves a trajectory-dependent share of the conv work: "
                                "ms_per_step_dense_convs is the same call with every tile computed (short chain)"},
             "roofline": roof, "roofline_fp32_kernel": roof32, "roofline_voxelize": roofv, "roofline_devoxelize": roofd,
+            "roofline_backward_operators": roofb,
         }
         if world > 1:  # the host baseline belongs to the 1-GPU line (other ranks would idle behind it)
             out["cpu_baseline"] = {"value": None, "unit": "shapes/s", "cores": os.cpu_count(), "kind": "port",

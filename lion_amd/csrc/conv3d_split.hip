@@ -309,13 +309,16 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       asm volatile("" : "+v"(wq2[1]));
       u4 wf[2][CB][2], xf[2][VB][2];
       constexpr int NR = 2 * VB + 2 * CB; // fragment reads per tap
+      // read r_ of a tap, in the order the tap's MFMAs need them: X_h (VB), W_h (CB) -- the main sweep --, then X_l (VB),
+      // then W_l (CB); LDS returns in order, so the counted wait in front of the first MFMA covers only the first VB + CB
       auto frag = [&](int tap, int s_, int r_) {
-        if (r_ < 2 * VB) {
-          const int pc = r_ / VB, vb = r_ % VB;
+        const int pc = r_ >= VB + CB, rr = pc ? r_ - (VB + CB) : r_;
+        if (rr < VB) {
+          const int vb = rr;
           const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
           xf[s_][vb][pc] = *(lds_u4 *)(uintptr_t)(xq[vb] + (uint32_t)((pc * 2 * HP + toff) * 16));
         } else {
-          const int pc = (r_ - 2 * VB) / CB, cb = (r_ - 2 * VB) % CB, k = tap / TG, t = tap % TG;
+          const int cb = rr - VB, k = tap / TG, t = tap % TG;
           wf[s_][cb][pc] = *(lds_u4 *)(uintptr_t)(wq2[k & 1] + (uint32_t)((t * WPL + pc * 2 * COT + cb * 32) * 16));
         }
       };
@@ -351,9 +354,12 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
           constexpr int NM = 3 * CB * VB;
 #pragma unroll
           for (int m = 0; m < NM; ++m) {
+            // the reads of tap + 1: PER per MFMA slot from slot 1 on (1 at CB = 2: slots 1 .. 8 of 11; 2 at CB = 1), so that
+            // the last of them has the rest of this tap to land
+            constexpr int PER = (NR + NM - 2) / (NM - 1);
             if (m >= 1 && tap + 1 < 27) {
 #pragma unroll
-              for (int r_ = (m - 1) * NR / (NM - 1); r_ < m * NR / (NM - 1); ++r_) frag(tap + 1, nxt, r_);
+              for (int r_ = (m - 1) * PER; r_ < m * PER && r_ < NR; ++r_) frag(tap + 1, nxt, r_);
             }
             mfma(m);
             __builtin_amdgcn_sched_barrier(0);

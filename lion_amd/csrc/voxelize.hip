@@ -400,13 +400,20 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static VoxPlan make_plan(int B, int C, int N, int r) {
   VoxPlan p;
   const long r3 = (long)r * r * r;
+  // Clouds of <= 1024 points (one point per thread: 42 registers, 8 waves per SIMD) run TWO workgroups per CU on half the
+  // LDS each: one's index / mean phases overlap the other's store phase ((128,1024,16), B = 32: 41 -> 35 us).  The
+  // 2048-point kernel needs 74 registers (one workgroup per CU); forced to 62 and split into 16 slabs it is slower
+  // (70 -> 74 us), so r = 32 keeps one workgroup per CU.
+  const bool two_per_cu = N <= VT;
+  const long wgs = two_per_cu ? 512 : 256;
+  const size_t lds_limit = two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT;
   // slabs per cloud: enough workgroups to touch every CU, slabs of >= 512 voxels (int4 groups)
   int S = 1;
-  while (S < 16 && (long)B * S < 256 && r3 / (S * 2) >= 512 && (r3 % (S * 2 * 4)) == 0) S *= 2;
+  while (S < 16 && (long)B * S < wgs && r3 / (S * 2) >= 512 && (r3 % (S * 2 * 4)) == 0) S *= 2;
   p.S = S;
   // ... and, for small grids, ranges of channels (each workgroup redoes the cheap index phase)
   int CS = 1;
-  while ((long)B * S * CS < 256 && C / (CS * 2) >= 8) CS *= 2;
+  while ((long)B * S * CS < wgs && C / (CS * 2) >= 8) CS *= 2;
   p.CS = CS;
   p.SV = (int)(r3 / S);
   p.n_words = align4i(N);
@@ -419,7 +426,7 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
   const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
   size_t want = ((size_t)N + nocc) * (C > 0 ? C : 1) * 4;
   if (want < need_a) want = need_a;
-  const size_t avail = fixed < (size_t)LDS_LIMIT ? (size_t)LDS_LIMIT - fixed : 0;
+  const size_t avail = fixed < lds_limit ? lds_limit - fixed : 0;
   const size_t arena = want < avail ? want : avail;
   p.arena_words = (int)(arena / 4);
   p.lds = fixed + (size_t)p.arena_words * 4;
