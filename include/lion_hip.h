@@ -295,6 +295,28 @@ int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows,
 int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int rows, int M, int U,
                           float *y, lionStream_t stream);
 
+/* ---- training forms of GroupNorm / AdaGN (+ Swish): models/adagn.py:45-65, models/pvcnn2_ada.py:78-84 --------------
+ * Per row (b, c) of length L a GroupNorm followed by per-(batch, channel) scalars and an activation is
+ * y = act(A x + Bs) (act: 0 identity, 1 swish).  Forward: lion_row_stats + lion_affine_act.  Backward:
+ * lion_affine_act_bwd_stats -> S f32[rows, 2] = {sum da, sum da x} with da = gy act'(A x + Bs); the caller combines them
+ * into Q, R f32[rows] (group means of the normalisation's gradient) and the parameter gradients;
+ * lion_affine_act_bwd_apply writes dx = A da + Q + R x.  (csrc/norm_train.hip, lion_amd/train_ops.py) */
+/* the [B, C] scalar algebra of both directions (double inside).  fac / bias f32[B, *] with row strides (views of the
+ * [B, 2C] AdaGN projection) or NULL (plain GroupNorm); dfac / dbias may be NULL; pw f32[B,C,2] = per-sample terms of the
+ * GroupNorm weight / bias gradients (the caller sums them over the batch). */
+int lion_gn_train_fold(const float *stats, const float *gw, const float *gb, const float *fac, int fac_stride,
+                       const float *bias, int bias_stride, int B, int C, int G, int L, float eps, float *A, float *Bs,
+                       float *mean, float *rstd, lionStream_t stream);
+int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
+                           const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
+                           float *dbias, float *pw, lionStream_t stream);
+int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
+                    lionStream_t stream);
+int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,
+                              float *S, lionStream_t stream);
+int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                              const float *R, int rows, int L, int act, float *dx, lionStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

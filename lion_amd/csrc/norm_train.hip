@@ -1,0 +1,213 @@
+// norm_train.hip -- the TRAINING forms of P2/P3 (GroupNorm / AdaGN + Swish around the voxel and point convolutions;
+// reference models/adagn.py:45-65, models/pvcnn2_ada.py:78-84, :120-164, :211-222).
+//
+// ATen runs y = swish(GroupNorm8(x) * factor + bias) as group_norm, mul, add, sigmoid, mul -- five passes over the
+// activation forward (268 MB at [32, 64, 32^3]) and about ten backward.  A GroupNorm followed by per-(batch, channel)
+// scalars and an activation is, per row (b, c) of length L,
+//     y = act(A x + Bs),   A = rstd_g gw_c f_bc,   Bs = (gb_c - mean_g rstd_g gw_c) f_bc + b_bc
+// so the forward is lion_row_stats (one read) + lion_affine_act (one read, one write), and the backward -- with
+// da = gy act'(A x + Bs), n = (x - mean) rstd, dn = gw f da --
+//     dx = rstd (dn - mean_g(dn) - n mean_g(dn n)) = A da + Q_bg + R_bg x
+// needs the per-row sums S1 = sum da, S2 = sum da x (lion_affine_act_bwd_stats: reads x, gy) and one elementwise pass
+// (lion_affine_act_bwd_apply: reads x, gy, writes dx); every parameter gradient is a combination of S1, S2 on [B, C]
+// scalars (lion_amd/train_ops.py).  act: 0 identity, 1 swish.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_f(float a, int act) { return act ? swish_fast(a) : a; }
+// d act(a) / da;  swish'(a) = s (1 + a (1 - s)),  s = sigmoid(a)
+__device__ __forceinline__ float act_d(float a, int act) {
+  if (!act) return 1.0f;
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+  return s * (1.0f + a * (1.0f - s));
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float *__restrict__ x, const float *__restrict__ A,
+                                                         const float *__restrict__ Bs, int L, int act,
+                                                         float *__restrict__ y) {
+  const int row = blockIdx.y;
+  const float a = A[row], b = Bs[row];
+  const float *p = x + (size_t)row * L;
+  float *q = y + (size_t)row * L;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < L && (L & 3) == 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + i);
+    *reinterpret_cast<float4 *>(q + i) = make_float4(act_f(v.x * a + b, act), act_f(v.y * a + b, act),
+                                                     act_f(v.z * a + b, act), act_f(v.w * a + b, act));
+  } else {
+    for (int j = i; j < L && j < i + 4; ++j) q[j] = act_f(p[j] * a + b, act);
+  }
+}
+
+// one workgroup per row: S[row] = {sum da, sum da x}
+__global__ __launch_bounds__(256) void affine_act_bwd_stats_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                   const float *__restrict__ A,
+                                                                   const float *__restrict__ Bs, int L, int act,
+                                                                   float *__restrict__ S) {
+  __shared__ float r1[4], r2[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float a = A[row], b = Bs[row];
+  const float *p = x + (size_t)row * L, *g = gy + (size_t)row * L;
+  float s1 = 0.f, s2 = 0.f;
+  if ((L & 3) == 0) {
+    for (int i = tid * 4; i < L; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4 *>(p + i), w = *reinterpret_cast<const float4 *>(g + i);
+      const float d0 = w.x * act_d(v.x * a + b, act), d1 = w.y * act_d(v.y * a + b, act);
+      const float d2 = w.z * act_d(v.z * a + b, act), d3 = w.w * act_d(v.w * a + b, act);
+      s1 += (d0 + d1) + (d2 + d3);
+      s2 += (d0 * v.x + d1 * v.y) + (d2 * v.z + d3 * v.w);
+    }
+  } else {
+    for (int i = tid; i < L; i += 256) { const float d = g[i] * act_d(p[i] * a + b, act); s1 += d; s2 += d * p[i]; }
+  }
+  s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+#pragma unroll
+  for (int m = 16; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (lane == 0) { r1[wave] = s1; r2[wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    S[(size_t)row * 2] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    S[(size_t)row * 2 + 1] = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                   const float *__restrict__ A,
+                                                                   const float *__restrict__ Bs,
+                                                                   const float *__restrict__ Q,
+                                                                   const float *__restrict__ R, int L, int act,
+                                                                   float *__restrict__ dx) {
+  const int row = blockIdx.y;
+  const float a = A[row], b = Bs[row], qq = Q[row], rr = R[row];
+  const float *p = x + (size_t)row * L, *g = gy + (size_t)row * L;
+  float *o = dx + (size_t)row * L;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < L && (L & 3) == 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + i), w = *reinterpret_cast<const float4 *>(g + i);
+    *reinterpret_cast<float4 *>(o + i) = make_float4(a * (w.x * act_d(v.x * a + b, act)) + qq + rr * v.x,
+                                                     a * (w.y * act_d(v.y * a + b, act)) + qq + rr * v.y,
+                                                     a * (w.z * act_d(v.z * a + b, act)) + qq + rr * v.z,
+                                                     a * (w.w * act_d(v.w * a + b, act)) + qq + rr * v.w);
+  } else {
+    for (int j = i; j < L && j < i + 4; ++j) o[j] = a * (g[j] * act_d(p[j] * a + b, act)) + qq + rr * p[j];
+  }
+}
+
+// the [B, C] scalar algebra of both directions, one workgroup per sample (C <= 1024 threads), in double
+// forward: stats [B,C,2] (row sums) -> A, Bs, mean, rstd [B,C]
+__global__ void gn_train_fold_kernel(const float *__restrict__ stats, const float *__restrict__ gw,
+                                     const float *__restrict__ gb, const float *__restrict__ fac, int fs,
+                                     const float *__restrict__ bia, int bs, int C, int G, int L, float eps,
+                                     float *__restrict__ A, float *__restrict__ Bs, float *__restrict__ mean,
+                                     float *__restrict__ rstd) {
+  extern __shared__ double sh[]; // [2 C]
+  const int b = blockIdx.x, c = threadIdx.x, cpg = C / G;
+  if (c < C) { sh[c] = stats[((size_t)b * C + c) * 2]; sh[C + c] = stats[((size_t)b * C + c) * 2 + 1]; }
+  __syncthreads();
+  if (c >= C) return;
+  const int g0 = (c / cpg) * cpg;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < cpg; ++k) { s1 += sh[g0 + k]; s2 += sh[C + g0 + k]; }
+  const double cnt = (double)cpg * (double)L, m = s1 / cnt;
+  double var = s2 / cnt - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  const double f = fac ? (double)fac[(size_t)b * fs + c] : 1.0, bb = bia ? (double)bia[(size_t)b * bs + c] : 0.0;
+  const double w = gw[c], o = gb[c];
+  A[(size_t)b * C + c] = (float)(rs * w * f);
+  Bs[(size_t)b * C + c] = (float)((o - m * rs * w) * f + bb);
+  mean[(size_t)b * C + c] = (float)m;
+  rstd[(size_t)b * C + c] = (float)rs;
+}
+
+// backward: S [B,C,2] = {sum da, sum da x} -> Q, R (dx = A da + Q + R x), dfac, dbias [B,C], and the per-sample
+// terms of the GroupNorm parameter gradients pw [B,C,2] = {f T, f S1} (summed over the batch by the caller)
+__global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const float *__restrict__ mean,
+                                         const float *__restrict__ rstd, const float *__restrict__ gw,
+                                         const float *__restrict__ gb, const float *__restrict__ fac, int fs, int C,
+                                         int G, int L, float *__restrict__ Q, float *__restrict__ R,
+                                         float *__restrict__ dfac, float *__restrict__ dbias, float *__restrict__ pw) {
+  extern __shared__ double sh[]; // [2 C]: coef S1, coef T
+  const int b = blockIdx.x, c = threadIdx.x, cpg = C / G;
+  double s1 = 0.0, T = 0.0, m = 0.0, rs = 0.0, f = 1.0, w = 0.0;
+  if (c < C) {
+    s1 = S[((size_t)b * C + c) * 2];
+    const double s2 = S[((size_t)b * C + c) * 2 + 1];
+    m = mean[(size_t)b * C + c]; rs = rstd[(size_t)b * C + c];
+    f = fac ? (double)fac[(size_t)b * fs + c] : 1.0;
+    w = gw[c];
+    T = rs * (s2 - m * s1); // sum da n
+    sh[c] = w * f * s1;
+    sh[C + c] = w * f * T;
+  }
+  __syncthreads();
+  if (c >= C) return;
+  const int g0 = (c / cpg) * cpg;
+  double a1 = 0.0, a2 = 0.0;
+  for (int k = 0; k < cpg; ++k) { a1 += sh[g0 + k]; a2 += sh[C + g0 + k]; }
+  const double cnt = (double)cpg * (double)L, m1 = a1 / cnt, m2 = a2 / cnt;
+  Q[(size_t)b * C + c] = (float)(-rs * m1 + rs * rs * m * m2);
+  R[(size_t)b * C + c] = (float)(-rs * rs * m2);
+  if (dfac) dfac[(size_t)b * C + c] = (float)(w * T + (double)gb[c] * s1);
+  if (dbias) dbias[(size_t)b * C + c] = (float)s1;
+  pw[((size_t)b * C + c) * 2] = (float)(f * T);
+  pw[((size_t)b * C + c) * 2 + 1] = (float)(f * s1);
+}
+
+} // namespace
+
+extern "C" {
+
+int lion_gn_train_fold(const float *stats, const float *gw, const float *gb, const float *fac, int fac_stride,
+                       const float *bias, int bias_stride, int B, int C, int G, int L, float eps, float *A, float *Bs,
+                       float *mean, float *rstd, lionStream_t stream) {
+  if (!stats || !gw || !gb || !A || !Bs || !mean || !rstd || B <= 0 || C <= 0 || G <= 0 || C % G || L <= 0) return LION_EINVAL;
+  if (C > 1024) return LION_EUNSUPPORTED;
+  const int T = (C + 63) / 64 * 64;
+  gn_train_fold_kernel<<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
+      stats, gw, gb, fac, fac_stride, bias, bias_stride, C, G, L, eps, A, Bs, mean, rstd);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
+                           const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
+                           float *dbias, float *pw, lionStream_t stream) {
+  if (!S || !mean || !rstd || !gw || !gb || !Q || !R || !pw || B <= 0 || C <= 0 || G <= 0 || C % G || L <= 0) return LION_EINVAL;
+  if (C > 1024) return LION_EUNSUPPORTED;
+  const int T = (C + 63) / 64 * 64;
+  gn_train_bwd_fold_kernel<<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
+      S, mean, rstd, gw, gb, fac, fac_stride, C, G, L, Q, R, dfac, dbias, pw);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+
+int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
+                    lionStream_t stream) {
+  if (!x || !A || !Bs || !y || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
+  affine_act_kernel<<<dim3(lion_cdiv(lion_cdiv(L, 4), 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      x, A, Bs, L, act, y);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,
+                              float *S, lionStream_t stream) {
+  if (!x || !gy || !A || !Bs || !S || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
+  affine_act_bwd_stats_kernel<<<rows, 256, 0, static_cast<hipStream_t>(stream)>>>(x, gy, A, Bs, L, act, S);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                              const float *R, int rows, int L, int act, float *dx, lionStream_t stream) {
+  if (!x || !gy || !A || !Bs || !Q || !R || !dx || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
+  affine_act_bwd_apply_kernel<<<dim3(lion_cdiv(lion_cdiv(L, 4), 256), rows), 256, 0,
+                                static_cast<hipStream_t>(stream)>>>(x, gy, A, Bs, Q, R, L, act, dx);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+} // extern "C"

@@ -175,6 +175,30 @@ def route_1x1_convs(module):
     return module
 
 
+def run_layers(layers, x, style, conv):
+    """the generic (training / non-fused) walk over [conv, AdaGN, Swish, ...] layer lists.  With gradients enabled on the
+    GPU an AdaGN (and the Swish behind it, when there is one) is ONE differentiable op on the library's kernels
+    (lion_amd/train_ops.py: two passes forward, three backward, instead of ATen's five and ten)."""
+    from .. import train_ops
+    i, n = 0, len(layers)
+    while i < n:
+        layer = layers[i]
+        if isinstance(layer, AdaGN):
+            if train_ops.usable(x) and layer.n_channel <= 1024:
+                fused_act = i + 1 < n and isinstance(layers[i + 1], Swish)
+                factor, bias = layer.affine(style)
+                x = train_ops.adagn_act(x, layer.norm, factor, bias, act=fused_act)
+                i += 2 if fused_act else 1
+                continue
+            x = layer(x, style)
+        elif isinstance(layer, (nn.Conv1d, nn.Conv2d, nn.Conv3d)):
+            x = conv(layer, x)
+        else:
+            x = layer(x)
+        i += 1
+    return x
+
+
 class SharedMLP(nn.Module):
     """[1x1 conv -> AdaGN -> Swish] x len(out_channels) over [B,C,N] (dim=1) or [B,C,M,U] (dim=2)."""
 
@@ -201,13 +225,7 @@ class SharedMLP(nn.Module):
             n = len(self.layers) // 3
             convs, gns = [self.layers[3 * i] for i in range(n)], [self.layers[3 * i + 1] for i in range(n)]
             return fused_ops.shared_mlp(x, convs, gns, style, reduce_max)
-        for layer in self.layers:
-            if isinstance(layer, AdaGN):
-                x = layer(x, style)
-            elif isinstance(layer, (nn.Conv1d, nn.Conv2d)):
-                x = conv1x1(layer, x)
-            else:
-                x = layer(x)
+        x = run_layers(list(self.layers), x, style, conv1x1)
         return x.max(dim=-1).values if reduce_max else x
 
     def forward_max(self, x, style):
@@ -339,13 +357,7 @@ class PVConv(nn.Module):
             if self.attn is not None:
                 fused = self.attn(fused)
             return fused, coords_input, time_emb, style
-        for layer in self.voxel_layers:
-            if isinstance(layer, AdaGN):
-                grid = layer(grid, style)
-            elif isinstance(layer, nn.Conv3d):
-                grid = conv3d_module(layer, grid)  # fp32-MFMA implicit GEMM (csrc/conv3d.hip)
-            else:
-                grid = layer(grid)
+        grid = run_layers(list(self.voxel_layers), grid, style, conv3d_module)  # convs: fp32-MFMA implicit GEMM (csrc/conv3d.hip)
         fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
         if self.add_point_feat:
             fused = fused + self.point_features(features, style)

@@ -1,0 +1,96 @@
+"""Training forms of GroupNorm / AdaGN (+ Swish) on the library's own kernels (csrc/norm_train.hip).
+
+``adagn_act(x, norm, factor, bias, act)`` == ``act(norm(x) * factor[:, :, None..] + bias[:, :, None..])`` with
+``norm = nn.GroupNorm(G, C)`` (reference models/adagn.py:45-65 followed by models/pvcnn2_ada.py:78-84), differentiable in
+x, norm.weight, norm.bias, factor, bias.  ATen evaluates that expression in five passes over the activation forward and
+about ten backward; here the forward is two passes (row sums; one fused apply) and the backward three (row sums of the
+activation gradient; one fused apply) plus one small kernel per direction for the [B, C] scalar algebra (double inside).
+"""
+import os
+
+import torch
+
+from . import _lib
+
+ENABLED = os.environ.get("LION_TRAIN_FUSE", "1") != "0"
+
+
+def usable(x) -> bool:
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and x.dim() >= 3 and x[0, 0].numel() >= 1)
+
+
+def _rows(t):
+    return t.reshape(-1).contiguous()
+
+
+def _rowview(t, B, C):
+    """(pointer holder, row stride) of a [B, C] float32 view whose channel stride is 1 (a chunk of the [B, 2C] AdaGN
+    projection is such a view) -- anything else is made contiguous"""
+    t = t.reshape(B, C)
+    if t.dtype != torch.float32 or t.stride(1) != 1:
+        t = t.float().contiguous()
+    return t, int(t.stride(0))
+
+
+class _AdaGNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gw, gb, factor, bias, groups, eps, act):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        L = x[0, 0].numel()
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        stats = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_row_stats(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats")
+        A, Bs, mean, rstd = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(4))
+        gwc, gbc = gw.detach().float().contiguous(), gb.detach().float().contiguous()
+        f, fs = _rowview(factor.detach(), B, C) if factor is not None else (None, 0)
+        bb, bs = _rowview(bias.detach(), B, C) if bias is not None else (None, 0)
+        _lib.check(lib.lion_gn_train_fold(_lib.ptr(stats), _lib.ptr(gwc), _lib.ptr(gbc), _lib.ptr(f), fs, _lib.ptr(bb), bs,
+                                          B, C, groups, L, eps, _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(mean), _lib.ptr(rstd),
+                                          st), "gn_train_fold")
+        y = torch.empty_like(x)
+        _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), B * C, L, int(act), _lib.ptr(y), st), "affine_act")
+        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0))
+        ctx.meta = (groups, int(act), factor is not None, bias is not None, fs,
+                    None if factor is None else factor.shape, None if bias is None else bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, A, Bs, mean, rstd, gwc, gbc, f = ctx.saved_tensors
+        groups, act, has_f, has_b, fs, f_shape, b_shape = ctx.meta
+        gy = gy.contiguous()
+        B, C = x.shape[:2]
+        L = x[0, 0].numel()
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        S = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_affine_act_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, L, act,
+                                                 _lib.ptr(S), st), "affine_act_bwd_stats")
+        Q, R = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
+        dfac = torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None
+        dbias = torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None
+        pw = torch.empty(B, C, 2, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
+                                              _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
+                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), st), "gn_train_bwd_fold")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
+                                                     _lib.ptr(R), B * C, L, act, _lib.ptr(dx), st), "affine_act_bwd_apply")
+        dpw = pw.sum(0)                                                       # [C, 2]: d norm.weight, d norm.bias
+        dgw = dpw[:, 0].contiguous() if ctx.needs_input_grad[1] else None
+        dgb = dpw[:, 1].contiguous() if ctx.needs_input_grad[2] else None
+        dfac = dfac.reshape(f_shape) if has_f and ctx.needs_input_grad[3] else None
+        dbias = dbias.reshape(b_shape) if has_b and ctx.needs_input_grad[4] else None
+        return dx, dgw, dgb, dfac, dbias, None, None, None
+
+
+def adagn_act(x, norm, factor=None, bias=None, act=True):
+    """act(GroupNorm(x) * factor + bias); factor / bias [B, C] (or broadcastable views of it) or None."""
+    return _AdaGNAct.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act))

@@ -1,0 +1,87 @@
+"""-m gpu: the fused training form of GroupNorm / AdaGN (+ Swish) -- lion_amd/train_ops.py on csrc/norm_train.hip -- against
+the same expression in float64 autograd (reference models/adagn.py:45-65 followed by models/pvcnn2_ada.py:78-84): output and
+the gradient of the input, of norm.weight / norm.bias and of the style factor / bias."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, norm, factor, bias, act):
+    x64 = x.detach().double().requires_grad_(True)
+    gw = norm.weight.detach().double().requires_grad_(True)
+    gb = norm.bias.detach().double().requires_grad_(True)
+    y = torch.nn.functional.group_norm(x64, norm.num_groups, gw, gb, norm.eps)
+    leaves = [x64, gw, gb]
+    shape = (x.shape[0], -1) + (1,) * (x.dim() - 2)
+    if factor is not None:
+        f = factor.detach().double().requires_grad_(True)
+        y = y * f.reshape(shape)
+        leaves.append(f)
+    if bias is not None:
+        b = bias.detach().double().requires_grad_(True)
+        y = y + b.reshape(shape)
+        leaves.append(b)
+    if act:
+        y = y * torch.sigmoid(y)
+    return y, leaves
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16, 16), (3, 32, 101), (2, 128, 64, 32), (2, 8, 7)])
+@pytest.mark.parametrize("ada", [True, False])
+@pytest.mark.parametrize("act", [True, False])
+def test_adagn_act_matches_float64_autograd(shape, ada, act):
+    from lion_amd import train_ops
+    torch.manual_seed(hash((shape, ada, act)) % 1000)
+    B, C = shape[:2]
+    norm = torch.nn.GroupNorm(8, C).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(shape, device="cuda") * 1.7 + 0.3).requires_grad_(True)
+    proj = None
+    factor = bias = None
+    if ada:   # strided views of one [B, 2C] projection, as AdaGN.affine returns them
+        proj = (torch.randn(B, 2 * C, device="cuda") * 0.3 + torch.cat([torch.ones(C), torch.zeros(C)]).cuda()).requires_grad_(True)
+        factor, bias = proj.chunk(2, 1)
+    assert train_ops.usable(x)
+    y = train_ops.adagn_act(x, norm, factor, bias, act=act)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yr, leaves = _ref(x, norm, factor, bias, act)
+    yr.backward(gy.double())
+    tol = lambda ref: 3e-5 * max(ref.abs().max().item(), 1e-3)
+    assert (y.double() - yr).abs().max().item() <= tol(yr)
+    assert (x.grad.double() - leaves[0].grad).abs().max().item() <= tol(leaves[0].grad)
+    assert (norm.weight.grad.double() - leaves[1].grad).abs().max().item() <= 3 * tol(leaves[1].grad)
+    assert (norm.bias.grad.double() - leaves[2].grad).abs().max().item() <= 3 * tol(leaves[2].grad)
+    if ada:
+        gf, gb_ = proj.grad.double().chunk(2, 1)
+        assert (gf - leaves[3].grad).abs().max().item() <= 3 * tol(leaves[3].grad)
+        assert (gb_ - leaves[4].grad).abs().max().item() <= 3 * tol(leaves[4].grad)
+
+
+def test_training_walk_uses_the_fused_op_and_matches_the_aten_walk():
+    """a SharedMLP in training mode: the walk with LION_TRAIN_FUSE on vs off -- same output, same parameter gradients"""
+    from lion_amd import train_ops
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models.pvcnn2_ada import SharedMLP
+    cfg = released_prior_cfg("airplane")
+    torch.manual_seed(3)
+    mlp = SharedMLP(35, [64, 64, 128], dim=2, cfg=cfg).cuda().train()
+    x = torch.randn(4, 35, 128, 32, device="cuda")
+    style = torch.randn(4, cfg.latent_pts.style_dim, device="cuda")
+    outs = []
+    for on in (True, False):
+        train_ops.ENABLED = on
+        try:
+            mlp.zero_grad(set_to_none=True)
+            y = mlp(x, style)
+            y.square().mean().backward()
+            outs.append((y.detach().clone(), [p.grad.detach().clone() for p in mlp.parameters()]))
+        finally:
+            train_ops.ENABLED = True
+    (y1, g1), (y0, g0) = outs
+    assert (y1 - y0).abs().max().item() <= 1e-4 * y0.abs().max().item()
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-6)
