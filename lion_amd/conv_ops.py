@@ -192,7 +192,10 @@ class _Conv3dK3(torch.autograd.Function):
             else:
                 gw = conv3d_k3_wgrad(x, gy, weight.shape)
             if want_gb:
-                gb = gy.sum(dim=(0, 2, 3, 4))
+                # one streaming pass (row sums per (b, c), then a [B, C] -> [C] sum) instead of ATen's strided
+                # reduction over dims (0, 2, 3, 4): 240-277 us -> ~60 us at [32, 64, 32^3]
+                from . import fused_ops
+                gb = fused_ops.row_stats(gy)[:, 0].reshape(gy.shape[0], gy.shape[1]).sum(0)
         return gx, gw, gb
 
 

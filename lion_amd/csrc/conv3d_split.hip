@@ -801,7 +801,7 @@ int lion_conv3d_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *
   unsigned *tail = reinterpret_cast<unsigned *>(wp + split_piece_halfs(Cout, Cin));
   const int n = Cout * Cin * 27;
   if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return LION_EINVAL;
-  split_wmax_kernel<<<lion_cdiv(n, 256), 256, 0, st>>>(w, n, tail);
+  split_wmax_kernel<<<min(lion_cdiv(n, 2048), 128), 256, 0, st>>>(w, n, tail);
   split_wscale_kernel<<<1, 1, 0, st>>>(tail);
   split_pack_kernel<<<lion_cdiv(n, 256), 256, 0, st>>>(w, Cout, Cin, wp, tail);
   LION_LAUNCH_CHECK();

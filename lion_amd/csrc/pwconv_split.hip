@@ -352,7 +352,7 @@ int lion_pwconv_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *
   unsigned *tail = reinterpret_cast<unsigned *>(wp + pws_halfs(Cout, Cin));
   const int n = Cout * Cin, nchunks = (Cin + KS - 1) / KS, Cpad = pws_pad(Cout);
   if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return LION_EINVAL;
-  split_wmax_kernel<<<lion_cdiv(n, 256), 256, 0, st>>>(w, n, tail);
+  split_wmax_kernel<<<min(lion_cdiv(n, 2048), 128), 256, 0, st>>>(w, n, tail);
   split_wscale_kernel<<<1, 1, 0, st>>>(tail);
   pw_split_pack_kernel<<<lion_cdiv(nchunks * KS * Cpad, 256), 256, 0, st>>>(w, Cout, Cpad, Cin, nchunks, wp, tail);
   LION_LAUNCH_CHECK();

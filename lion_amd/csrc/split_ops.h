@@ -56,10 +56,21 @@ __device__ __forceinline__ f32x16 mma(u4 a, u4 b, f32x16 c) {
 // ---- the per-tensor power-of-two scale of a packed weight: tail = 4 words behind the pieces {max |w| bits, ew, 2^-ew, 0}
 // with max |w| * 2^ew in [2^13, 2^14).  pass 1: max |w| (as bits: non-negative floats order like unsigned integers).
 static __global__ void split_wmax_kernel(const float *__restrict__ w, int n, unsigned *__restrict__ tail) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned m = i < n ? (__float_as_uint(w[i]) & 0x7fffffffu) : 0u;
+  // grid-stride, ONE atomic per workgroup: with one element per thread and one atomicMax per wave a 442 k-element tensor
+  // queued 6.9 k atomics on one word (54 us -- the training step repacks ~120 weights per step)
+  __shared__ unsigned sm[4];
+  unsigned m = 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned a = __float_as_uint(w[i]) & 0x7fffffffu;
+    m = a > m ? a : m;
+  }
   for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(tail, m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = sm[k] > m ? sm[k] : m;
+    if (m) atomicMax(tail, m);
+  }
 }
 static __global__ void split_wscale_kernel(unsigned *__restrict__ tail) {
   const float m = __uint_as_float(tail[0]);

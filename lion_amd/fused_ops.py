@@ -270,6 +270,16 @@ def linear_attention_core(qkv, heads, dim_head):
     return out
 
 
+def row_stats(x):
+    """x f32[B, C, ...] -> f32[B*C, 2]: per (batch, channel) row the sum and the sum of squares (one streaming pass)"""
+    lib = _lib.load()
+    x = x.contiguous()
+    rows = x.shape[0] * x.shape[1]
+    stats = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    _lib.check(lib.lion_row_stats(_lib.ptr(x), rows, x[0, 0].numel(), _lib.ptr(stats), _lib.stream_ptr(x.device)), "row_stats")
+    return stats
+
+
 def affine_swish(x, A, Bs, reduce_max=False):
     """swish(x*A+Bs) per (batch, channel) row; reduce_max: max over the last (neighbour) dimension too."""
     lib = _lib.load()
