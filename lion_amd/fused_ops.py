@@ -230,6 +230,45 @@ def pwconv_fused(x, conv, pro=None, want_stats=True, split=None):
     return y, stats
 
 
+def pwconv_raw(x, w2d, bias=None, cached_param=None):
+    """y[b] = w2d @ x[b] (+ bias) on the library's 1x1-convolution kernels for a plain [Cout, Cin] matrix; None when
+    the shape is not supported.  cached_param: the nn.Parameter w2d is a view of (its packed form is cached per
+    version); otherwise -- transposed weights of a backward pass -- the matrix is packed for this call only."""
+    lib = _lib.load()
+    x = x.contiguous()
+    b, cin = x.shape[:2]
+    cout = w2d.shape[0]
+    L = x[0, 0].numel()
+    if not (x.is_cuda and x.dtype == torch.float32 and L > 0 and lib.lion_pwconv_stat_tiles(cout, cin, L) > 0):
+        return None
+    use_split = pw_use_split(None, b, cin, cout, L)
+    if cached_param is not None:
+        wp = _PW_SPLIT_CACHE.get(cached_param) if use_split else _PW_CACHE.get(cached_param)
+    else:
+        wp = (_pw_split_pack if use_split else _pw_pack)(w2d)
+    y = torch.empty((b, cout) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+    bias_c = bias.detach().contiguous() if bias is not None else None
+    fwd = lib.lion_pwconv_split_forward if use_split else lib.lion_pwconv_forward
+    _lib.check(fwd(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias_c), b, cin, cout, L, None, None, _lib.ptr(y), None,
+                   _lib.stream_ptr(x.device)), "pwconv_split_forward" if use_split else "pwconv_forward")
+    return y
+
+
+def pwconv_wgrad(x, gy):
+    """gw [Cout, Cin] = sum_b gy[b] @ x[b]^T for x [B, Cin, *], gy [B, Cout, *] (csrc/pwconv_wgrad.hip)"""
+    lib = _lib.load()
+    x, gy = x.contiguous(), gy.contiguous()
+    b, cin = x.shape[:2]
+    cout = gy.shape[1]
+    L = x[0, 0].numel()
+    wsb = lib.lion_pwconv_wgrad_workspace_bytes(b, cin, cout, L)
+    ws = torch.empty((wsb,), device=x.device, dtype=torch.uint8)
+    gw = torch.empty((cout, cin), device=x.device, dtype=torch.float32)
+    _lib.check(lib.lion_pwconv_wgrad(_lib.ptr(x), _lib.ptr(gy), b, cin, cout, L, _lib.ptr(ws), wsb, _lib.ptr(gw),
+                                     _lib.stream_ptr(x.device)), "pwconv_wgrad")
+    return gw
+
+
 def group_points(coords, centers, feat, idx):
     """[B, 3 + C, M, U]: neighbour coordinates relative to their centre and (feat not None) the gathered features, in
     one tensor (BallQuery.forward, pvcnn2_ada.py:98-114) -- no subtraction pass, no torch.cat."""

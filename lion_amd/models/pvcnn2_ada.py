@@ -155,6 +155,9 @@ def conv1x1(conv, x):
             y = fused_ops.linear_rows(x.reshape(x.shape[0], x.shape[1]), conv.weight.flatten(1), conv.bias)
             return y.reshape(x.shape[0], conv.out_channels, *x.shape[2:])
         return fused_ops.pwconv_fused(x, conv, None, want_stats=False)[0]  # fp32 MFMA GEMM, no layout transposes
+    from .. import train_ops
+    if train_ops.pwconv_trainable(conv, x):  # training: forward, data / weight / bias gradients on own kernels
+        return train_ops.pwconv(conv, x)
     if (x.is_cuda and torch.is_grad_enabled() and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
             and all(p == 0 for p in conv.padding) and conv.groups == 1):
         y = torch.matmul(conv.weight.flatten(1), x.flatten(2))

@@ -13,6 +13,7 @@ import torch
 from . import _lib
 
 ENABLED = os.environ.get("LION_TRAIN_FUSE", "1") != "0"
+PWCONV = os.environ.get("LION_TRAIN_PWCONV", "1") != "0"   # 1x1 convolutions of the training path on own kernels
 
 
 def usable(x) -> bool:
@@ -94,3 +95,56 @@ class _AdaGNAct(torch.autograd.Function):
 def adagn_act(x, norm, factor=None, bias=None, act=True):
     """act(GroupNorm(x) * factor + bias); factor / bias [B, C] (or broadcastable views of it) or None."""
     return _AdaGNAct.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act))
+
+
+class _PwConv(torch.autograd.Function):
+    """kernel-size-1 convolution, every direction on the library's kernels: forward and the data gradient on the 1x1
+    MFMA kernels (the data gradient = the same kernel on the transposed matrix), the weight gradient on
+    csrc/pwconv_wgrad.hip, the bias gradient as one streaming row-sum pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import fused_ops
+        w2d = weight.reshape(weight.shape[0], -1)
+        y = fused_ops.pwconv_raw(x, w2d, bias, cached_param=weight)
+        if y is None:
+            raise RuntimeError("pwconv: unsupported shape (call sites check fused_ops.pwconv_raw support first)")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import fused_ops
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        w2d = weight.detach().reshape(weight.shape[0], -1)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = fused_ops.pwconv_raw(gy, w2d.t().contiguous())
+            if gx is None:
+                gx = torch.matmul(w2d.t(), gy.flatten(2)).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = fused_ops.pwconv_wgrad(x, gy).reshape(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = fused_ops.row_stats(gy)[:, 0].reshape(gy.shape[0], gy.shape[1]).sum(0)
+        return gx, gw, gb
+
+
+def pwconv_trainable(conv, x) -> bool:
+    from . import fused_ops
+    if not (PWCONV and usable(x) and conv.groups == 1 and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
+            and all(p == 0 for p in conv.padding)):
+        return False
+    lib = _lib.load()
+    L = x[0, 0].numel()
+    # Where it pays (measured, B = 32): the grouped set-abstraction layers -- B L = 2^20 columns, <= 128 channels -- whose
+    # library backward is two transposing copies + a GEMM with K = 10^6 (1.45 ms per layer against 0.1 here): VAE step
+    # 157 -> 131 ms.  On the [32, C, 2048] layers of the prior (B L = 65536, up to 512 channels) the library GEMM is the
+    # faster one (prior step 82 vs 88 ms with everything here), so those stay on the matrix-product form.
+    return (x.shape[0] * L >= (1 << 18) and lib.lion_pwconv_stat_tiles(conv.out_channels, conv.in_channels, L) > 0
+            and (x.data_ptr() & 15) == 0)
+
+
+def pwconv(conv, x):
+    return _PwConv.apply(x, conv.weight, conv.bias)

@@ -85,3 +85,41 @@ def test_training_walk_uses_the_fused_op_and_matches_the_aten_walk():
     assert (y1 - y0).abs().max().item() <= 1e-4 * y0.abs().max().item()
     for a, b in zip(g1, g0):
         assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(4, 35, 64, 128, 32), (3, 64, 3, 1000), (2, 131, 128, 257), (2, 320, 256, 512), (32, 32, 35, 2048),
+                                   (8, 35, 64, 1024, 32)])
+def test_trainable_pwconv_matches_float64_autograd(shape):
+    """1x1 convolution with every direction on own kernels: y, dx, dW, db vs the float64 matrix product"""
+    from lion_amd import train_ops
+    torch.manual_seed(sum(shape))
+    if len(shape) == 5:
+        B, I, O, M, U = shape
+        conv = torch.nn.Conv2d(I, O, 1).cuda()
+        x = torch.randn(B, I, M, U, device="cuda").requires_grad_(True)
+    else:
+        B, I, O, L = shape
+        conv = torch.nn.Conv1d(I, O, 1).cuda()
+        x = torch.randn(B, I, L, device="cuda").requires_grad_(True)
+    # straight through the Function: pwconv_trainable() is the POLICY (only the long layers take this path in a model)
+    y = train_ops._PwConv.apply(x, conv.weight, conv.bias)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = conv.weight.detach().double().flatten(1).requires_grad_(True)
+    b64 = conv.bias.detach().double().requires_grad_(True)
+    yr = (torch.matmul(w64, x64.flatten(2)) + b64[:, None]).reshape(y.shape)
+    yr.backward(gy.double())
+    tol = lambda ref: 2e-5 * max(ref.abs().max().item(), 1e-3)
+    assert (y.double() - yr).abs().max().item() <= tol(yr)
+    assert (x.grad.double() - x64.grad).abs().max().item() <= tol(x64.grad)
+    assert (conv.weight.grad.double().flatten(1) - w64.grad).abs().max().item() <= tol(w64.grad)
+    assert (conv.bias.grad.double() - b64.grad).abs().max().item() <= tol(b64.grad)
+
+
+def test_pwconv_policy_takes_the_long_layers_only():
+    from lion_amd import train_ops
+    long_ = torch.randn(8, 35, 1024, 32, device="cuda", requires_grad=True)
+    short = torch.randn(8, 256, 2048, device="cuda", requires_grad=True)
+    assert train_ops.pwconv_trainable(torch.nn.Conv2d(35, 64, 1).cuda(), long_)
+    assert not train_ops.pwconv_trainable(torch.nn.Conv1d(256, 256, 1).cuda(), short)
