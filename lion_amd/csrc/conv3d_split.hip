@@ -337,6 +337,9 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         if (sg + 2 < nchunks * (27 / TG)) weights_dma(sg + 2);
       };
       if constexpr (WORK) {
+        // raised priority while the wave owns MFMAs: its issue wins the SIMD's arbitration against the co-resident
+        // workgroup's staging VALU (64->64@32^3: 618-624 -> 603-614 us)
+        __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int r_ = 0; r_ < NR; ++r_) frag(0, 0, r_);
 #pragma unroll
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+        __builtin_amdgcn_s_setprio(0);
       } else {
 #pragma unroll
         for (int k = 0; k < 27 / TG; ++k) group_barrier(k);
