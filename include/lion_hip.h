@@ -294,6 +294,14 @@ int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows,
                       lionStream_t stream);
 int lion_affine_swish_max(const float *x, const float *A, const float *Bs, int rows, int M, int U,
                           float *y, lionStream_t stream);
+/* y = swish(x * A + Bs) + addend (rows x L, same layout): the point branch's last activation with PVConv's residual sum
+ * (models/pvcnn2_ada.py:276-278) behind it. */
+/* emb f32[B, D]: [sin, cos] of (t_b * scale) * row_i, i < half (D = 2 half, or 2 half + 1 with a zero column):
+ * models/latent_points_ada.py get_timestep_embedding (reference latent_points_ada.py:101-115) in one launch. */
+int lion_timestep_embedding(const float *t, const float *row, float scale, int B, int half, int D, float *emb,
+                            lionStream_t stream);
+int lion_affine_swish_add(const float *x, const float *A, const float *Bs, const float *addend, int rows, int L, float *y,
+                          lionStream_t stream);
 
 /* ---- weight gradient of the 1x1 convolutions (training): gw[o][i] = sum_b sum_l gy[b][o][l] x[b][i][l] --------------
  * x f32[B,Cin,L], gy f32[B,Cout,L] (16-byte aligned), gw f32[Cout,Cin]; ws from lion_pwconv_wgrad_workspace_bytes.  What

@@ -76,6 +76,8 @@ SIGNATURES = {
     "lion_linear_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "lion_affine_swish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "lion_affine_swish_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lion_timestep_embedding": (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp]),
+    "lion_affine_swish_add": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "lion_pwconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "lion_pwconv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "lion_gn_train_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

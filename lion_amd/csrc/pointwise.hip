@@ -56,6 +56,41 @@ __global__ __launch_bounds__(256) void affine_swish_kernel(const float *__restri
   }
 }
 
+// y = swish(x * A + Bs) + addend: the last activation pass of a PVConv's point branch with the residual sum behind it
+// (fused_features = voxel_features + point_features, models/pvcnn2_ada.py:276-278) -- one launch instead of two
+__global__ __launch_bounds__(256) void affine_swish_add_kernel(const float *__restrict__ x, const float *__restrict__ A,
+                                                               const float *__restrict__ Bs,
+                                                               const float *__restrict__ addend, int L,
+                                                               float *__restrict__ y) {
+  const int row = blockIdx.y;
+  const float a = A[row], b = Bs[row];
+  const float *p = x + (size_t)row * L, *ad = addend + (size_t)row * L;
+  float *q = y + (size_t)row * L;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < L && (L & 3) == 0) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + i), w = *reinterpret_cast<const float4 *>(ad + i);
+    *reinterpret_cast<float4 *>(q + i) = make_float4(swishf(v.x * a + b) + w.x, swishf(v.y * a + b) + w.y,
+                                                     swishf(v.z * a + b) + w.z, swishf(v.w * a + b) + w.w);
+  } else {
+    for (int j = i; j < L && j < i + 4; ++j) q[j] = swishf(p[j] * a + b) + ad[j];
+  }
+}
+
+// sinusoidal timestep embedding (models/latent_points_ada.py get_timestep_embedding, reference :101-115):
+// emb[b][i] = sin((t_b * scale) * row_i), emb[b][half + i] = cos(same), one launch instead of mul, mul, sin, cos, cat
+__global__ void timestep_embedding_kernel(const float *__restrict__ t, const float *__restrict__ row, float scale, int B,
+                                          int half, int D, float *__restrict__ emb) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * D) return;
+  const int b = e / D, i = e - b * D;
+  float v = 0.f; // odd D: the last column is zero padding
+  if (i < 2 * half) {
+    const float ang = mul_rn(mul_rn(t[b], scale), row[i < half ? i : i - half]);
+    v = i < half ? sinf(ang) : cosf(ang);
+  }
+  emb[e] = v;
+}
+
 // one lane per centre m: U consecutive floats (U % 4 == 0), max of the activated values
 __global__ __launch_bounds__(256) void affine_swish_max_kernel(const float *__restrict__ x,
                                                                const float *__restrict__ A,
@@ -159,6 +194,23 @@ int lion_affine_swish(const float *x, const float *A, const float *Bs, int rows,
   if (!x || !A || !Bs || !y || rows <= 0 || L <= 0) return LION_EINVAL;
   affine_swish_kernel<<<dim3(lion_cdiv(lion_cdiv(L, 4), 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
       x, A, Bs, L, y);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_timestep_embedding(const float *t, const float *row, float scale, int B, int half, int D, float *emb,
+                            lionStream_t stream) {
+  if (!t || !row || !emb || B <= 0 || half <= 0 || D < 2 * half) return LION_EINVAL;
+  timestep_embedding_kernel<<<lion_cdiv(B * D, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(t, row, scale, B, half, D, emb);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_affine_swish_add(const float *x, const float *A, const float *Bs, const float *addend, int rows, int L, float *y,
+                          lionStream_t stream) {
+  if (!x || !A || !Bs || !addend || !y || rows <= 0 || L <= 0) return LION_EINVAL;
+  affine_swish_add_kernel<<<dim3(lion_cdiv(lion_cdiv(L, 4), 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      x, A, Bs, addend, L, y);
   LION_LAUNCH_CHECK();
   return 0;
 }

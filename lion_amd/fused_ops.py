@@ -319,11 +319,19 @@ def row_stats(x):
     return stats
 
 
-def affine_swish(x, A, Bs, reduce_max=False):
-    """swish(x*A+Bs) per (batch, channel) row; reduce_max: max over the last (neighbour) dimension too."""
+def affine_swish(x, A, Bs, reduce_max=False, add=None):
+    """swish(x*A+Bs) per (batch, channel) row; reduce_max: max over the last (neighbour) dimension too; add: a tensor of
+    the output's shape summed onto the result in the same pass."""
     lib = _lib.load()
     b, c = x.shape[:2]
     st = _lib.stream_ptr(x.device)
+    if add is not None and not reduce_max:
+        add = add.contiguous()
+        assert add.shape == x.shape and add.dtype == torch.float32
+        y = torch.empty_like(x)
+        _lib.check(lib.lion_affine_swish_add(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(add), b * c, x[0, 0].numel(),
+                                             _lib.ptr(y), st), "affine_swish_add")
+        return y
     if reduce_max:
         m, u = x.shape[2], x.shape[3]
         y = torch.empty((b, c, m), device=x.device, dtype=torch.float32)
@@ -336,7 +344,7 @@ def affine_swish(x, A, Bs, reduce_max=False):
     return y
 
 
-def shared_mlp(x, convs, adagns, style, reduce_max=False):
+def shared_mlp(x, convs, adagns, style, reduce_max=False, add=None):
     """[1x1 conv -> AdaGN -> Swish] x n (inference).  Large activations: the conv runs on the MFMA kernel,
     reads the RAW output of the previous conv and applies that layer's AdaGN + Swish in flight, and
     emits its own GroupNorm sums -- one read and one write per layer instead of five passes.  Short
@@ -358,7 +366,8 @@ def shared_mlp(x, convs, adagns, style, reduce_max=False):
         f, g = gn.affine(style)
         A, Bs, _ = groupnorm_fold(st, gn.norm, f, g, x[0, 0].numel())
         pro = (A, Bs)
-    return affine_swish(x, pro[0], pro[1], reduce_max)
+    out = affine_swish(x, pro[0], pro[1], reduce_max, add=None if reduce_max else add)
+    return out + add if (add is not None and reduce_max) else out
 
 
 def adagn_swish(x, adagn, style, reduce_max=False):

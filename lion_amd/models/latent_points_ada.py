@@ -81,6 +81,15 @@ class PVCNN2Unet(nn.Module):
             half = self.embed_dim // 2
             row = torch.from_numpy(np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))).float().to(device)
             rows[device] = row
+        if pvcnn2_ada.own_kernels(timesteps) and timesteps.dtype == torch.float32:   # inference: one launch
+            from .. import _lib
+            B = timesteps.shape[0]
+            emb = torch.empty(B, self.embed_dim, device=timesteps.device, dtype=torch.float32)
+            tc = timesteps.contiguous()
+            _lib.check(_lib.load().lion_timestep_embedding(_lib.ptr(tc), _lib.ptr(row), float(self.time_emb_scales), B,
+                                                           self.embed_dim // 2, self.embed_dim, _lib.ptr(emb),
+                                                           _lib.stream_ptr(timesteps.device)), "timestep_embedding")
+            return emb
         ang = (timesteps * self.time_emb_scales).unsqueeze(1) * row.unsqueeze(0)
         emb = torch.cat((ang.sin(), ang.cos()), dim=1)
         if self.embed_dim % 2:

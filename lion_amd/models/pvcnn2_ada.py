@@ -221,15 +221,17 @@ class SharedMLP(nn.Module):
         return (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled() and x.is_cuda
                 and x.dtype == torch.float32 and not torch.is_autocast_enabled())
 
-    def _run(self, x, style, reduce_max=False):
+    def _run(self, x, style, reduce_max=False, add=None):
         """reduce_max: additionally take the max over the last dimension (the SA modules' pooling,
-        reference :375-377), fused into the last layer's activation pass on the inference path."""
+        reference :375-377), fused into the last layer's activation pass on the inference path; add: a tensor summed
+        onto the output (PVConv's voxel features), in that same pass on the inference path."""
         if self._fusable(x):
             n = len(self.layers) // 3
             convs, gns = [self.layers[3 * i] for i in range(n)], [self.layers[3 * i + 1] for i in range(n)]
-            return fused_ops.shared_mlp(x, convs, gns, style, reduce_max)
+            return fused_ops.shared_mlp(x, convs, gns, style, reduce_max, add=add)
         x = run_layers(list(self.layers), x, style, conv1x1)
-        return x.max(dim=-1).values if reduce_max else x
+        x = x.max(dim=-1).values if reduce_max else x
+        return x if add is None else x + add
 
     def forward_max(self, x, style):
         return self._run(x, style, reduce_max=True)
@@ -355,8 +357,8 @@ class PVConv(nn.Module):
                 main.wait_stream(side)
                 pf.record_stream(main)
                 fused = fused + pf
-            elif self.add_point_feat:
-                fused = fused + self.point_features(features, style)
+            elif self.add_point_feat:   # the residual sum rides on the point branch's last activation pass
+                fused = self.point_features._run(features, style, add=fused)
             if self.attn is not None:
                 fused = self.attn(fused)
             return fused, coords_input, time_emb, style
