@@ -78,7 +78,7 @@ class GraphedChain:
         # ordered with two events per step.  Models without set abstraction never reach "first use": one graph, as before.
         from . import geometry
         src = getattr(model, "geometry_source", None)
-        self.geo_graph = self.graph_b = None
+        self.geo_graphs = self.graph_b = None
         self.geo_plan = None
         split = geometry.SPLIT_GRAPH and src is not None and not geometry.ENABLED
         main = torch.cuda.current_stream(dev)
@@ -90,44 +90,68 @@ class GraphedChain:
                     step()
             main.wait_stream(side)
             if split:
-                # NORMAL priority: on a high-priority stream (geometry._side_stream) the same three graphs take 15.3 ms per
+                # NORMAL priority: on a high-priority stream (geometry._side_stream) the same graphs take 15.3 ms per
                 # step instead of 7.4 -- the main stream's queue starves while the 0.7-ms FPS kernels run (measured, round 3)
                 self.geo_stream = torch.cuda.Stream(device=dev)
-                self.ev_geo, self.ev_step = torch.cuda.Event(), torch.cuda.Event()
+                self.ev_step = torch.cuda.Event()
 
-                def geo():
+                def geo(boundary=None):
                     mods, coords = src(self.x)
-                    return geometry.compute_chain(mods, coords)
+                    return geometry.compute_chain(mods, coords, boundary=boundary)
                 self.geo_stream.wait_stream(main)
                 with torch.no_grad(), torch.cuda.stream(self.geo_stream):
                     geo()
                 main.wait_stream(self.geo_stream)
                 torch.cuda.synchronize(dev)
-                self.geo_graph = torch.cuda.CUDAGraph()
-                with torch.no_grad(), torch.cuda.graph(self.geo_graph, stream=self.geo_stream):
-                    self.geo_plan = geo()
-                torch.cuda.synchronize(dev)
-                graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                used = []
+                # geometry graphs: [stage 0: the 2048 -> 1024 FPS, 0.55 of the chain's 0.76 ms, and its ball queries] and
+                # [the later stages] -- the forward waits for the first one only where it needs it (SA-1's grouping); the
+                # second is long done when SA-2 asks (two cuts of the main graph instead of one: 0.2 ms less exposed)
+                self.geo_graphs = [torch.cuda.CUDAGraph()]
+                gs = torch.cuda.Stream(device=dev)
+                gs.wait_stream(main)
 
-                def first_use():   # called inside the forward, on the capturing stream
-                    graph_a.capture_end()
-                    graph_b.capture_begin(pool=graph_a.pool())
-                    used.append(True)
+                def geo_cut(i):
+                    if i == 1:
+                        self.geo_graphs[-1].capture_end()
+                        self.geo_graphs.append(torch.cuda.CUDAGraph())
+                        self.geo_graphs[-1].capture_begin(pool=self.geo_graphs[0].pool())
+                with torch.no_grad(), torch.cuda.stream(gs):
+                    self.geo_graphs[0].capture_begin()
+                    try:
+                        self.geo_plan = geo(geo_cut)
+                    finally:
+                        self.geo_graphs[-1].capture_end()
+                main.wait_stream(gs)
+                torch.cuda.synchronize(dev)
+                self.geo_stage_of_graph = [0, self.geo_plan["stages"] - 1][:len(self.geo_graphs)]  # last stage each graph holds
+                self.ev_geo = [torch.cuda.Event() for _ in self.geo_graphs]
+                graphs, waits = [torch.cuda.CUDAGraph()], []   # main graphs; waits[k]: geometry graphs awaited before graphs[k+1]
+
+                def on_use(first, last):   # called inside the forward, on the capturing stream
+                    need = [g for g, st_ in enumerate(self.geo_stage_of_graph)
+                            if st_ >= first and (g == 0 or self.geo_stage_of_graph[g - 1] < last)]
+                    need = [g for g in need if not any(g in w for w in waits)]
+                    if not need:
+                        return
+                    graphs[-1].capture_end()
+                    waits.append(need)
+                    graphs.append(torch.cuda.CUDAGraph())
+                    graphs[-1].capture_begin(pool=graphs[0].pool())
                 cap = torch.cuda.Stream(device=dev)
                 cap.wait_stream(main)
-                with torch.no_grad(), torch.cuda.stream(cap), geometry.external(self.geo_plan, first_use):
-                    graph_a.capture_begin()
+                with torch.no_grad(), torch.cuda.stream(cap), geometry.external(self.geo_plan, on_use):
+                    graphs[0].capture_begin()
                     try:
                         step()
                     finally:
-                        (graph_b if used else graph_a).capture_end()
+                        graphs[-1].capture_end()
                 main.wait_stream(cap)
-                self.graph = graph_a
-                if used:
-                    self.graph_b = graph_b
+                self.graph = graphs[0]
+                if waits:
+                    self.graphs, self.waits = graphs, waits
+                    self.graph_b = graphs[1]
                 else:              # the forward never asked for a geometry result: one graph, no geometry stream
-                    self.geo_graph = self.geo_plan = None
+                    self.geo_graphs = self.geo_plan = None
             else:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.no_grad(), torch.cuda.graph(self.graph):
@@ -143,11 +167,14 @@ class GraphedChain:
         self.ev_step.record(main)                 # x of this step is final (and last step's readers of the plan are done)
         self.geo_stream.wait_event(self.ev_step)
         with torch.cuda.stream(self.geo_stream):
-            self.geo_graph.replay()
-            self.ev_geo.record(self.geo_stream)
-        self.graph.replay()                       # A: overlaps the geometry chain
-        main.wait_event(self.ev_geo)
-        self.graph_b.replay()
+            for g, ev in zip(self.geo_graphs, self.ev_geo):
+                g.replay()
+                ev.record(self.geo_stream)
+        self.graphs[0].replay()                   # overlaps the geometry chain
+        for k, need in enumerate(self.waits):
+            for g in need:
+                main.wait_event(self.ev_geo[g])
+            self.graphs[k + 1].replay()
 
     def matches(self, condition_input, clip_feat):
         same = lambda buf, new: (buf is None) == (new is None) and (buf is None or buf.shape == new.shape)

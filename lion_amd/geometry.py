@@ -41,10 +41,12 @@ def _side_stream(device):
 
 def _take(entry):
     tensor, event = entry[-2], entry[-1]
-    if event is None:   # an entry of an external plan (split-graph chains): ordering is the plan owner's business
-        if _PLAN is not None and _PLAN.get("first_use") is not None:
-            cb, _PLAN["first_use"] = _PLAN["first_use"], None
-            cb()
+    if not isinstance(event, torch.cuda.Event):   # an entry of an external plan (split-graph chains): `event` is the stage
+        plan = _PLAN                              # index; ordering is the plan owner's business
+        if plan is not None and plan.get("on_use") is not None and event is not None and event > plan["seen"]:
+            first, last = plan["seen"] + 1, event
+            plan["seen"] = event
+            plan["on_use"](first, last)           # stages first .. last are about to be read for the first time
         return tensor
     cur = torch.cuda.current_stream(tensor.device)
     cur.wait_event(event)
@@ -66,31 +68,35 @@ def lookup_ball_query(centers, points, radius, num_neighbors):
     return None if hit is None else _take(hit)
 
 
-def compute_chain(sa_modules, coords, stream=None):
+def compute_chain(sa_modules, coords, stream=None, boundary=None):
     """FPS -> ball queries -> next FPS ... of the set-abstraction stages on `coords`, launched on the current stream.
     With `stream` given an event is recorded behind every result (the in-forward prefetch); without, entries carry
-    None (external plans: a chain runner orders whole graphs instead)."""
+    their stage index (external plans: a chain runner orders whole graphs instead) and `boundary(i)` is called between
+    stage i - 1 and stage i (the runner cuts its geometry graph there)."""
     from .functional.ball_query import _ball_query_compute
     from .functional.sampling import _fps_compute
-    plan = {"fps": {}, "bq": {}, "root": coords}
+    plan = {"fps": {}, "bq": {}, "root": coords, "stages": 0}
     cur = coords
-    for m in sa_modules:
+    for i, m in enumerate(sa_modules):
         if getattr(m, "num_centers", None) is None:
             break
+        if boundary is not None and i > 0:
+            boundary(i)
         centers = _fps_compute(cur, m.num_centers)
-        ev = None
+        ev = i
         if stream is not None:
             ev = torch.cuda.Event()
             ev.record(stream)
         plan["fps"][(id(cur), int(m.num_centers))] = (cur, centers, ev)  # `cur` kept alive: its id is the key
         for g in m.groupers:
             idx = _ball_query_compute(centers, cur, g.radius, g.num_neighbors)
-            ev2 = None
+            ev2 = i
             if stream is not None:
                 ev2 = torch.cuda.Event()
                 ev2.record(stream)
             plan["bq"][(id(centers), id(cur), float(g.radius), int(g.num_neighbors))] = (centers, cur, idx, ev2)
         cur = centers
+        plan["stages"] = i + 1
     return plan
 
 
@@ -98,13 +104,13 @@ _EXTERNAL = None
 
 
 @contextlib.contextmanager
-def external(plan, first_use=None):
+def external(plan, on_use=None):
     """A chain runner (lion_amd/chain.py, split-graph mode) computed `plan` = compute_chain(...) on a static copy of the
-    coordinates the forward inside this context will see, in its own graph on its own stream.  The forward's
-    `prefetch()` then adopts it instead of launching anything; `first_use()` is called once, right before the first
-    result is handed to the forward (the runner ends its first graph / waits for the geometry stream there)."""
+    coordinates the forward inside this context will see, in its own graph(s) on its own stream.  The forward's
+    `prefetch()` then adopts it instead of launching anything; `on_use(first, last)` is called right before a result of a
+    stage not seen so far is handed to the forward (the runner cuts its main graph / waits for the geometry stream)."""
     global _EXTERNAL
-    prev, _EXTERNAL = _EXTERNAL, (plan, first_use)
+    prev, _EXTERNAL = _EXTERNAL, (plan, on_use)
     try:
         yield
     finally:
@@ -113,11 +119,11 @@ def external(plan, first_use=None):
 
 def _adopt(ext, coords):
     """the external plan, re-keyed on this forward's root tensor (every other key is a tensor of the plan itself)"""
-    plan, first_use = ext
+    plan, on_use = ext
     root = plan["root"]
     if tuple(root.shape) != tuple(coords.shape) or root.device != coords.device:
         return None
-    out = {"fps": dict(plan["fps"]), "bq": dict(plan["bq"]), "first_use": first_use, "keep": coords}
+    out = {"fps": dict(plan["fps"]), "bq": dict(plan["bq"]), "on_use": on_use, "seen": -1, "keep": coords}
     for (cid, n), ent in plan["fps"].items():
         if cid == id(root):
             out["fps"][(id(coords), n)] = ent

@@ -1,14 +1,24 @@
 # Round profile set (run through gpurun from the repo root): everything the roofline numbers of DESIGN.md / bench.py are
-# checked against.  Output: gpurun_out/profiles/<tag>_*; copy what should be judged into profiles/.
-TAG=${1:-r02}
+# checked against.  Output: gpurun_out/profiles/<tag>_*; copy what should be judged into profiles/ and stamp it with the
+# commit (tools/stamp_profiles.py -- the GPU box has no .git).
+# The driver's command runs UNTRACED first (<tag>_bench_steps20_line.json): rocprofv3 changes how graphs replay (round 2's
+# "9.22 ms" line had been taken under the tracer; untraced the same build gave 11.5), so the traced run of the same command is
+# stored as <tag>_bench_steps20_TRACED_line.json and only serves the per-kernel tables.
+TAG=${1:-r03}
 R=$PWD; O=$R/gpurun_out/profiles; mkdir -p $O
-python bench.py > $O/${TAG}_bench_default_1000steps.json 2> $O/${TAG}_bench_default.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
+python bench.py > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
+python bench.py --mode demo > $O/${TAG}_bench_demo.json 2>> $O/${TAG}_bench_default.err
 python bench.py --mode train_vae > $O/${TAG}_bench_train_vae.json 2>> $O/${TAG}_bench_default.err
 python bench.py --mode train_prior > $O/${TAG}_bench_train_prior.json 2>> $O/${TAG}_bench_default.err
-( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-dense-check > $O/${TAG}_bench_steps20_line.json 2> /dev/null )
+python bench.py --mode train_prior_clip > $O/${TAG}_bench_train_prior_clip.json 2>> $O/${TAG}_bench_default.err
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-dense-check > $O/${TAG}_bench_steps20_TRACED_line.json 2> /dev/null )
 python tools/kstats.py $O/step_trace 70 > $O/${TAG}_bench_steps20_kernel_stats.txt 2>&1
 python tools/trace_gaps.py $O/step_trace begin_step_kernel --top 45 --last 9 > $O/${TAG}_bench_steps20_timeline.txt 2>&1
 python tools/conv_split_bench.py > $O/${TAG}_conv_split_bench.txt 2>/dev/null
+python tools/sparse_conv_bench.py > $O/${TAG}_sparse_conv_bench.txt 2>/dev/null
+python tools/kbench.py > $O/${TAG}_kbench.txt 2>/dev/null
+python tools/victims_beside_conv.py --replays 40 > $O/${TAG}_victims_beside_conv.txt 2>/dev/null
 python tools/pw_bench.py > $O/${TAG}_pw_bench.txt 2>/dev/null
 python tools/fps_under_dma.py > $O/${TAG}_fps_under_dma.txt 2>/dev/null
 ./tools/exp/lds_probe > $O/${TAG}_exp_lds_b128_probe.txt 2>/dev/null
