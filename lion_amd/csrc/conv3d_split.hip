@@ -504,7 +504,7 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
 //   * weight slices by LDS-DMA in groups of 9 taps (one kd plane: 18 KiB), ring of three groups, issued TWO groups
 //     (108 MFMAs per wave) ahead; waited for with a counted s_waitcnt (memory operations retire in order; the counts
 //     below are the operations this wave is known to have issued behind the awaited DMA -- at least DMA_MIN weight
-//     instructions per group and the NI*8 operand loads -- so they can only be too strict, never too lax);
+//     instructions per group and the NLOAD operand loads -- so they can only be too strict, never too lax);
 //   * fragments of tap t+1 are read from LDS in front of the MFMAs of tap t.
 // Two facts measured in round 2 shape the workgroup (tools/exp/lds_b128_probe.hip, s_memtime): ONE wave reads LDS at
 // 32 B/clk and issues a 32x32x16 MFMA every ~64 cycles, whatever else the CU does -- four waves x (32 channels x 64
@@ -529,8 +529,6 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
   static_assert(NW == 4 || NW == 8, "4 waves x 2 column blocks or 8 waves x 1");
   constexpr int HD = TD + 2, HH = TH + 2, HW = NW == 8 ? TW + 4 : TW + 2, HALO = HD * HH * HW; // 600 / 720
   constexpr int HP = (HALO + 63) / 64 * 64;                                 // 640 / 768
-  constexpr int NI = 2 * HP / TM;                                           // 5 / 3 staging items per thread
-  static_assert(2 * HP % TM == 0, "whole staging rounds");
   constexpr int WPL = 4 * COT, TG = 9, NG = 27 / TG;                        // 128 u4 per tap slice; groups of 9 taps
   constexpr int DMA_PER_GROUP = TG * WPL / 64, DMA_MIN = DMA_PER_GROUP / NW; // 18 wave instructions over the waves
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -552,16 +550,20 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
   int E = 127;
   // @phase-init
 
-  int goff[NI];
-  bool gok[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int p = (tid + TM * i) % HP;
-    const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW; // hw >= TW + 2: padding of the row stride
-    const int gd = d0 - 1 + hd, gh = hh - 1, gw = hw - 1;
-    gok[i] = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r; // gw < r excludes the padding
-    goff[i] = gok[i] ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
-  }
+  // Staging by aligned 16-byte row loads (round 3, as conv3d_split_kernel).  At r = 8 the tile spans the whole (h, w)
+  // plane: its halo in h and w lies outside the grid -- always zero -- so only the 6 x 8 rows x 2 quads of real voxels
+  // move at all (the planes' halo slots are zeroed once, below).  Thread t < 384 owns (k-half ig, 4 of its 8 channels,
+  // row, quad): 4 dwordx4 loads, 16 values, 4 positions x 2 pieces x 8 bytes of LDS; threads 384 .. 511 issue the same
+  // number of (out-of-range, zero) loads so that the counted vmcnt waits below stay uniform.
+  static_assert(NW == 8, "the quad staging is laid out for 512 threads");
+  constexpr int NLOAD = 4;
+  const int st_ig = tid / 192, st_u = tid % 192, st_ch4 = st_u / 96, st_rq = st_u % 96;
+  const int st_row = st_rq >> 1, st_quad = st_rq & 1, st_hd = st_row >> 3, st_gh = st_row & 7;
+  const int st_gd = d0 - 1 + st_hd;
+  const bool gok = tid < 384 && st_gd >= 0 && st_gd < r;
+  const int goff = gok ? ((st_gd * r + st_gh) * r + st_quad * 4) * 4 + (st_ig * 8 + st_ch4 * 4) * r3 * 4 : 0x7fffff00;
+  // byte offset of (position of voxel 0 of the quad, this thread's 8-byte channel half) inside a [piece][half] plane pair
+  const int st_pos = (st_hd * HH + st_gh + 1) * HW + st_quad * 4 + 1;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(x + (size_t)b * Cin * r3), 0, Cin * r3 * 4, 0x00020000);
   // this lane's voxel in column block vbk = wave * VB + vb: d = vbk / 2, w = l % 8,
@@ -595,41 +597,35 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
                    : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
     }
   };
-  float v[NI][8];
-  auto issue_loads = [&](int q) { // all 40 operand loads of a chunk, unconditionally (outside the grid: offset past the end -> 0)
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 v[NLOAD];
+  auto issue_loads = [&](int q) { // the operand loads of a chunk, unconditionally (outside the grid: offset past the end -> 0)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int ig = __builtin_amdgcn_readfirstlane((tid + TM * i) / HP);
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, goff[i], (q * KS + ig * 8 + j) * r3 * 4, 0));
-    }
+    for (int j = 0; j < NLOAD; ++j)
+      v[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff, (q * KS + j) * r3 * 4, 0));
   };
   auto stage = [&](int q) { // registers -> activated, scaled, cut -> plane buffer q & 1 (contains the chunk-maximum barrier)
     unsigned mloc = 0u;
+    if (PRO) {
+      const int c0 = q * KS + st_ig * 8 + st_ch4 * 4;
+      const float4 a4 = *reinterpret_cast<const float4 *>(spa + (tid < 384 ? c0 : 0));
+      const float4 b4 = *reinterpret_cast<const float4 *>(spb + (tid < 384 ? c0 : 0));
+      const float pa[4] = {a4.x, a4.y, a4.z, a4.w}, pb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int ig = __builtin_amdgcn_readfirstlane((tid + TM * i) / HP);
-      float pa8[8], pb8[8];
-      if (PRO) { // see conv3d_split_kernel: vector broadcast reads, unconditional activation + select
-        const int c0 = q * KS + ig * 8;
-        const float4 a0 = *reinterpret_cast<const float4 *>(spa + c0), a1 = *reinterpret_cast<const float4 *>(spa + c0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(spb + c0), b1 = *reinterpret_cast<const float4 *>(spb + c0 + 4);
-        pa8[0] = a0.x; pa8[1] = a0.y; pa8[2] = a0.z; pa8[3] = a0.w; pa8[4] = a1.x; pa8[5] = a1.y; pa8[6] = a1.z; pa8[7] = a1.w;
-        pb8[0] = b0.x; pb8[1] = b0.y; pb8[2] = b0.z; pb8[3] = b0.w; pb8[4] = b1.x; pb8[5] = b1.y; pb8[6] = b1.z; pb8[7] = b1.w;
-      }
+      for (int j = 0; j < NLOAD; ++j)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float t = v[i][j];
-        if (PRO) {
-          const float act = pro_act(t, pa8[j], pb8[j]);
-          t = gok[i] ? act : 0.f;
-          v[i][j] = t;
+        for (int k = 0; k < 4; ++k) {
+          const float act = pro_act(v[j][k], pa[j], pb[j]);
+          v[j][k] = gok ? act : 0.f;
         }
-        const unsigned a = __float_as_uint(t) & 0x7fffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned a = __float_as_uint(v[j][k]) & 0x7fffffffu;
         mloc = (a > mloc && a <= 0x7f7fffffu) ? a : mloc;
       }
-    }
     mloc = wave_max_u32_lane63(mloc);
     if (lane == 63 && mloc) atomicMax(&s_max[q & 1], mloc);
     __syncthreads(); // the chunk's maximum is complete
@@ -649,19 +645,21 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
       }
     }
     const float xs = E == 127 ? 1.0f : pow2f(E);
-    u4 *dstp = sx + (q & 1) * 4 * HP;
+    if (tid < 384) {
+      uint2 *dst2 = reinterpret_cast<uint2 *>(sx + (q & 1) * 4 * HP);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int item = tid + TM * i;
-      const int ig = __builtin_amdgcn_readfirstlane(item / HP), p = item - ig * HP;
-      u4 ph, pl;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { unsigned h2, l2; cut2(v[i][2 * k] * xs, v[i][2 * k + 1] * xs, h2, l2); ph[k] = h2; pl[k] = l2; }
-      dstp[(0 + ig) * HP + p] = ph;
-      dstp[(2 + ig) * HP + p] = pl;
+      for (int k = 0; k < 4; ++k) { // voxel k of the quad: this thread's 4 channels = 8 bytes of the position's u4
+        unsigned h0, l0, h1, l1;
+        cut2(v[0][k] * xs, v[1][k] * xs, h0, l0);
+        cut2(v[2][k] * xs, v[3][k] * xs, h1, l1);
+        dst2[((0 + st_ig) * HP + st_pos + k) * 2 + st_ch4] = make_uint2(h0, h1);
+        dst2[((2 + st_ig) * HP + st_pos + k) * 2 + st_ch4] = make_uint2(l0, l1);
+      }
     }
   };
 
+  // the halo slots (and the row-stride padding) of both plane buffers are never written again: zero everything once
+  for (int e = tid; e < 2 * 4 * HP; e += TM) sx[e] = u4{0u, 0u, 0u, 0u};
   weights_dma(0);
   if (ngroups > 1) weights_dma(1);
   issue_loads(0);
@@ -678,7 +676,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
       // [grp 1, 2] the DMA of group sg + 1 and this chunk's operand prefetch (when there is a next chunk)
       const bool dma_behind = sg + 1 < ngroups;
       if (grp == 0 || !more) { if (dma_behind) wait_vm<DMA_MIN>(); else wait_vm<0>(); }
-      else { if (dma_behind) wait_vm<DMA_MIN + NI * 8>(); else wait_vm<NI * 8>(); }
+      else { if (dma_behind) wait_vm<DMA_MIN + NLOAD>(); else wait_vm<NLOAD>(); }
       // @phase 1
       __syncthreads(); // slices of group sg and (grp 0) the planes of chunk q visible; ring slot of group sg - 1 free
       // @phase 5
