@@ -55,6 +55,35 @@ def ev_time(fn, iters, warm=2):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+def ev_time_graph(fn, iters, warm=2):
+    """average seconds per call with `iters` calls captured in ONE hipGraph and the replay bracketed by HIP events on the
+    launch stream: the kernels' own time.  Eagerly, a 60-us operator whose python wrapper allocates four outputs is timed
+    at the host's launch rate, not the GPU's (round 3: the same voxelize kernel read 63 us in one tool and 72 in this
+    file, in one gpurun call)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    del g
+    return a.elapsed_time(b) / iters * 1e-3
+
+
 def hbm_roofline(kernel, algorithmic_bytes, seconds):
     """achieved = SURVEY.md 8d algorithmic bytes / HIP-event time; frac against the 8.0 TB/s spec, frac_of_copy_ceiling
     against the 6.29 TB/s a float4 copy reaches on this part (MI355X_MICROARCH.md).  traffic: HBM bytes per launch
@@ -468,33 +497,33 @@ def main():
             C, N, r = 64, 2048, 32
             co = torch.randn(B, 3, N, device=dev)
             ft = torch.randn(B, C, N, device=dev)
-            tv = ev_time(lambda: bk.voxelize_points_forward(ft, co, r, True, 0.0), 20)
+            tv = ev_time_graph(lambda: bk.voxelize_points_forward(ft, co, r, True, 0.0), 20)
             vbytes = 4.0 * B * (3 * N + C * N + C * r ** 3 + N + r ** 3) + 4.0 * B * 3 * N
             roofv = hbm_roofline("voxelize_points (P1+K1+K2) C=64 N=2048 r=32: vox_fused_kernel", vbytes, tv)
             _, nc, _, _ = bk.voxelize_points_forward(None, co, r, True, 0.0)
             gridv = torch.randn(B, C, r ** 3, device=dev)
-            td = ev_time(lambda: bk.trilinear_devoxelize_forward(r, False, nc, gridv), 20)
+            td = ev_time_graph(lambda: bk.trilinear_devoxelize_forward(r, False, nc, gridv), 20)
             dbytes = 4.0 * B * (3 * N + C * min(r ** 3, 8 * N) + C * N)       # 8 corners per point
             roofd = hbm_roofline("trilinear_devoxelize C=64 N=2048 r=32 (eval): devoxelize.hip", dbytes, td)
             # backward scatters of the training path (K5, K8, K12-grad) at the largest shapes of a forward; algorithmic bytes =
             # gradient in + indices / weights + dense gradient out, each once (tools/kbench.py --only bwd uses the same)
             _, inds, wgts = bk.trilinear_devoxelize_forward(r, True, nc, gridv)
             gyp = torch.randn(B, C, N, device=dev)
-            tk5 = ev_time(lambda: bk.trilinear_devoxelize_backward(gyp, inds, wgts, r), 10)
+            tk5 = ev_time_graph(lambda: bk.trilinear_devoxelize_backward(gyp, inds, wgts, r), 10)
             roofb = {"K5": hbm_roofline("trilinear_devoxelize_backward C=64 N=2048 r=32: devox_bwd_lds_kernel",
                                         4.0 * B * (C * N + 16 * N + C * r ** 3), tk5)}
             del gridv, inds, wgts, gyp
             Cg, Ng, Mg = 35, 2048, 1024
             gidx = torch.randint(0, Ng, (B, Mg, 32), device=dev, dtype=torch.int32)
             gyg = torch.randn(B, Cg, Mg, 32, device=dev)
-            tk8 = ev_time(lambda: bk.grouping_backward(gyg, gidx, Ng), 10)
+            tk8 = ev_time_graph(lambda: bk.grouping_backward(gyg, gidx, Ng), 10)
             roofb["K8"] = hbm_roofline("grouping_backward C=35 N=2048 M=1024 U=32 (SA-0)", 4.0 * B * (Cg * Mg * 32 + Mg * 32 + Cg * Ng), tk8)
             del gidx, gyg
             Ci, Ni, Mi = 192, 2048, 1024
             pts = torch.randn(B, 3, Ni, device=dev)
             _, ii, iw = bk.three_nearest_neighbors_interpolate_forward(pts, pts[:, :, :Mi].contiguous(), torch.randn(B, Ci, Mi, device=dev))
             gyi = torch.randn(B, Ci, Ni, device=dev)
-            tk12 = ev_time(lambda: bk.three_nearest_neighbors_interpolate_backward(gyi, ii, iw, Mi), 10)
+            tk12 = ev_time_graph(lambda: bk.three_nearest_neighbors_interpolate_backward(gyi, ii, iw, Mi), 10)
             roofb["K12g"] = hbm_roofline("three_nn_interpolate_backward C=192 N=2048 M=1024 (FP-0)", 4.0 * B * (Ci * Ni + 6 * Ni + Ci * Mi), tk12)
             del pts, ii, iw, gyi
         out = {
