@@ -9,8 +9,9 @@
 // column (2 voxels x 32 (ci, tap) columns; the column order ci*27 + tap is exactly the memory order of a gw row, so
 // the accumulator tile is written straight into the [Cout][Cin][27] layout).  A workgroup owns 32 output channels x
 // CIT input channels (CIT*27 columns = 7 column blocks at CIT = 8) and walks the spatial tiles of ONE sample; its 4
-// waves split each 256-voxel tile, so there are B * 4 partial results per (co, ci) tile, summed in a fixed order by a
-// second kernel (deterministic, no atomics).  Exact fp32 products, like the forward.
+// waves split each 256-voxel tile (combined through LDS in fixed order at the end), so there are B * splits partial
+// results per (co, ci) tile, summed in a fixed order by a second kernel (deterministic, no atomics).  The next tile's
+// loads travel through registers under the current tile's MFMAs.  Exact fp32 products, like the forward.
 #include "common.h"
 
 namespace {
@@ -54,28 +55,49 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float *__res
       const_cast<float *>(x + ((size_t)b * Cin + ci0) * r3), 0, CIT * r3 * 4, 0x00020000);
   const float *gyb = gy + ((size_t)b * Cout + co0) * r3;
 
-  for (int t = ts; t < ntiles; t += TS) {
+  // Staging through registers: the loads of tile t + TS are issued in front of the MFMAs of tile t (round 3; the kernel was
+  // load -> barrier -> compute -> barrier with only the co-resident workgroup to hide the loads behind).
+  constexpr int NXI = (HALO + 255) / 256; // halo positions per thread
+  float rgy[32], rx[NXI][CIT];
+  auto load_tile = [&](int t) {
     const int tw_i = t % ntw, th_i = (t / ntw) % nth, td_i = t / (ntw * nth);
     const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
-    __syncthreads(); // the previous tile's LDS reads are done
-    // gy tile: 32 channels x 256 voxels; thread = voxel, loop over channels (coalesced rows of TW voxels)
     {
       const int v = tid, d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
       const int gv = ((d0 + d) * r + (h0 + h)) * r + (w0 + w);
-#pragma unroll 8
-      for (int c = 0; c < 32; ++c) sgy[c * GS + v] = gyb[(size_t)c * r3 + gv];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) rgy[c] = gyb[(size_t)c * r3 + gv];
     }
-    // input halo tile (zero padding through out-of-range buffer offsets)
-    for (int p = tid; p < HALO; p += 256) {
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int p = tid + 256 * i;
       const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
       const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-      const bool ok = gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
-      const int off = ok ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
+      const bool ok = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+      const int off = ok ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00; // zero padding through out-of-range buffer offsets
 #pragma unroll
       for (int c = 0; c < CIT; ++c)
-        sx[c * HALO + p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, c * r3 * 4, 0));
+        rx[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, c * r3 * 4, 0));
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) sgy[c * GS + tid] = rgy[c];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int p = tid + 256 * i;
+      if (p < HALO) {
+#pragma unroll
+        for (int c = 0; c < CIT; ++c) sx[c * HALO + p] = rx[i][c];
+      }
+    }
+  };
+  if (ts < ntiles) load_tile(ts);
+  for (int t = ts; t < ntiles; t += TS) {
+    __syncthreads(); // the previous tile's LDS reads are done
+    store_tile();
     __syncthreads();
+    if (t + TS < ntiles) load_tile(t + TS); // in flight under the MFMAs below
     // 32 k-steps of 2 voxels over this wave's 64 voxels
 #pragma unroll 4
     for (int s = 0; s < 32; ++s) {
@@ -90,16 +112,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float *__res
       for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[nb], acc[nb], 0, 0, 0);
     }
   }
-  // partial[(b*4 + wave)][co][ci*27 + tap]; acc register i of lane l: row (i&3) + 8*(i>>2) + 4*(l>>5), column l&31
-  float *pt = partial + (size_t)(blockIdx.x * 4 + wave) * Cout * Cin * 27;
+  // The four waves hold partial sums over disjoint voxels of the same (co, column) tile: combine them through LDS in fixed
+  // order (w0 + w1) + (w2 + w3), one column block at a time, and write ONE partial per workgroup (round 3: the reduce kernel
+  // read 4x the bytes).  partial[blockIdx.x][co][ci*27 + tap]; acc register i of lane l: row (i&3) + 8*(i>>2) + 4*(l>>5),
+  // column l&31
+  float *pt = partial + (size_t)blockIdx.x * Cout * Cin * 27;
+  float *red = smem; // [4 waves][16][64]
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int c = nb * 32 + cl;
-    if (c < NCOL) {
+    __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-        pt[((size_t)co * Cin + ci0) * 27 + c] = acc[nb][i];
+    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[nb][i];
+    __syncthreads();
+    // 1024 values per column block, 4 per thread: value e = i * 64 + lane'
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = tid + 256 * k, i = e >> 6, ln = e & 63;
+      const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+      const int c = nb * 32 + (ln & 31);
+      if (c < NCOL) {
+        const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
+        pt[((size_t)co * Cin + ci0) * 27 + c] = v;
       }
     }
   }
@@ -141,10 +174,10 @@ static int wgrad_splits(int B, int Cin, int Cout, int r) {
   return ts;
 }
 
-// floats of scratch: B * splits * 4 partial copies of the [Cout,Cin,27] gradient
+// floats of scratch: B * splits partial copies of the [Cout,Cin,27] gradient (one per workgroup)
 size_t lion_conv3d_wgrad_workspace_floats(int B, int Cin, int Cout, int r) {
   if (Cin % 4 != 0 || Cout % 32 != 0 || (r != 8 && r != 16 && r != 32)) return 0;
-  return (size_t)B * wgrad_splits(B, Cin, Cout, r) * 4 * Cout * Cin * 27;
+  return (size_t)B * wgrad_splits(B, Cin, Cout, r) * Cout * Cin * 27;
 }
 
 // x f32[B,Cin,r,r,r] (Cin % 4 == 0), gy f32[B,Cout,r,r,r] (Cout % 32 == 0), r in {8,16,32} -> gw f32[Cout,Cin,3,3,3]
@@ -162,7 +195,7 @@ int lion_conv3d_k3_wgrad(const float *x, const float *gy, int B, int Cin, int Co
   else rc = c8 ? launch_wgrad<4, 8, 8, 8>(x, gy, B, Cin, Cout, r, TS, ws, st) : launch_wgrad<4, 8, 8, 4>(x, gy, B, Cin, Cout, r, TS, ws, st);
   if (rc) return rc;
   const size_t n = (size_t)Cout * Cin * 27;
-  conv3d_wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ws, B * TS * 4, n, gw);
+  conv3d_wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ws, B * TS, n, gw);
   LION_LAUNCH_CHECK();
   return 0;
 }
