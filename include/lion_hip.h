@@ -248,6 +248,11 @@ int lion_skinny_finish(const float *A, int ks_a, const float *bias_a, const floa
                        int nb, int C, int mode, float *y, lionStream_t stream);
 /* SE3d (pvcnn2_ada.py:27-41) on the folded scalars: A, Bs f32[B,C] are multiplied in place by
  * sigmoid(W2 relu(W1 (A*chmean + Bs))), w1 f32[H,C], w2 f32[C,H] (C <= 1024, H <= 128). */
+/* lion_groupnorm_fold + lion_se_gate in one launch (C <= 256, H <= 128): the second AdaGN of a PVConv with its SE3d gate
+ * (models/pvcnn2_ada.py:27-41, :219-226). */
+int lion_groupnorm_fold_se(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
+                           const float *beta, const float *fac, const float *gbias, int ld_fg, float eps, const float *w1,
+                           const float *w2, int H, float *A, float *Bs, lionStream_t stream);
 int lion_se_gate(const float *chmean, const float *w1, const float *w2, int B, int C, int H, float *A,
                  float *Bs, lionStream_t stream);
 int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *feat, const float *scale,

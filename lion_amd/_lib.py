@@ -56,6 +56,7 @@ SIGNATURES = {
     "lion_conv3d_split_stat_tiles": (_i, [_i, _i]),
     "lion_conv3d_k3_split_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "lion_groupnorm_fold_se": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "lion_skinny_packed_floats": (_sz, [_i, _i]),
     "lion_skinny_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_skinny_splits": (_i, [_i, _i]),

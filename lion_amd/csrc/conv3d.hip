@@ -366,6 +366,63 @@ __global__ void gn_fold_kernel(const float *__restrict__ stats, int C, int T, in
   }
 }
 
+// gn_fold_kernel + the SE3d gate (csrc/pointwise.hip se_gate_kernel) in ONE launch, one workgroup per sample: the second
+// AdaGN of a PVConv is always followed by the gate, and both are a few hundred flops behind a 5-us launch (round 3: 14
+// launches per denoiser step less).  C <= 256, hidden <= 128.  Channel sums: LPC = 256 / pow2ceil(C) consecutive lanes per
+// channel, each over tiles sub, sub + LPC, ... in double, combined with an xor-butterfly; group totals by a fixed-order loop.
+__global__ __launch_bounds__(256) void gn_fold_se_kernel(const float *__restrict__ stats, int C, int T, int G, float count,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         const float *__restrict__ fac, const float *__restrict__ gbias,
+                                                         int ld_fg, float eps, const float *__restrict__ w1,
+                                                         const float *__restrict__ w2, int H, float *__restrict__ A,
+                                                         float *__restrict__ Bs) {
+  __shared__ double cs[256][2];
+  __shared__ float sA[256], sB[256], sm[256], sh[128];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cpg = C / G;
+  int cp2 = 1;
+  while (cp2 < C) cp2 <<= 1;
+  const int LPC = 256 / cp2, ch = tid / LPC, sub = tid % LPC; // LPC in {1, ..., 64}
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < C) {
+    const float2 *p = reinterpret_cast<const float2 *>(stats + (((size_t)b * C + ch) * T) * 2);
+    for (int t = sub; t < T; t += LPC) { const float2 v = p[t]; s1 += (double)v.x; s2 += (double)v.y; }
+  }
+  for (int m = 1; m < LPC; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (ch < C && sub == 0) { cs[ch][0] = s1; cs[ch][1] = s2; }
+  __syncthreads();
+  if (tid < C) {
+    const int g0 = (tid / cpg) * cpg;
+    double g1 = 0.0, g2 = 0.0;
+    for (int k = 0; k < cpg; ++k) { g1 += cs[g0 + k][0]; g2 += cs[g0 + k][1]; }
+    const double n = (double)count * cpg, mean = g1 / n;
+    double var = g2 / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float f = fac[(size_t)b * ld_fg + tid], gb = gbias[(size_t)b * ld_fg + tid];
+    const float a0 = rstd * gamma[tid];
+    const float a = a0 * f, bb = (beta[tid] - (float)mean * a0) * f + gb;
+    sA[tid] = a;
+    sB[tid] = bb;
+    sm[tid] = a * (float)(cs[tid][0] / count) + bb; // mean over the grid of AdaGN(y) (se_gate_kernel)
+  }
+  __syncthreads();
+  for (int j = wave; j < H; j += 4) { // one wave per hidden unit: coalesced row of W1
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * C + c] * sm[c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) sh[j] = acc > 0.f ? acc : 0.f;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float acc = 0.f;
+    for (int j = 0; j < H; ++j) acc += w2[(size_t)tid * H + j] * sh[j];
+    const float g = 1.0f / (1.0f + expf(-acc));
+    A[(size_t)b * C + tid] = sA[tid] * g;
+    Bs[(size_t)b * C + tid] = sB[tid] * g;
+  }
+}
+
 // One workgroup per sample: (1) which (d, h) columns of the count grid hold a point (tiles span the whole w axis),
 // (2) per spatial tile: any point within `margin` voxels of the tile, for margin 1 (the conv that reads the voxelised
 // grid) and margin 2 (the delta of the second conv), (3) the sample's work list for each margin -- occupied tiles
@@ -628,6 +685,19 @@ int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32
 int lion_conv3d_stat_tiles(int r, int Cout, int B, int sparse) {
   if (r != 8 && r != 16 && r != 32) return 0;
   return conv_plan(r, Cout, B, sparse != 0).tiles;
+}
+
+// lion_groupnorm_fold followed by lion_se_gate (w1 f32[H,C], w2 f32[C,H]) in one launch: A, Bs already carry the gate
+int lion_groupnorm_fold_se(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
+                           const float *beta, const float *fac, const float *gbias, int ld_fg, float eps, const float *w1,
+                           const float *w2, int H, float *A, float *Bs, lionStream_t stream) {
+  if (!stats || !gamma || !beta || !fac || !gbias || !w1 || !w2 || !A || !Bs) return LION_EINVAL;
+  if (B <= 0 || C <= 0 || T <= 0 || G <= 0 || C % G != 0 || ld_fg < C || H <= 0) return LION_EINVAL;
+  if (C > 256 || C < 4 || H > 128) return LION_EUNSUPPORTED;
+  gn_fold_se_kernel<<<B, 256, 0, static_cast<hipStream_t>(stream)>>>(stats, C, T, G, (float)voxels, gamma, beta, fac, gbias,
+                                                                     ld_fg, eps, w1, w2, H, A, Bs);
+  LION_LAUNCH_CHECK();
+  return 0;
 }
 
 // stats f32[B,C,T,2] -> A, Bs, chmean f32[B,C]   (GroupNorm(G) folded with the AdaGN affine fac/gbias f32[B,C])

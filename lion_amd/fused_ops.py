@@ -113,6 +113,25 @@ def groupnorm_fold(stats, gn: torch.nn.GroupNorm, fac, gbias, voxels):
     return A, Bs, cm
 
 
+def groupnorm_fold_se(stats, gn: torch.nn.GroupNorm, fac, gbias, voxels, se):
+    """groupnorm_fold followed by se_gate_ in one launch; None when the shape is outside the merged kernel's range."""
+    b, c, t, _ = stats.shape
+    w1, w2 = se.fc[0].weight.detach(), se.fc[2].weight.detach()
+    h = w1.shape[0]
+    if c > 256 or c < 4 or h > 128 or not (w1.is_contiguous() and w2.is_contiguous()):
+        return None
+    A = torch.empty((b, c), device=stats.device, dtype=torch.float32)
+    Bs = torch.empty_like(A)
+    if not (fac.stride(1) == 1 and gbias.stride(1) == 1 and fac.stride(0) == gbias.stride(0) and fac.stride(0) >= c):
+        fac, gbias = fac.contiguous(), gbias.contiguous()
+    fac_c, gb_c, ld = fac, gbias, int(fac.stride(0))   # kept alive until the launch is enqueued (see groupnorm_fold)
+    _lib.check(_lib.load().lion_groupnorm_fold_se(
+        _lib.ptr(stats), b, c, t, gn.num_groups, int(voxels), _lib.ptr(gn.weight.detach()), _lib.ptr(gn.bias.detach()),
+        _lib.ptr(fac_c), _lib.ptr(gb_c), ld, float(gn.eps), _lib.ptr(w1), _lib.ptr(w2), h, _lib.ptr(A), _lib.ptr(Bs),
+        _lib.stream_ptr(stats.device)), "groupnorm_fold_se")
+    return A, Bs
+
+
 def se_gate_(A, Bs, chmean, se):
     """in place: (A, Bs) *= SE3d gate computed from the folded scalars (mean of AdaGN(y) = A*mean(y)+Bs)."""
     w1, w2 = se.fc[0].weight.detach(), se.fc[2].weight.detach()

@@ -324,9 +324,13 @@ class PVConv(nn.Module):
         # conv2's activated input = per-channel constant + a delta that is non-zero only near the points
         y2, st2 = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True, occ2, prev_conv=conv1)
         f2, g2 = gn2.affine(style)
-        a2, b2, m2 = fused_ops.groupnorm_fold(st2, gn2.norm, f2, g2, r ** 3)
-        if se is not None:
-            a2, b2 = fused_ops.se_gate_(a2, b2, m2, se)  # mean over the grid of AdaGN2(y2) is affine in mean(y2)
+        merged = fused_ops.groupnorm_fold_se(st2, gn2.norm, f2, g2, r ** 3, se) if se is not None else None
+        if merged is not None:     # fold + SE gate in one launch
+            a2, b2 = merged
+        else:
+            a2, b2, m2 = fused_ops.groupnorm_fold(st2, gn2.norm, f2, g2, r ** 3)
+            if se is not None:
+                a2, b2 = fused_ops.se_gate_(a2, b2, m2, se)  # mean over the grid of AdaGN2(y2) is affine in mean(y2)
         return fused_ops.devoxelize_affine(y2, voxel_coords, r, a2, b2)
 
     def forward(self, inputs):

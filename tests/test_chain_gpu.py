@@ -225,3 +225,40 @@ def test_lion_sample_ancestral_chain(small_lion):
     sch.variance_type = 'fixed_large'
     assert abs(sch._noise_scale(t) - float(d._h_betas[t].sqrt())) < 1e-7
     sch.variance_type = 'fixedlarge'
+
+
+def test_split_graph_chain_equals_the_single_graph_chain(small_lion):
+    """The local prior's chain cut into [geometry stage 0 | later stages] on a second stream and [A | B | C] on the main one
+    (lion_amd/chain.py, geometry.SPLIT_GRAPH) against the same chain as ONE graph on one stream: the same kernels on the same
+    data in a different launch structure -- every step of the trajectory bit for bit, at B = 2 and at B = 32."""
+    from lion_amd import chain, geometry
+    lion, d = small_lion, small_lion.diffusion
+    S = 6
+    sh = lion.vae.latent_shape()
+    saved = geometry.SPLIT_GRAPH
+    try:
+        for B in (2, 32):
+            with torch.no_grad():
+                style = lion.vae.global2style(torch.randn([B] + sh[0], device="cuda"))
+            steps = d.ddim_schedule(1000, S, 'uniform')
+            table = np.zeros((S, 8), np.float32)
+            for i, t in enumerate(steps):
+                table[i, :4] = (t + 1,) + d.ddim_coefficients(t, None if i == S - 1 else steps[i + 1], 1.0)
+            x0 = torch.randn([B] + sh[1], device="cuda")
+            trajs = []
+            for split in (True, False):
+                geometry.SPLIT_GRAPH = split
+                ch = chain.GraphedChain(lion.priors[1], B, sh[1], style, None, "cuda", chain.DDIM, 16)
+                assert (ch.graph_b is not None) == split, "split mode must cut the step where a geometry result is first used"
+                if split:
+                    assert len(ch.geo_graphs) == 2 and len(ch.graphs) == 3
+                xs = []
+                for _ in range(2):                    # the chain twice: replays 1..12 of one capture
+                    xs = []
+                    ch.run(x0, table, 1234, style, None, trajectory=xs)
+                trajs.append(xs)
+                del ch
+            for i, (a, b) in enumerate(zip(*trajs)):
+                assert torch.equal(a, b), (B, i, (a - b).abs().max().item())
+    finally:
+        geometry.SPLIT_GRAPH = saved
