@@ -22,6 +22,10 @@ Extra objects on the JSON line:
                 exact-fp32 kernel vs the 157.3 TF fp32 MFMA peak;
   roofline_voxelize  the kernel the metric names: fused voxelize (64, 2048, 32), algorithmic bytes
                 (SURVEY.md 8d) / measured time vs 8 TB/s HBM;
+  roofline_devoxelize, roofline_backward_operators (K5, K8, K12-grad)  the same for the devoxelize forward and the
+                backward scatters of the training path; these operators (60-200 us) are timed as 20 / 10 launches inside
+                ONE hipGraph replay bracketed by HIP events: the kernels' time, not the host's launch rate;
+  config.ms_per_step_all_runs  the timed call is repeated --repeats (3) times, `value` is the median;
   cpu_baseline  the same step on the host cores (PyTorch-CPU dense layers + the C oracle operators).
 """
 import argparse

@@ -3,11 +3,14 @@
 
 One denoiser evaluation of the local prior is ~500 kernel launches; the reference's samplers
 (utils/diffusion_pvd.py:224-303, :390-473) additionally issue ~10 elementwise launches, a ``torch.full`` and a
-host-side ``randn`` + H2D copy per step.  Here ONE hipGraph holds
+host-side ``randn`` + H2D copy per step.  Here a captured step holds
     lion_chain_begin_step  ->  denoiser forward  ->  lion_chain_update_noise
-and a chain of S steps is S replays of it.  Everything that changes from step to step lives in device memory:
+and a chain of S steps is S replays of it: one hipGraph for models without set abstraction (the global prior); for the
+point-voxel denoiser three single-branch graphs on the main stream and the step's FPS / ball-query chain as two graphs on a
+second stream, ordered by events between the launches (GraphedChain.__init__; round 3 -- branches INSIDE one graph replay
+slower than one stream on ROCm 7.2, separate graphs on separate streams overlap).  Everything that changes from step to step lives in device memory:
 the schedule table (timestep for the model + the update's coefficients, S x 8 floats uploaded once per chain), the
-step counter, the Philox seed, the latent ``x`` (updated in place).  The host issues one ``hipGraphLaunch`` per step
+step counter, the Philox seed, the latent ``x`` (updated in place).  The host issues one to five ``hipGraphLaunch`` per step
 and never synchronises inside the chain.
 
 A captured graph bakes in the packed-weight pointers of its model: it is keyed by ``_wcache.fingerprint(model)``
