@@ -308,6 +308,17 @@ int lion_timestep_embedding(const float *t, const float *row, float scale, int B
 int lion_affine_swish_add(const float *x, const float *A, const float *Bs, const float *addend, int rows, int L, float *y,
                           lionStream_t stream);
 
+/* ---- backward scatters without float atomics (training; K5, K8, K12-grad) -------------------------------------------
+ * gx f32[B,C,bins] = sum over the entries e with idx[b,e] = bin of (w ? w[b,e] : 1) * gy[b,c, e mod S]:
+ *   grouping backward (grouping.cu:58-80):            idx [B, M*U], w NULL,       gy [B,C,M*U], S = E = M*U, bins = N
+ *   3-NN interpolation backward (neighbor_interpolate.cu:145-170): idx / w [B, 3*N], gy [B,C,N], S = N, E = 3N, bins = M
+ *   devoxelize backward (trilinear_devox.cu:119-162):  idx / w [B, 8*N], gy [B,C,N], S = N, E = 8N, bins = r^3
+ * The inverse index is built once per sample, every channel is a gather-sum in ascending entry order: deterministic
+ * (the reference's atomicAdd order is not), and not bound by the LDS float-atomic rate (csrc/scatter_csr.hip). */
+size_t lion_scatter_csr_workspace_bytes(int B, int E, int bins);
+int lion_scatter_csr(const float *gy, const int32_t *idx, const float *w, int B, int C, int S, int E, int bins, void *ws,
+                     size_t ws_bytes, float *gx, lionStream_t stream);
+
 /* ---- weight gradient of the 1x1 convolutions (training): gw[o][i] = sum_b sum_l gy[b][o][l] x[b][i][l] --------------
  * x f32[B,Cin,L], gy f32[B,Cout,L] (16-byte aligned), gw f32[Cout,Cin]; ws from lion_pwconv_wgrad_workspace_bytes.  What
  * autograd's mm([O, B L] x [B L, I]) of models/pvcnn2_ada.py's SharedMLP layers computes, without the transposing copies;

@@ -79,6 +79,8 @@ SIGNATURES = {
     "lion_affine_swish_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_timestep_embedding": (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp]),
     "lion_affine_swish_add": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "lion_scatter_csr_workspace_bytes": (_sz, [_i, _i, _i]),
+    "lion_scatter_csr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "lion_pwconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "lion_pwconv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "lion_gn_train_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -94,9 +94,27 @@ class _HipBackend:
             _lib.stream_ptr(out.device)), "grouping_forward")
         return out
 
+    def _scatter_csr(self, grad_y, indices, weights, S, E, bins, what):
+        """gx[b,c,bin] = sum_{e: idx[b,e] = bin} w[b,e] * gy[b,c, e mod S] on csrc/scatter_csr.hip (no float atomics,
+        deterministic); None when the shape is outside its range (the callers fall back to the LDS-atomic kernels)."""
+        b, c = grad_y.shape[:2]
+        wsb = self.lib.lion_scatter_csr_workspace_bytes(b, E, bins)
+        if wsb == 0 or ((bins + 7) // 8) * 4 > 60 * 1024 or S * 4 > 128 * 1024:
+            return None
+        gy, idx = grad_y.contiguous(), indices.contiguous()
+        w = weights.contiguous() if weights is not None else None
+        ws = torch.empty((wsb,), device=gy.device, dtype=torch.uint8)
+        gx = torch.empty((b, c, bins), device=gy.device, dtype=torch.float32)
+        _lib.check(self.lib.lion_scatter_csr(_lib.ptr(gy), _lib.ptr(idx), _lib.ptr(w), b, c, S, E, bins, _lib.ptr(ws), wsb,
+                                             _lib.ptr(gx), _lib.stream_ptr(gx.device)), what)
+        return gx
+
     def grouping_backward(self, grad_y, indices, n):
         _lib.require_cuda(grad_y, indices); _f32(grad_y, "grad_y"); _i32(indices, "indices")
         b, c, m, u = grad_y.shape
+        gx = self._scatter_csr(grad_y, indices, None, m * u, m * u, int(n), "grouping_backward (csr)")
+        if gx is not None:
+            return gx
         gx = torch.empty((b, c, n), device=grad_y.device, dtype=torch.float32)
         _lib.check(self.lib.lion_grouping_backward(
             _lib.ptr(grad_y), _lib.ptr(indices), b, c, n, m, u, _lib.ptr(gx),
@@ -125,6 +143,9 @@ class _HipBackend:
         _lib.require_cuda(grad_y, indices, weights)
         _f32(grad_y, "grad_y"); _i32(indices, "indices"); _f32(weights, "weights")
         b, c, n = grad_y.shape
+        gx = self._scatter_csr(grad_y, indices, weights, n, 3 * n, int(m), "three_nn_interpolate_backward (csr)")
+        if gx is not None:
+            return gx
         gx = torch.empty((b, c, m), device=grad_y.device, dtype=torch.float32)
         _lib.check(self.lib.lion_three_nn_interpolate_backward(
             _lib.ptr(grad_y), _lib.ptr(indices), _lib.ptr(weights), b, c, n, m, _lib.ptr(gx),
@@ -159,6 +180,8 @@ class _HipBackend:
         _f32(grad_y, "grad_y"); _i32(indices, "indices"); _f32(weights, "weights")
         b, c, n = grad_y.shape
         r3 = r * r * r
+        # (the atomics-free path of csrc/scatter_csr.hip is correct here too -- tests/test_scatter_csr_gpu.py -- but slower:
+        # 32768 mostly empty bins per sample, 373 us against 198 at (64, 2048, 32), B = 32; K8 and K12-grad use it)
         gx = torch.empty((b, c, r3), device=grad_y.device, dtype=torch.float32)
         _lib.check(self.lib.lion_trilinear_devoxelize_backward(
             _lib.ptr(grad_y), _lib.ptr(indices), _lib.ptr(weights), b, c, n, r3, _lib.ptr(gx),
