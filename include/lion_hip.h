@@ -56,6 +56,21 @@ int lion_voxelize_points_forward(const float *feat, const float *coords, int B, 
                                  float *norm_coords, int32_t *ind, int32_t *cnt, void *ws,
                                  size_t ws_bytes, lionStream_t stream);
 
+/* ---- P1+K1 once, K2 many times: the index plan of a (cloud, resolution) pair ----------------
+ * One forward of the denoiser voxelises 4 distinct (coordinates, r) pairs 14 times (PVConv.forward,
+ * models/pvcnn2_ada.py:235-243: every PVConv of a stage re-derives the same voxel ids from the same
+ * coordinates).  lion_voxel_index computes what depends on the coordinates only -- norm_coords, ind, cnt
+ * exactly as lion_voxelize_points_forward, plus the points of every voxel in ascending point index
+ * (an opaque plan of lion_voxel_plan_bytes bytes, 0 = shape outside the fast path: use the fused entry
+ * point) -- and lion_voxel_scatter mean-pools feat f32[B,C,N] into out f32[B,C,r^3] from that plan:
+ * same sums in the same order, bit-identical to lion_voxelize_points_forward (vox.cu:48-72). */
+size_t lion_voxel_plan_bytes(int B, int N, int r);
+int lion_voxel_index(const float *coords, int B, int N, int r, int normalize, float eps,
+                     float *norm_coords, int32_t *ind, int32_t *cnt, void *plan, size_t plan_bytes,
+                     lionStream_t stream);
+int lion_voxel_scatter(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N,
+                       int r, float *out, lionStream_t stream);
+
 /* ---- K3: avg_voxelize_backward, vox.cpp:54-79 (vox.cu:86-110) --------------------------
  * gy f32[B,C,r3], ind i32[B,N], cnt i32[B,r3] -> gx f32[B,C,N]. */
 int lion_avg_voxelize_backward(const float *gy, const int32_t *ind, const int32_t *cnt, int B,

@@ -37,12 +37,117 @@ __host__ __device__ inline int align4i(int x) { return (x + 3) & ~3; }
 // LDS (dynamic): slot[SVP] | ust[nw] | fscr[64] | iscr[32] | arena[arena_words]; during phase A the
 // arena holds hist[SVP] | tmp[nw], afterwards prod[ch * my_pts] | vm[ch * my_occ].
 // ---------------------------------------------------------------------------------------------
+// Phases B + C of one (cloud, slab, channel range) workgroup, shared by the fused kernel and the plan-driven scatter
+// kernel.  In LDS: slot[SV] dense (voxel -> rank among the slab's occupied voxels, -1 = empty), ust[my_occ]
+// ((start << 16) | count per occupied voxel); per thread: the sorted position (or -1) and 1 / count of its NP points.
+template <int NP>
+__device__ __forceinline__ void vox_means_and_store(
+    const float *__restrict__ feat, float *__restrict__ out, int b, int C, int N, int r3, int lo, int SV, int cs, int CS,
+    int my_pts, int my_occ, const int (&posv)[NP], const float (&invp)[NP], const int32_t *slot, const int32_t *ust,
+    float *arena, int arena_words, int ch_cap) {
+  const int tid = threadIdx.x;
+  const int q4 = SV >> 2; // int4 groups in the slab
+  const int ch_max = min(ch_cap, my_pts > 0 ? min(C, arena_words / (my_pts + my_occ)) : C);
+  const int step_c = VT / q4, step_g = VT - step_c * q4;
+  const int c_per = (C + CS - 1) / CS, c_lo = cs * c_per, c_hi = min(C, c_lo + c_per);
+  for (int c0 = c_lo; c0 < c_hi; c0 += ch_max) {
+    const int ch = min(ch_max, c_hi - c0);
+    float *prod = arena, *vm = arena + ch * my_pts;
+    __syncthreads(); // hist/tmp (or the previous chunk's vm) are dead from here on
+    if (my_pts > 0) {
+      // B1: every lane reads ITS points' feature rows fully coalesced (the 8 slabs of a cloud share
+      // the rows through one L2); only lanes whose point lies in the slab keep feat * (1 / count),
+      // at the point's sorted position.  No gathers, no dependent loads.
+      const float *fb = feat + ((size_t)b * C + c0) * N;
+      constexpr int CU = 16 / NP; // 16 independent row loads in flight per lane
+      for (int cl0 = 0; cl0 < ch; cl0 += CU) {
+        float f[CU][NP];
+#pragma unroll
+        for (int k = 0; k < CU; ++k)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            f[k][p] = fb[(size_t)min(cl0 + k, ch - 1) * N + min(tid + p * VT, N - 1)];
+#pragma unroll
+        for (int k = 0; k < CU; ++k)
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            if (posv[p] >= 0 && cl0 + k < ch) prod[(cl0 + k) * my_pts + posv[p]] = mul_rn(f[k][p], invp[p]);
+      }
+      __syncthreads();
+      // B2: per-voxel means from LDS, summed in ascending point index (vox.cu:59-71)
+      const int items = my_occ * ch;
+      for (int it = tid; it < items; it += VT) {
+        const int cl = it / my_occ, u = it - cl * my_occ;
+        const int info = ust[u], st = info >> 16, n = info & 0xffff;
+        const float *pr = prod + cl * my_pts + st;
+        // the sum's ORDER is fixed (ascending point index), its operands are not dependent on it: fetch 8 ahead so that
+        // a voxel of n points costs n dependent adds, not n LDS round trips (in-step clouds: n up to ~150; round 4)
+        float acc = add_rn(0.f, pr[0]);
+        int k = 1;
+        for (; k + 8 <= n; k += 8) {
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = pr[k + j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = add_rn(acc, t[j]);
+        }
+        for (; k < n; ++k) acc = add_rn(acc, pr[k]);
+        vm[it] = acc; // it == cl * my_occ + u
+      }
+    }
+    __syncthreads();
+    // C: the slab of the dense grid for channels [c0, c0 + ch): LDS -> 16-byte stores only
+    int cl = tid / q4, g = tid - cl * q4;
+    float *obase = out + ((size_t)b * C + c0) * r3 + lo;
+    while (cl < ch) {
+      const int4 sl = *reinterpret_cast<const int4 *>(slot + 4 * g);
+      const float *vmc = vm + cl * my_occ;
+      const float x = vmc[max(sl.x, 0)], y = vmc[max(sl.y, 0)], z = vmc[max(sl.z, 0)], w = vmc[max(sl.w, 0)];
+      float4 o;
+      o.x = sl.x >= 0 ? x : 0.f;
+      o.y = sl.y >= 0 ? y : 0.f;
+      o.z = sl.z >= 0 ? z : 0.f;
+      o.w = sl.w >= 0 ? w : 0.f;
+      *reinterpret_cast<float4 *>(obase + (size_t)cl * r3 + 4 * g) = o;
+      cl += step_c; g += step_g;
+      if (g >= q4) { g -= q4; ++cl; }
+    }
+  }
+}
+
+// The index plan of a (coordinates, resolution) pair -- what phase A computes, kept in memory so that every voxelisation
+// of the same cloud at the same resolution (a forward of the denoiser voxelises 4 distinct (cloud, r) pairs 14 times)
+// starts at phase B.  int32 words, per cloud b and slab s (Ncap = align4(N)):
+//   pos [B][N]          (slab << 16) | position of the point in its slab's (voxel, point index) order
+//   inv [B][N]          float 1 / count of the point's voxel
+//   hdr [B][S][4]       points in the slab, occupied voxels in the slab
+//   ust [B][S][Ncap]    (start << 16) | count per occupied voxel, ascending voxel id
+//   uvl [B][S][Ncap]    the occupied voxel's id relative to the slab
+struct VoxPlanPtrs {
+  int32_t *pos;
+  float *inv;
+  int32_t *hdr, *ust, *uvl;
+};
+__host__ __device__ inline size_t vox_plan_words(int B, int N, int S) {
+  return (size_t)B * (2 * (size_t)N + (size_t)S * (4 + 2 * (size_t)align4i(N)));
+}
+__host__ __device__ inline VoxPlanPtrs vox_plan_ptrs(void *base, int B, int N, int S) {
+  VoxPlanPtrs q;
+  int32_t *w = static_cast<int32_t *>(base);
+  q.pos = w; w += (size_t)B * N;
+  q.inv = reinterpret_cast<float *>(w); w += (size_t)B * N;
+  q.hdr = w; w += (size_t)B * S * 4;
+  q.ust = w; w += (size_t)B * S * align4i(N);
+  q.uvl = w;
+  return q;
+}
+
 template <bool FUSE_P1, int NP>
 __global__ __launch_bounds__(VT) void vox_fused_kernel(
     const float *__restrict__ feat, const int32_t *__restrict__ coords_i,
     const float *__restrict__ coords_f, int B, int C, int N, int r, int S, int CS, int SV, int n_words,
     int arena_words, int ch_cap, int normalize, float eps, float *__restrict__ out,
-    float *__restrict__ norm_coords, int32_t *__restrict__ ind, int32_t *__restrict__ cnt) {
+    float *__restrict__ norm_coords, int32_t *__restrict__ ind, int32_t *__restrict__ cnt, void *plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int SVP = ((SV + (SV >> 5) + 3) & ~3) + 4;         // padded (1 word per 32) + 16-byte aligned
   int32_t *slot = reinterpret_cast<int32_t *>(smem);       // [SVP] arrival counters, later dense slots
@@ -171,7 +276,10 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
   for (int v = tid * 4; v < SV && cs == 0; v += VT * 4)
     *reinterpret_cast<int4 *>(cnt + (size_t)b * r3 + lo + v) =
         make_int4((int)hist[padv(v)], (int)hist[padv(v + 1)], (int)hist[padv(v + 2)], (int)hist[padv(v + 3)]);
-  if (feat == nullptr) return;
+  if (feat == nullptr && plan == nullptr) return;
+  VoxPlanPtrs pl = {};
+  if (plan) pl = vox_plan_ptrs(plan, B, N, S);
+  int32_t *uvl_g = plan ? pl.uvl + ((size_t)b * S + slab) * n_words : nullptr;
 
   // ---- scan: rank among the slab's occupied voxels + start in the sorted list -------------------
   const int VPT = (SV + VT - 1) / VT;
@@ -192,6 +300,7 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
       if (c) {
         hist[padv(v)] = ((uint32_t)urun << 16) | c;
         ust[urun] = (run << 16) | (int)c;
+        if (uvl_g) uvl_g[urun] = v;
         ++urun;
         run += (int)c;
       }
@@ -219,76 +328,85 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
     if (i < N && myv[p] >= 0 && myv[p] < SV) {
       const int h = ust[hist[padv(myv[p])] >> 16];
       const int s = h >> 16, c = h & 0xffff;
-      int rank = 0;
-      for (int q = 0; q < c; ++q) rank += (tmp[s + q] < i) ? 1 : 0;
+      // crowded voxels (real latents put 100+ points into one voxel): 8 independent LDS reads per round trip instead
+      // of one dependent read per step
+      int rank = 0, q = 0;
+      for (; q + 8 <= c; q += 8) {
+        int t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = tmp[s + q + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rank += (t[j] < i) ? 1 : 0;
+      }
+      for (; q < c; ++q) rank += (tmp[s + q] < i) ? 1 : 0;
       posv[p] = s + rank;
       invp[p] = div_rn(1.0f, (float)c); // vox.cu:66 (== float(1.0 / cnt))
     }
+  }
+  if (plan) {   // index mode: everything the scatter kernel needs to start at phase B
+    if (tid == 0) {
+      int32_t *h = pl.hdr + ((size_t)b * S + slab) * 4;
+      h[0] = my_pts; h[1] = my_occ; h[2] = 0; h[3] = 0;
+    }
+    int32_t *ust_g = pl.ust + ((size_t)b * S + slab) * n_words;
+    for (int u = tid; u < my_occ; u += VT) ust_g[u] = ust[u];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int i = tid + p * VT;
+      if (i < N && posv[p] >= 0) {
+        pl.pos[(size_t)b * N + i] = (slab << 16) | posv[p];
+        pl.inv[(size_t)b * N + i] = invp[p];
+      }
+    }
+    if (feat == nullptr) return;
   }
   // dense slots, unpadded so that phase C reads them 16 bytes at a time
   for (int v = tid; v < SV; v += VT) {
     const uint32_t h = hist[padv(v)];
     slot[v] = (h & 0xffff) ? (int)(h >> 16) : -1;
   }
+  vox_means_and_store<NP>(feat, out, b, C, N, r3, lo, SV, cs, CS, my_pts, my_occ, posv, invp, slot, ust, arena,
+                          arena_words, ch_cap);
+}
 
-  // ---- phases B + C per chunk of channels ---------------------------------------------------------
-  const int q4 = SV >> 2; // int4 groups in the slab
-  const int ch_max = min(ch_cap, my_pts > 0 ? min(C, arena_words / (my_pts + my_occ)) : C);
-  const int step_c = VT / q4, step_g = VT - step_c * q4;
-  const int c_per = (C + CS - 1) / CS, c_lo = cs * c_per, c_hi = min(C, c_lo + c_per);
-  for (int c0 = c_lo; c0 < c_hi; c0 += ch_max) {
-    const int ch = min(ch_max, c_hi - c0);
-    float *prod = arena, *vm = arena + ch * my_pts;
-    __syncthreads(); // hist/tmp (or the previous chunk's vm) are dead from here on
-    if (my_pts > 0) {
-      // B1: every lane reads ITS points' feature rows fully coalesced (the 8 slabs of a cloud share
-      // the rows through one L2); only lanes whose point lies in the slab keep feat * (1 / count),
-      // at the point's sorted position.  No gathers, no dependent loads.
-      const float *fb = feat + ((size_t)b * C + c0) * N;
-      constexpr int CU = 16 / NP; // 16 independent row loads in flight per lane
-      for (int cl0 = 0; cl0 < ch; cl0 += CU) {
-        float f[CU][NP];
+// vox_scatter_kernel: phases B + C from a stored plan.  LDS (dynamic): slot[SV] | ust[n_words] | arena.
+template <int NP>
+__global__ __launch_bounds__(VT) void vox_scatter_kernel(
+    const float *__restrict__ feat, const void *__restrict__ plan, int B, int C, int N, int r3, int S, int CS, int SV,
+    int n_words, int arena_words, int ch_cap, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t *slot = reinterpret_cast<int32_t *>(smem);
+  int32_t *ust = slot + SV;
+  float *arena = reinterpret_cast<float *>(ust + n_words);
+  const int tid = threadIdx.x;
+  const int W = S * CS;
+  const int L = blockIdx.x, grp = L / (8 * W), j8 = L - grp * 8 * W;
+  const int b = grp * 8 + (j8 & 7), wq = j8 >> 3, slab = wq % S, cs = wq / S;
+  if (b >= B) return;
+  const VoxPlanPtrs pl = vox_plan_ptrs(const_cast<void *>(plan), B, N, S);
+  const int32_t *h = pl.hdr + ((size_t)b * S + slab) * 4;
+  const int my_pts = h[0], my_occ = h[1];
+  int posv[NP];
+  float invp[NP];
 #pragma unroll
-        for (int k = 0; k < CU; ++k)
-#pragma unroll
-          for (int p = 0; p < NP; ++p)
-            f[k][p] = fb[(size_t)min(cl0 + k, ch - 1) * N + min(tid + p * VT, N - 1)];
-#pragma unroll
-        for (int k = 0; k < CU; ++k)
-#pragma unroll
-          for (int p = 0; p < NP; ++p)
-            if (posv[p] >= 0 && cl0 + k < ch) prod[(cl0 + k) * my_pts + posv[p]] = mul_rn(f[k][p], invp[p]);
-      }
-      __syncthreads();
-      // B2: per-voxel means from LDS, summed in ascending point index (vox.cu:59-71)
-      const int items = my_occ * ch;
-      for (int it = tid; it < items; it += VT) {
-        const int cl = it / my_occ, u = it - cl * my_occ;
-        const int info = ust[u], st = info >> 16, n = info & 0xffff;
-        const float *pr = prod + cl * my_pts + st;
-        float acc = add_rn(0.f, pr[0]);
-        for (int k = 1; k < n; ++k) acc = add_rn(acc, pr[k]);
-        vm[it] = acc; // it == cl * my_occ + u
-      }
-    }
-    __syncthreads();
-    // C: the slab of the dense grid for channels [c0, c0 + ch): LDS -> 16-byte stores only
-    int cl = tid / q4, g = tid - cl * q4;
-    float *obase = out + ((size_t)b * C + c0) * r3 + lo;
-    while (cl < ch) {
-      const int4 sl = *reinterpret_cast<const int4 *>(slot + 4 * g);
-      const float *vmc = vm + cl * my_occ;
-      const float x = vmc[max(sl.x, 0)], y = vmc[max(sl.y, 0)], z = vmc[max(sl.z, 0)], w = vmc[max(sl.w, 0)];
-      float4 o;
-      o.x = sl.x >= 0 ? x : 0.f;
-      o.y = sl.y >= 0 ? y : 0.f;
-      o.z = sl.z >= 0 ? z : 0.f;
-      o.w = sl.w >= 0 ? w : 0.f;
-      *reinterpret_cast<float4 *>(obase + (size_t)cl * r3 + 4 * g) = o;
-      cl += step_c; g += step_g;
-      if (g >= q4) { g -= q4; ++cl; }
-    }
+  for (int p = 0; p < NP; ++p) {
+    const int i = min(tid + p * VT, N - 1);
+    const int w = pl.pos[(size_t)b * N + i];
+    const float iv = pl.inv[(size_t)b * N + i];
+    const bool mine = (tid + p * VT < N) && (w >> 16) == slab;
+    posv[p] = mine ? (w & 0xffff) : -1;
+    invp[p] = mine ? iv : 0.f;
   }
+  for (int v = tid; v < SV; v += VT) slot[v] = -1;
+  __syncthreads();
+  const int32_t *ust_g = pl.ust + ((size_t)b * S + slab) * n_words;
+  const int32_t *uvl_g = pl.uvl + ((size_t)b * S + slab) * n_words;
+  for (int u = tid; u < my_occ; u += VT) {
+    ust[u] = ust_g[u];
+    slot[uvl_g[u]] = u;
+  }
+  vox_means_and_store<NP>(feat, out, b, C, N, r3, slab * SV, SV, cs, CS, my_pts, my_occ, posv, invp, slot, ust, arena,
+                          arena_words, ch_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,17 +559,19 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
 static int voxelize_impl(const float *feat, const int32_t *coords_i, const float *coords_f, int B,
                          int C, int N, int r, int normalize, float eps, float *out,
                          float *norm_coords, int32_t *ind, int32_t *cnt, void *ws, size_t ws_bytes,
-                         hipStream_t st) {
+                         hipStream_t st, void *plan = nullptr) {
   if (B <= 0 || N <= 0 || r <= 0 || !ind || !cnt) return LION_EINVAL;
   if (feat && (C <= 0 || !out)) return LION_EINVAL;
   if (!coords_i && !coords_f) return LION_EINVAL;
   if (coords_f && !norm_coords) return LION_EINVAL;
   if ((long)r * r * r > (1L << 30)) return LION_EUNSUPPORTED;
   const VoxPlan p = make_plan(B, feat ? C : 0, N, r);
-  if (!ws || ws_bytes < p.total) return LION_EWORKSPACE;
+  if (plan) {   // index mode (lion_voxel_index): fast path only, no workspace
+    if (!p.fast || ((((uintptr_t)cnt) & 15) != 0)) return LION_EUNSUPPORTED;
+  } else if (!ws || ws_bytes < p.total) return LION_EWORKSPACE;
   const int r3 = r * r * r;
   char *w = static_cast<char *>(ws);
-  const bool aligned = (((uintptr_t)out | (uintptr_t)cnt) & 15) == 0;
+  const bool aligned = (((uintptr_t)out | (uintptr_t)cnt) & 15) == 0;   // (out == nullptr in index mode)
   if (p.fast && aligned) {
     const int grid = ((B + 7) / 8) * 8 * p.S * p.CS;
     const int ch_cap = 64; // channel chunk (as many as the arena holds).  Round 3 sweep at (64,2048,32), us with / without P1: 8: 77.5 / 75.3, 16: 72.9 / 67.6, 24: 65.9 / 63.4, 32: 66.7 / 64.0, 64: 64.3 / 62.1
@@ -461,7 +581,7 @@ static int voxelize_impl(const float *feat, const int32_t *coords_i, const float
     if (int e = lion_dynamic_lds(&vox_fused_kernel<P1, NPV>, p.lds, cfg)) return e;                    \
     vox_fused_kernel<P1, NPV><<<grid, VT, p.lds, st>>>(feat, coords_i, coords_f, B, C, N, r, p.S, p.CS, p.SV, \
                                                        p.n_words, p.arena_words, ch_cap, normalize, eps, out, \
-                                                       norm_coords, ind, cnt);                         \
+                                                       norm_coords, ind, cnt, plan);                   \
   }
 #define LION_VOX_NP(P1)                                                                                \
   switch (p.NP) {                                                                                      \
@@ -526,6 +646,61 @@ int lion_voxelize_points_forward(const float *feat, const float *coords, int B, 
   if (!coords) return LION_EINVAL;
   return voxelize_impl(feat, nullptr, coords, B, C, N, r, normalize, eps, out, norm_coords, ind,
                        cnt, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t lion_voxel_plan_bytes(int B, int N, int r) {
+  if (B <= 0 || N <= 0 || r <= 0 || (long)r * r * r > (1L << 30)) return 0;
+  const VoxPlan p = make_plan(B, 0, N, r);
+  if (!p.fast) return 0;
+  return vox_plan_words(B, N, p.S) * 4;
+}
+
+int lion_voxel_index(const float *coords, int B, int N, int r, int normalize, float eps, float *norm_coords,
+                     int32_t *ind, int32_t *cnt, void *plan, size_t plan_bytes, lionStream_t stream) {
+  if (!coords || !plan || !norm_coords) return LION_EINVAL;
+  const size_t need = lion_voxel_plan_bytes(B, N, r);
+  if (need == 0) return LION_EUNSUPPORTED;
+  if (plan_bytes < need) return LION_EWORKSPACE;
+  return voxelize_impl(nullptr, nullptr, coords, B, 0, N, r, normalize, eps, nullptr, norm_coords, ind, cnt, nullptr, 0,
+                       static_cast<hipStream_t>(stream), plan);
+}
+
+int lion_voxel_scatter(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int r, float *out,
+                       lionStream_t stream) {
+  if (!feat || !plan || !out || B <= 0 || C <= 0 || N <= 0 || r <= 0) return LION_EINVAL;
+  const size_t need = lion_voxel_plan_bytes(B, N, r);
+  if (need == 0 || (((uintptr_t)out) & 15) != 0) return LION_EUNSUPPORTED;
+  if (plan_bytes < need) return LION_EWORKSPACE;
+  const VoxPlan p = make_plan(B, C, N, r);
+  if (!p.fast) return LION_EUNSUPPORTED;
+  const bool two_per_cu = N <= VT;
+  const size_t lds_limit = two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT;
+  const size_t fixed = ((size_t)p.SV + (size_t)p.n_words) * 4;
+  const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
+  const size_t want = ((size_t)N + nocc) * C * 4;
+  const size_t avail = fixed < lds_limit ? lds_limit - fixed : 0;
+  const size_t arena = want < avail ? want : avail;
+  if (arena / 4 < (size_t)N + nocc) return LION_EUNSUPPORTED;
+  const size_t lds = fixed + arena;
+  const int grid = ((B + 7) / 8) * 8 * p.S * p.CS;
+  const int r3 = r * r * r;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define LION_VOXS_LAUNCH(NPV)                                                                          \
+  {                                                                                                    \
+    static LionLdsLimit cfg = {};                                                                      \
+    if (int e = lion_dynamic_lds(&vox_scatter_kernel<NPV>, lds, cfg)) return e;                        \
+    vox_scatter_kernel<NPV><<<grid, VT, lds, st>>>(feat, plan, B, C, N, r3, p.S, p.CS, p.SV, p.n_words, \
+                                                   (int)(arena / 4), 64, out);                         \
+  }
+  switch (p.NP) {
+  case 1: LION_VOXS_LAUNCH(1) break;
+  case 2: LION_VOXS_LAUNCH(2) break;
+  case 4: LION_VOXS_LAUNCH(4) break;
+  default: LION_VOXS_LAUNCH(8) break;
+  }
+#undef LION_VOXS_LAUNCH
+  LION_LAUNCH_CHECK();
+  return 0;
 }
 
 int lion_avg_voxelize_backward(const float *gy, const int32_t *ind, const int32_t *cnt, int B,

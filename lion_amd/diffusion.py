@@ -235,13 +235,20 @@ class DiffusionDiscretized(object):
     def run_ddim(self, model, num_samples, shape, temp=1.0, enable_autocast=False, is_image=True,
                  prior_var=1.0, condition_input=None, ddim_step=100, skip_type='uniform', kappa=1.0,
                  clip_feat=None, grid_emb=None, x_noisy=None, dae_index=-1, noise='device',
-                 keep_trajectory=True, graph=True):
-        """DDIM sampling with ``ddim_step`` model evaluations; kappa is DDIM's eta (reference :390-473)."""
+                 keep_trajectory=True, graph=True, given_noise=None):
+        """DDIM sampling with ``ddim_step`` model evaluations; kappa is DDIM's eta (reference :390-473).
+        noise='cpu': EVERY draw of the chain -- the start and the per-step noise -- comes from torch's CPU generator, so
+        that one seed gives one chain on any device (the reference draws the per-step noise there, :465-466, and the
+        start on its device).  given_noise = (start, [z_0, z_1, ...]): run the eager loop on exactly these draws (the
+        counterpart of run_denoising_diffusion's given_noise; tests replay a graphed chain's recorded noise with it)."""
         model.eval()
         dev = self.device
         size = [num_samples] + list(shape)
-        x_noisy = torch.randn(size=size, device=dev) if x_noisy is None else x_noisy.to(dev)
-        x_noisy = x_noisy.contiguous()
+        if given_noise is not None:
+            x_noisy, noise = given_noise[0], 'given'
+        if x_noisy is None:
+            x_noisy = torch.randn(size=size).to(dev) if noise == 'cpu' else torch.randn(size=size, device=dev)
+        x_noisy = x_noisy.to(dev).contiguous()
         steps = self.ddim_schedule(self._diffusion_steps, ddim_step, skip_type)
         kwargs = {'grid_emb': grid_emb} if grid_emb is not None else {}
         output_list = []
@@ -269,7 +276,10 @@ class DiffusionDiscretized(object):
                              clip_feat=clip_feat, **kwargs)
                 eps_hat = _mixed(model, pred, mixing).float().contiguous()
             # the reference draws (and adds, scaled by sigma == 0) noise on the last step as well
-            z = self._noise(size, noise, dev).contiguous() if (sigma != 0.0 or noise == 'cpu') else None
+            if noise == 'given':
+                z = given_noise[1][i].to(dev).contiguous() if sigma != 0.0 else None
+            else:
+                z = self._noise(size, noise, dev).contiguous() if (sigma != 0.0 or noise == 'cpu') else None
             x_noisy = diffusion_ops.ddim_update(x_noisy, eps_hat, z if sigma != 0.0 else None, s, c, sigma)
             if keep_trajectory:
                 output_list.append(x_noisy)

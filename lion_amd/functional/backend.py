@@ -242,5 +242,39 @@ class _HipBackend:
             _lib.stream_ptr(dev)), "voxelize_points_forward")
         return out, norm, ind, cnt
 
+    # -- the same in two steps: index plan of (coords, r) once, mean-pool per feature tensor --------------------
+    def voxel_index(self, coords, resolution, normalize=True, eps=0.0):
+        """coords f32[B,3,N] raw -> plan dict {norm, ind, cnt, ws, key} for voxel_scatter, or None when the shape is
+        outside the plan kernels' range (callers then use voxelize_points_forward)."""
+        _lib.require_cuda(coords); _f32(coords, "coords")
+        b, _, n = coords.shape
+        r = int(resolution)
+        nbytes = self.lib.lion_voxel_plan_bytes(b, n, r)
+        if nbytes == 0:
+            return None
+        dev = coords.device
+        norm = torch.empty((b, 3, n), device=dev, dtype=torch.float32)
+        ind = torch.empty((b, n), device=dev, dtype=torch.int32)
+        cnt = torch.empty((b, r * r * r), device=dev, dtype=torch.int32)
+        ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+        _lib.check(self.lib.lion_voxel_index(_lib.ptr(coords), b, n, r, int(bool(normalize)), float(eps), _lib.ptr(norm),
+                                             _lib.ptr(ind), _lib.ptr(cnt), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev)),
+                   "voxel_index")
+        return {"norm": norm, "ind": ind, "cnt": cnt, "ws": ws, "shape": (b, n, r)}
+
+    def voxel_scatter(self, features, plan):
+        """features f32[B,C,N] -> f32[B,C,r^3] mean-pooled with plan's voxel assignment (bit-identical to
+        voxelize_points_forward on the plan's coordinates)."""
+        _lib.require_cuda(features); _f32(features, "features")
+        b, n, r = plan["shape"]
+        if features.shape[0] != b or features.shape[2] != n:
+            raise RuntimeError("voxel_scatter: features do not match the plan's cloud")
+        c = features.shape[1]
+        out = torch.empty((b, c, r * r * r), device=features.device, dtype=torch.float32)
+        ws = plan["ws"]
+        _lib.check(self.lib.lion_voxel_scatter(_lib.ptr(features), _lib.ptr(ws), ws.numel(), b, c, n, r, _lib.ptr(out),
+                                               _lib.stream_ptr(features.device)), "voxel_scatter")
+        return out
+
 
 _backend = _HipBackend()

@@ -128,7 +128,8 @@ class PVCNN2Unet(nn.Module):
         geo = geometry.prefetch(sa_mods, coords) if pvcnn2_ada.FUSE_INFERENCE and not self.training \
             else contextlib.nullcontext()
         # one GEMM for every AdaGN projection; FPS / ball-query chain on a side stream (inference)
-        with self._style_plan.projected(style), geo:
+        vplans = pvcnn2_ada.voxel_plans() if pvcnn2_ada.FUSE_INFERENCE and not self.training else contextlib.nullcontext()
+        with self._style_plan.projected(style), geo, vplans:
             coords_list, in_features_list = [], []
             for i, sa_blocks in enumerate(self.sa_layers):
                 in_features_list.append(features)

@@ -9,6 +9,7 @@ Differences that matter on MI355X (all numerically equivalent to fp32 rounding, 
   * the time embedding that the reference broadcasts to [B,64,N] and concatenates before every
     block is kept as given (shape contract of the callers), nothing is re-laid-out on the host.
 """
+import contextlib
 import functools
 import os
 
@@ -27,6 +28,25 @@ SPARSE_CONV1 = True
 # as a parallel branch of the captured step it costs 0.5 ms per step (lion_amd/geometry.py has the measurements)
 OVERLAP_POINT_BRANCH = os.environ.get("LION_OVERLAP_POINT_BRANCH", "0") != "0"
 _POINT_STREAMS = {}
+
+
+# Index plans of the voxelisations of one forward pass (inference): every PVConv of a stage voxelises the SAME coordinates
+# at the SAME resolution (reference :235-243), and the feature-propagation stages come back to the set-abstraction stages'
+# clouds -- 4 distinct (cloud, r) pairs for 14 voxelisations in the released denoiser.  While a PVCNN2Unet forward is in
+# flight this holds {(data_ptr, shape, r, normalize, eps): (coords tensor, plan)}; the coordinates tensor is kept alive by
+# the entry, so its address cannot be handed to another tensor while the entry exists.
+_VOX_PLANS = None
+VOX_PLAN = os.environ.get("LION_VOX_PLAN", "1") != "0"   # A/B switch: 0 = every voxelisation recomputes its indices
+
+
+@contextlib.contextmanager
+def voxel_plans():
+    global _VOX_PLANS
+    prev, _VOX_PLANS = _VOX_PLANS, ({} if VOX_PLAN else None)
+    try:
+        yield
+    finally:
+        _VOX_PLANS = prev
 
 
 def _point_stream(device):
@@ -264,8 +284,22 @@ class Voxelization(nn.Module):
         if return_counts:
             from ..functional.backend import _backend
             b, c = features.shape[:2]
+            co = coords[:, :3].float().contiguous()
+            plan = None
+            if _VOX_PLANS is not None and hasattr(_backend, "voxel_index"):
+                key = (co.data_ptr(), tuple(co.shape), self.r, bool(self.normalize), float(self.eps))
+                hit = _VOX_PLANS.get(key)
+                if hit is None:
+                    plan = _backend.voxel_index(co, self.r, self.normalize, self.eps)
+                    if plan is not None:
+                        _VOX_PLANS[key] = (co, plan)
+                else:
+                    plan = hit[1]
+            if plan is not None:   # phases B + C only: the voxel ids of this cloud at this resolution exist already
+                out = _backend.voxel_scatter(features.float().contiguous(), plan)
+                return out.view(b, c, self.r, self.r, self.r), plan["norm"], plan["cnt"]
             out, norm_coords, _, counts = _backend.voxelize_points_forward(
-                features.float().contiguous(), coords[:, :3].float().contiguous(), self.r, self.normalize, self.eps)
+                features.float().contiguous(), co, self.r, self.normalize, self.eps)
             return out.view(b, c, self.r, self.r, self.r), norm_coords, counts
         if features is None:
             from ..functional.backend import _backend

@@ -11,10 +11,12 @@ import torch
 @torch.no_grad()
 def generate_samples_vada_2prior(shape, dae, diffusion, vae, num_samples, enable_autocast=False,
                                  temp=1.0, ddim_step=0, clip_feat=None, ddim_skip_type='uniform',
-                                 ddim_kappa=1.0, noise='device', step_callback=None, graph=True):
+                                 ddim_kappa=1.0, noise='device', step_callback=None, graph=True, given_noise=None):
     """shape: vae.latent_shape(); dae: [global prior, local prior].  Returns (points [B,N,3], info).
     graph=True (default): every chain is replayed from one captured hipGraph per prior (lion_amd/chain.py);
-    graph=False: the eager per-step loop (noise='cpu' then reproduces the reference's noise stream)."""
+    graph=False: the eager per-step loop; noise='cpu' draws the start and every step's noise from torch's CPU generator
+    (one seed = one chain on any device: what the sampler-level parity test runs on the GPU and on the host);
+    given_noise = [(start, [z per step]) per prior] replays recorded draws through the eager loop (DDIM only)."""
     condition_input = None
     all_eps = []
     for i in range(len(dae)):
@@ -23,7 +25,8 @@ def generate_samples_vada_2prior(shape, dae, diffusion, vae, num_samples, enable
                                         is_image=False, ddim_step=ddim_step,
                                         condition_input=condition_input, clip_feat=clip_feat,
                                         skip_type=ddim_skip_type, kappa=ddim_kappa, noise=noise,
-                                        keep_trajectory=False, graph=graph)
+                                        keep_trajectory=False, graph=graph,
+                                        given_noise=None if given_noise is None else given_noise[i])
         else:
             eps, _ = diffusion.run_denoising_diffusion(dae[i], num_samples, shape[i], temp,
                                                        enable_autocast, is_image=False,

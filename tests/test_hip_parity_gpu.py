@@ -115,6 +115,37 @@ def test_voxelize_points_fused_p1(bk, orc, N, r, kind):
     assert np.array_equal(host(out), o_out)
 
 
+@pytest.mark.parametrize("C,N,r", [(6, 2048, 32), (70, 2048, 32), (9, 1024, 16), (130, 256, 8), (5, 64, 8), (3, 1000, 16)])
+@pytest.mark.parametrize("kind", ["gauss", "surface", "clump", "one-voxel"])
+def test_voxel_index_then_scatter_equals_fused_and_oracle(bk, orc, C, N, r, kind):
+    """The two-step form the models use (lion_voxel_index once per (cloud, r), lion_voxel_scatter per feature tensor):
+    norm_coords / ids / counts and the float means bit-identical to the fused entry point and to the oracle -- also on
+    clouds that put hundreds of points into one voxel (2 % outliers set the normalisation; the latents of a sampling
+    chain look like this) and on a cloud that collapses into a single voxel.  vox.cu:18-72, pvcnn2_ada.py:173-188."""
+    rng = np.random.default_rng(C + N + r)
+    B = 5
+    co = surface_cloud(rng, B, N) if kind == "surface" else gaussian_cloud(rng, B, N)
+    if kind == "clump":
+        co[:, :, : int(N * 0.98)] *= 0.08
+    if kind == "one-voxel":
+        co[:, :, 1:] = co[:, :, 1:] * 1e-4 + 0.3
+    feat = rng.standard_normal((B, C, N)).astype(np.float32)
+    o_nc, o_vc = orc.voxelize_coords(co, r, True, 0.0)
+    o_out, o_ind, o_cnt = orc.avg_voxelize_forward(feat, o_vc, r)
+    plan = bk.voxel_index(dev(co), r, True, 0.0)
+    assert plan is not None
+    assert np.array_equal(host(plan["norm"]), o_nc)
+    assert np.array_equal(host(plan["ind"]), o_ind)
+    assert np.array_equal(host(plan["cnt"]), o_cnt)
+    out = bk.voxel_scatter(dev(feat), plan)
+    assert np.array_equal(host(out), o_out)
+    out2 = bk.voxel_scatter(dev(feat[:, : max(C // 2, 1)].copy()), plan)        # the plan serves any channel count
+    assert np.array_equal(host(out2), o_out[:, : max(C // 2, 1)])
+    f_out, f_nc, f_ind, f_cnt = bk.voxelize_points_forward(dev(feat), dev(co), r, True, 0.0)
+    assert torch.equal(f_out, out) and torch.equal(f_nc, plan["norm"]) and torch.equal(f_ind, plan["ind"])
+    assert torch.equal(f_cnt, plan["cnt"])
+
+
 def test_voxelize_points_no_normalize_and_eps(bk, orc):
     rng = np.random.default_rng(11)
     B, C, N, r = 2, 3, 500, 16
