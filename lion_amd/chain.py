@@ -24,6 +24,9 @@ import torch
 from . import _lib, _wcache
 
 DDIM, DDPM = 0, 1
+# tests: a list here makes every chain run append (start latent, [the noise each step drew]) -- what an eager loop needs
+# to repeat a graphed chain draw for draw (run_ddim(given_noise=...)); chains are then captured with the noise output on
+RECORD = None
 
 
 def policy_key() -> tuple:
@@ -201,6 +204,9 @@ class GraphedChain:
         self.counter.zero_()
         words = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)
         self.seed.copy_(torch.from_numpy(words))
+        if RECORD is not None and self.z is not None and noise_trajectory is None:
+            noise_trajectory = []
+            RECORD.append((x_init.detach().clone(), noise_trajectory))
         for i in range(S):
             if trajectory is not None and trajectory_before_last and i == S - 1:
                 trajectory.append(self.x.clone())
@@ -222,7 +228,8 @@ class ChainCache:
         self._capacity = capacity
 
     def get(self, model, num_samples, shape, condition_input, clip_feat, device, mode, table_capacity):
-        key = (id(model), mode, int(num_samples), tuple(shape), str(device))
+        rec = RECORD is not None
+        key = (id(model), mode, int(num_samples), tuple(shape), str(device), rec)
         hit = self._entries.get(key)
         if hit is not None and hit.model is model and hit.capacity >= table_capacity \
                 and hit.matches(condition_input, clip_feat):
@@ -232,7 +239,8 @@ class ChainCache:
         if hit is not None:
             del self._entries[key]
             self._order.remove(key)
-        chain = GraphedChain(model, num_samples, shape, condition_input, clip_feat, device, mode, table_capacity)
+        chain = GraphedChain(model, num_samples, shape, condition_input, clip_feat, device, mode, table_capacity,
+                             record_noise=rec)
         self._entries[key] = chain
         self._order.append(key)
         while len(self._order) > self._capacity:

@@ -115,14 +115,14 @@ def test_sampling_chain_b32_graph_equals_eager_steps(lion32, streams):
                     tt = torch.full((B,), float(table[i, 0]), device="cuda")
                     eps = prior(x=x, t=tt, condition_input=cond, clip_feat=None).float().contiguous()
                     want = diffusion_ops.ddim_update(x, eps, zs[i], *[float(v) for v in table[i, 1:4]])
-                    err = (xs[i] - want).abs().max().item() / want.abs().max().item()
-                    assert err <= 2e-6, (rep, i, err)
+                    assert torch.equal(xs[i], want), (rep, i, (xs[i] - want).abs().max().item() / want.abs().max().item())
                     x = xs[i]
 
 
 def test_product_sampler_b32_runs_twice_identically(lion32):
     """generate_samples_vada_2prior at B = 32 on the graphed path: same torch seed -> same start, same Philox key ->
-    the same clouds, and they are finite"""
+    the same clouds BIT FOR BIT, and they are finite (every kernel of a sampling step sums in a fixed order; the work
+    queue of the sparse convolutions only decides WHO computes a tile)"""
     from lion_amd.sampling import generate_samples_vada_2prior
     lion, d = lion32, lion32.diffusion
     sh = lion.vae.latent_shape()
@@ -132,7 +132,7 @@ def test_product_sampler_b32_runs_twice_identically(lion32):
         p, _ = generate_samples_vada_2prior(sh, lion.priors, d, lion.vae, B, ddim_step=5)
         outs.append(p.clone())
     assert tuple(outs[0].shape) == (B, 2048, 3) and torch.isfinite(outs[0]).all()
-    assert (outs[0] - outs[1]).abs().max().item() <= 1e-3 * outs[0].abs().max().item()
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_local_prior_b32_forward_vs_oracle_backend():

@@ -157,8 +157,7 @@ def test_graphed_chain_equals_eager_steps(small_lion):
                 tt = torch.full((B,), float(table[i, 0]), device="cuda")
                 eps = prior(x=x, t=tt, condition_input=cond, clip_feat=None).float().contiguous()
                 want = diffusion_ops.ddim_update(x, eps, zs[i], *[float(v) for v in table[i, 1:4]])
-                err = (xs[i] - want).abs().max().item() / want.abs().max().item()
-                assert err <= 2e-6, (i, err)
+                assert torch.equal(xs[i], want), (i, (xs[i] - want).abs().max().item() / want.abs().max().item())
                 x = xs[i]                            # follow the graph's trajectory: per-step comparison
 
 
@@ -176,8 +175,7 @@ def test_product_sampler_graph_equals_eager_when_deterministic(small_lion):
     b, _ = d.run_ddim(lion.priors[1], B, sh[1], ddim_step=4, kappa=0.0, condition_input=style, x_noisy=x0,
                       is_image=False, graph=False)
     assert len(tr) == 4 and torch.equal(tr[-1], a)
-    err = (a - b).abs().max().item() / b.abs().max().item()
-    assert err <= 1e-5, err
+    assert torch.equal(a, b), (a - b).abs().max().item() / b.abs().max().item()
     n_before = len(d._chains._entries)
     torch.manual_seed(11)
     p1, _ = generate_samples_vada_2prior(sh, lion.priors, d, lion.vae, B, ddim_step=3)
@@ -186,8 +184,9 @@ def test_product_sampler_graph_equals_eager_when_deterministic(small_lion):
     p2, _ = generate_samples_vada_2prior(sh, lion.priors, d, lion.vae, B, ddim_step=3)
     assert tuple(p1.shape) == (B, 2048, 3) and torch.isfinite(p1).all()
     assert len(d._chains._entries) == n_mid >= n_before     # second call: no new capture
-    # same torch seed -> same start and same Philox key -> same cloud up to kernel-order noise
-    assert (p1 - p2).abs().max().item() <= 1e-3 * p1.abs().max().item()
+    # same torch seed -> same start and same Philox key -> the same cloud, bit for bit (no kernel of the step leaves its
+    # summation order to the scheduler: tools/determinism_probe.py)
+    assert torch.equal(p1, p2)
 
 
 def test_chain_is_recaptured_when_weights_change(small_lion):

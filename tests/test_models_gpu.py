@@ -117,10 +117,8 @@ def test_ddim_sampler_single_steps_match_torch_formulation():
 
 
 def test_two_prior_sampling_runs_end_to_end():
-    """4 shapes x 2048 points, 6 DDIM steps per prior + decode: finite and the right shape.  (Run-to-run
-    bit reproducibility of the WHOLE chain is not asserted: the library GEMMs of the 1x1 convs /
-    Linear layers may use split-K atomics, and one flipped voxel id or FPS pick changes the cloud; the
-    hand-written operators are individually pinned bit-exact in test_hip_parity_gpu.)"""
+    """4 shapes x 2048 points, 6 DDIM steps per prior + decode: finite and the right shape.  (Run-to-run bit
+    reproducibility of the whole chain: tests/test_b32_replay_gpu.py, tests/test_sampler_parity_gpu.py.)"""
     from lion_amd.config import released_prior_cfg
     from lion_amd.models.lion import LION
     from lion_amd.sampling import generate_samples_vada_2prior
