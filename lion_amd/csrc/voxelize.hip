@@ -671,9 +671,21 @@ int lion_voxel_scatter(const float *feat, const void *plan, size_t plan_bytes, i
   const size_t need = lion_voxel_plan_bytes(B, N, r);
   if (need == 0 || (((uintptr_t)out) & 15) != 0) return LION_EUNSUPPORTED;
   if (plan_bytes < need) return LION_EWORKSPACE;
-  const VoxPlan p = make_plan(B, C, N, r);
-  if (!p.fast) return LION_EUNSUPPORTED;
-  const bool two_per_cu = N <= VT;
+  const VoxPlan p0 = make_plan(B, C, N, r);
+  if (!p0.fast) return LION_EUNSUPPORTED;
+  VoxPlan p = p0;
+  // Option: TWO workgroups per CU for every cloud size (the scatter kernel needs 40 registers): one's mean phase (B) under
+  // the other's store phase (C).  Half the LDS each -> more channel chunks; 512 workgroups -> channel ranges (the plan
+  // makes the per-workgroup prologue cheap).  Measured (round 4, (64,2048,32)): 66 us against 58 with one workgroup per CU -- off; -DLION_VOXS_TWO=1 builds it.
+#ifndef LION_VOXS_TWO
+#define LION_VOXS_TWO 0
+#endif
+  const bool two_per_cu = LION_VOXS_TWO || N <= VT;
+  if (two_per_cu) {
+    int CS = 1;
+    while ((long)B * p.S * CS < 512 && C / (CS * 2) >= 8) CS *= 2;
+    p.CS = CS;
+  }
   const size_t lds_limit = two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT;
   const size_t fixed = ((size_t)p.SV + (size_t)p.n_words) * 4;
   const size_t nocc = (size_t)(N < p.SV ? N : p.SV);

@@ -148,9 +148,12 @@ def _compare_geometry(hip_seg, cpu_seg):
             continue
         cands = hip_vox.get((r, b.shape))
         assert cands, f"no HIP voxelisation at r={r} for a cloud of shape {b.shape}"
-        e = res.setdefault("voxel ids", [0, 0, 0])
+        # the 2048-point input cloud is the latent itself; the smaller clouds are furthest-point picks (they differ
+        # wholesale once one pick differs)
+        which = "input cloud" if b.shape[1] == 2048 else "FPS-sampled clouds"
+        e = res.setdefault(f"voxel ids, {which}", [0, 0, 0])
         e[0] += 1; e[1] += b.size; e[2] += min(int((a != b).sum()) for a, _ in cands)
-        e = res.setdefault("voxel counts", [0, 0, 0])
+        e = res.setdefault(f"voxel counts, {which}", [0, 0, 0])
         e[0] += 1; e[1] += cb.size; e[2] += min(int((ca != cb).sum()) for _, ca in cands)
     return res
 
@@ -186,7 +189,8 @@ def test_product_sampler_hip_vs_cpu_oracle_same_noise(lions, B, K):
         g = _compare_geometry(segs_h[k], segs_c[k])
         rep["later_geometry"].append({"segment": "decode" if k == 2 * K else f"local step {k - K}",
                                       **{kk: {"integers": v[1], "differing": v[2], "fraction": v[2] / v[1]} for kk, v in g.items()}})
-        assert g["voxel ids"][2] <= 0.02 * g["voxel ids"][1], rep["later_geometry"][-1]
+        v = g["voxel ids, input cloud"]
+        assert v[2] <= 0.01 * v[1], rep["later_geometry"][-1]
     # -- floats: latent after every step, decoded coordinates --------------------------------------------------
     rep["latent_rel_err"] = []
     for k, (a, b) in enumerate(zip(xs_h, xs_c)):
