@@ -219,8 +219,8 @@ def train_bench(args, rank, world, dev, backend):
     """--mode train_vae | train_prior: one data-parallel training step of BASELINE.json configs[2] / configs[3] at the
     per-GPU share of the quoted batch (B = 128 / 4 and 256 / 8 = 32 x 2048 points): forward + backward + bucketed
     gradient averaging (lion_amd/dist.py; hooks armed at world size 1 too) + Adam, synthetic N(0, 1) clouds.
-    value = samples/s over all ranks.  The step is captured in one hipGraph when it can be (world size 1; 7.8 k launches
-    per VAE step otherwise leave the GPU idle 80 % of the time); `launch` says which one ran."""
+    value = samples/s over all ranks.  The step runs through lion_amd.training.GraphedTrainStep at every world size
+    (7.8 k launches per eager VAE step leave the GPU idle 80 % of the time); `launch` says which form ran."""
     import torch.distributed as dist
     from lion_amd.config import released_prior_cfg
     from lion_amd.dist import BucketedGradAverager, broadcast_params
@@ -231,7 +231,7 @@ def train_bench(args, rank, world, dev, backend):
     B = args.batch if args.batch_given else (8 if clip_mode else 32)   # configs[4]: B = 64 over 8 GPUs
     K, W = (args.steps if args.steps_given else 20), args.warmup
     torch.manual_seed(0)
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not args.no_graph
     if vae_mode:
         from lion_amd.models.vae_adain import Model as VAE
         model = VAE(cfg).to(dev).train()
@@ -258,53 +258,26 @@ def train_bench(args, rank, world, dev, backend):
     torch.manual_seed(1234 + rank)
     x = torch.randn(B, 2048, 3, device=dev)
     clip_feat = torch.randn(B, 512, device=dev) if clip_mode else None   # the CLIP encoder itself is out of scope
+    # the PRODUCT's captured step (lion_amd/training.py::GraphedTrainStep): whole-step graph at world 1 and with RCCL
+    # (bucket all-reduces captured as a side branch), [fwd + bwd] -> eager all-reduce -> [optimizer] graphs on backends
+    # whose collectives cannot be captured (gloo); eager only with --no-graph or if capture fails (`launch` says so)
+    if vae_mode:
+        def fb(x):
+            return training.vae_forward_backward(model, opt, x, step=0, averager=averager)
+    else:
+        def fb(x):
+            return training.prior_forward_backward(lion.vae, model, lion.diffusion, opt, x, averager=averager,
+                                                   clip_feat=clip_feat)
+    stepper = training.GraphedTrainStep(fb, {"x": x}, params, opt, averager, mode="off" if args.no_graph else None,
+                                        warmup=max(W, 3))
+    launch = stepper.launch
     static_loss = [None]
 
-    def step():
-        nonlocal opt, averager
-        if vae_mode:
-            loss, _ = training.vae_train_step(model, opt, x, step=0, averager=averager, distributed=world > 1)
-        else:
-            loss, _ = training.prior_train_step(lion.vae, model, lion.diffusion, opt, x, averager=averager,
-                                                distributed=world > 1, clip_feat=clip_feat)
-        static_loss[0] = loss
-        return loss
+    def runner():
+        static_loss[0] = stepper()
 
-    launch = "eager"
-    for _ in range(max(W, 3)):
-        step()
+    runner()
     torch.cuda.synchronize()
-    runner = step
-    if use_graph:
-        try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step()
-            runner = g.replay
-            launch = "hipGraph replay of the whole step (forward, backward, Adam)"
-            g.replay()
-            torch.cuda.synchronize()
-        except Exception as e:  # capture is an optimisation: say so and measure the eager step
-            import traceback
-            traceback.print_exc(file=sys.stderr)
-            print(f"bench: training-step capture failed ({type(e).__name__}); eager launches", file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            # an aborted capture leaves gradient views / optimizer state pointing into the dead graph pool: start over
-            averager.remove_hooks()
-            for p_ in params:
-                p_.grad = None
-            opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), fused=fused_adam)
-            averager = BucketedGradAverager(params)
-            runner = step
-            launch = f"eager (capture failed: {type(e).__name__})"
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
 
     def sync_all():
         torch.cuda.synchronize()

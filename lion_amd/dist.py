@@ -84,6 +84,11 @@ class BucketedGradAverager:
         self._works = []
         self._hooks = []
         self._stream = None
+        self._launched = set()
+        # False: the hooks only keep the books (who got a gradient, aliasing); the buckets are reduced by finish() /
+        # reduce_all().  GraphedTrainStep's split mode sets it: a backend whose collectives cannot be stream-captured
+        # (gloo) must not be called from inside the captured backward.
+        self.launch_in_hooks = True
         if not self.params:
             return
         dev = self.params[0].device
@@ -118,9 +123,11 @@ class BucketedGradAverager:
         self._pending = {i: len(pl) for i, (_, pl) in enumerate(self.buckets)}
         self._works = []
         self._seen = set()
+        self._launched = set()
 
     def _launch(self, i):
         flat, _ = self.buckets[i]
+        self._launched.add(i)
         if self.world == 1:
             return
         if self._stream is not None:
@@ -153,7 +160,7 @@ class BucketedGradAverager:
         self._seen.add(p)
         self._realias(p)
         self._pending[i] -= 1
-        if self._pending[i] == 0:
+        if self._pending[i] == 0 and self.launch_in_hooks:
             self._launch(i)
 
     def zero_grad(self):
@@ -185,8 +192,8 @@ class BucketedGradAverager:
                 for i in range(len(self.buckets)):
                     self._launch(i)
             else:  # parameters that received no gradient this step leave their bucket pending
-                for i, left in self._pending.items():
-                    if left > 0:
+                for i in range(len(self.buckets)):
+                    if i not in self._launched:
                         self._launch(i)
             for w in self._works:
                 w.wait()
@@ -197,6 +204,19 @@ class BucketedGradAverager:
                 if p not in touched:
                     p.grad = None
         self._reset()
+
+    def reduce_all(self):
+        """average every bucket now, on the current stream's timeline, and wait -- no bookkeeping (which parameters take
+        part was fixed when the step was captured): what a replayed [forward + backward] graph is followed by when the
+        collectives themselves are not capturable"""
+        if self.world == 1:
+            return
+        works = []
+        for flat, _ in self.buckets:
+            flat.div_(float(self.world))
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
 
     def remove_hooks(self):
         for h in self._hooks:

@@ -130,10 +130,13 @@ class Model(nn.Module):
         output['final_pred'] = output['x_0_pred']
         return output
 
-    def get_loss(self, x, writer=None, it=None, noisy_input=None, class_label=None, **kwargs):
-        """L1 reconstruction + KL of both latents (reference :209-296)."""
+    def get_loss(self, x, writer=None, it=None, noisy_input=None, class_label=None, kl_weight=None, **kwargs):
+        """L1 reconstruction + KL of both latents (reference :209-296).  kl_weight (not in the reference): the KL weight
+        as a 0-d tensor, for callers that keep the annealing schedule in device memory (a captured training step)."""
         a = self.args
-        if a.trainer.anneal_kl and self.num_total_iter > 0:
+        if kl_weight is not None:
+            pass
+        elif a.trainer.anneal_kl and self.num_total_iter > 0:
             kl_weight = kl_coeff(step=it, total_step=a.sde.kl_anneal_portion_vada * self.num_total_iter,
                                  constant_step=a.sde.kl_const_portion_vada * self.num_total_iter,
                                  min_kl_coeff=a.sde.kl_const_coeff_vada, max_kl_coeff=a.sde.kl_max_coeff_vada)

@@ -50,11 +50,21 @@ def test_train_vae_two_ranks_bucketed_averaging_over_gloo():
     d = _bench("--gpus", "2", "--mode", "train_vae", "--steps", "2", "--warmup", "1", "--batch", "2",
                env={"LION_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["unit"] == "samples/s" and d["value"] > 0
-    assert "world 2" in d["config"]["gradient_averaging"] and d["config"]["launch"].startswith("eager")
+    # the captured step runs at world size 2 as well (round 4): gloo's collectives cannot be stream-captured, so the
+    # product's GraphedTrainStep replays [forward + backward], averages the buckets eagerly, replays [optimizer step]
+    launch = d["config"]["launch"]
+    assert "world 2" in d["config"]["gradient_averaging"]
+    assert not launch.startswith("eager") and "eager bucket all-reduce (gloo)" in launch and "hipGraph" in launch, launch
     assert d["config"]["final_loss"] == d["config"]["final_loss"]  # not NaN
 
 
 def test_train_prior_clip_line():
     d = _bench("--gpus", "1", "--mode", "train_prior_clip", "--steps", "2", "--warmup", "1", "--batch", "2")
     assert "configs[4]" in d["config"]["workload"] and d["value"] > 0
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]
+
+
+def test_train_prior_single_rank_whole_step_graph():
+    d = _bench("--gpus", "1", "--mode", "train_prior", "--steps", "2", "--warmup", "1", "--batch", "2")
+    assert d["config"]["launch"].startswith("hipGraph replay of the whole step"), d["config"]["launch"]
     assert d["config"]["final_loss"] == d["config"]["final_loss"]

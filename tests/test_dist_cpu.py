@@ -102,6 +102,23 @@ def _w_bucketed(rank, world):
     avg4.finish()
     for p, q in zip(m4.parameters(), m2.parameters()):
         torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7)
+    # hooks armed but told not to launch (GraphedTrainStep's split mode: the backward is a replayed graph, the
+    # collectives run eagerly behind it): finish() reduces every bucket itself; reduce_all() is the replay-time form
+    m5 = _model(100)
+    avg5 = BucketedGradAverager(m5.parameters(), bucket_bytes=256, overlap=True)
+    avg5.launch_in_hooks = False
+    avg5.zero_grad()
+    (m5(x) - y).square().mean().backward()
+    assert not avg5._launched and not avg5._works
+    avg5.finish()
+    for p, q in zip(m5.parameters(), m2.parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7)
+    avg5.zero_grad()
+    (m5(x) - y).square().mean().backward()
+    avg5.reduce_all()
+    for p, q in zip(m5.parameters(), m2.parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7)
+    avg5._reset()
 
 
 def _w_sampling(rank, world):

@@ -197,3 +197,47 @@ def test_resident_point_clouds_cut_batches_on_the_device(tmp_path):
     ds.sample_with_replacement = 0
     pick = D.ResidentPointClouds(ds, "cuda", 4).pick_points(5).cpu()
     assert all(len(set(r.tolist())) == 32 for r in pick)
+
+
+def test_graphed_train_step_whole_split_and_eager_agree():
+    """lion_amd.training.GraphedTrainStep on a deterministic toy regression (no dropout, no sampled noise): the three
+    ways it can run a step -- one graph, [forward + backward] / [optimizer] graphs around an eager averaging, plain eager
+    -- leave bit-identical parameters after 5 steps, with the bucketed averager's hooks armed (world size 1)."""
+    from lion_amd.dist import BucketedGradAverager
+    from lion_amd.training import GraphedTrainStep
+
+    def run(mode):
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4)).cuda()
+        unused = torch.nn.Parameter(torch.ones(7, device="cuda"))          # never receives a gradient
+        params = list(net.parameters()) + [unused]
+        opt = torch.optim.Adam(params, lr=1e-2, capturable=True)
+        avg = BucketedGradAverager(params, bucket_bytes=2048)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        xs = [torch.randn(32, 16, device="cuda", generator=gen) for _ in range(8)]
+        ys = [torch.randn(32, 4, device="cuda", generator=gen) for _ in range(8)]
+
+        def fb(x, y, w):
+            avg.zero_grad()
+            loss = ((net(x) - y) ** 2).mean() * w
+            loss.backward()
+            return loss.detach(), None
+        st = GraphedTrainStep(fb, {"x": xs[0].clone(), "y": ys[0].clone(), "w": torch.ones((), device="cuda")}, params, opt,
+                              avg, mode=mode, warmup=4 if mode == "off" else 3)
+        losses = []
+        for i in range(3, 8):
+            st.set_scalar("w", 1.0 + 0.1 * i)
+            losses.append(float(st(x=xs[i], y=ys[i])))
+        torch.cuda.synchronize()
+        assert unused.grad is None and torch.equal(unused.detach(), torch.ones(7, device="cuda"))
+        return st, [p.detach().clone() for p in net.parameters()], losses
+
+    st_w, p_w, l_w = run("whole")
+    st_s, p_s, l_s = run("split")
+    st_e, p_e, l_e = run("off")     # (run() gives the eager form the extra warm-up step the captures spend on their side-stream pass)
+    assert st_w.mode == "whole" and len(st_w._graphs) == 1, st_w.launch
+    assert st_s.mode == "split" and len(st_s._graphs) == 2, st_s.launch
+    assert st_e.mode == "eager"
+    assert l_w == l_s == l_e
+    for a, b, c in zip(p_w, p_s, p_e):
+        assert torch.equal(a, b) and torch.equal(a, c)
