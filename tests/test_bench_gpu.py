@@ -34,6 +34,16 @@ def test_sample_line_contract_single_rank():
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert len(d["config"]["ms_per_step_all_runs"]) == 2 and "workload" in d["config"]
+    # round 4: the in-step conv instantiation is THE roofline, the plain kernel a side key; the real 1000-step chain
+    # rides along with a short timed region; the chain structure that was replayed is on the line
+    assert "PRO=true" in d["roofline"]["kernel"] and d["roofline_plain_kernel"]["frac"] > 0
+    fc = d["config"]["full_chain_1000"]
+    assert fc["seconds"] > 0 and abs(fc["shapes_per_s"] - 2 / fc["seconds"]) < 1e-9
+    chains = d["config"]["streams"]["captured_chains [global prior, local prior]"]
+    assert len(chains) == 2 and chains[0]["streams"] == 1 and chains[1]["geometry_graphs"] >= 1
+    for k in ("roofline_chamfer", "roofline_emd", "latency_bound_operators", "roofline_voxelize", "roofline_devoxelize"):
+        assert k in d, k
+    assert d["cpu_baseline"]["ms_per_step_B32"] > 0 and len(d["cpu_baseline"]["per_kernel_B32"]) == 3
 
 
 def test_sample_two_ranks_share_the_device_over_gloo():
