@@ -27,6 +27,7 @@ DDIM, DDPM = 0, 1
 # tests: a list here makes every chain run append (start latent, [the noise each step drew]) -- what an eager loop needs
 # to repeat a graphed chain draw for draw (run_ddim(given_noise=...)); chains are then captured with the noise output on
 RECORD = None
+TEMB_TABLE = __import__("os").environ.get("LION_TEMB_TABLE", "1") != "0"   # A/B: 0 = every step recomputes its time embedding
 
 
 def policy_key() -> tuple:
@@ -35,7 +36,7 @@ def policy_key() -> tuple:
     from . import conv_ops, fused_ops, geometry
     from .models import pvcnn2_ada
     return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, geometry.ENABLED,
-            geometry.SPLIT_GRAPH, conv_ops.SPLIT, fused_ops.PW_SPLIT, pvcnn2_ada.VOX_PLAN)
+            geometry.SPLIT_GRAPH, conv_ops.SPLIT, fused_ops.PW_SPLIT, pvcnn2_ada.VOX_PLAN, TEMB_TABLE)
 
 
 class GraphedChain:
@@ -59,6 +60,11 @@ class GraphedChain:
         self.table[:, 0] = 1.0   # t_model
         self.table[:, 1] = 1.0   # a0: x passes through
         self.table[:, 3] = 1.0   # a2: DDPM divisor (DDIM: z has weight 1 -- finite)
+        # The time embedding of a step depends on the step's timestep alone: its rows for the whole chain are computed once
+        # per run() (model.time_embedding over the schedule) and a replayed step picks its row by the device-resident step
+        # index -- instead of 7 (global prior) / 3 (local prior) launches per step that recompute it for every sample.
+        self.temb_table = None
+        self.use_temb_table = TEMB_TABLE and hasattr(model, "time_embedding") and not getattr(model, "embed_dim", 1) == 0
         self.policy = policy_key()
         self.pinned = []         # strong references to every packed / mirrored weight the captured launches point at
         lib = _lib.load()
@@ -68,7 +74,10 @@ class GraphedChain:
             _lib.check(lib.lion_chain_begin_step(_lib.ptr(self.table), self.capacity, _lib.ptr(self.counter),
                                                  _lib.ptr(self.t), num_samples, _lib.ptr(self.cur), st),
                        "chain_begin_step")
-            pred = model(x=self.x, t=self.t, condition_input=self.cond, clip_feat=self.clip)
+            extra = {}
+            if self.temb_table is not None:   # cur[7] holds the step index (begin_step_kernel), bit-cast into a float slot
+                extra["temb"] = self.temb_table.index_select(0, self.cur[7:8].view(torch.int32))
+            pred = model(x=self.x, t=self.t, condition_input=self.cond, clip_feat=self.clip, **extra)
             eps = pred.float().contiguous()
             _lib.check(lib.lion_chain_update_noise(mode, _lib.ptr(self.x), _lib.ptr(eps), self.x.numel(),
                                                    _lib.ptr(self.cur), _lib.ptr(self.seed), 0, _lib.ptr(self.x),
@@ -87,6 +96,10 @@ class GraphedChain:
         self.geo_graphs = self.graph_b = None
         self.geo_plan = None
         split = geometry.SPLIT_GRAPH and src is not None and not geometry.ENABLED
+        if self.use_temb_table:
+            with torch.no_grad():
+                row = model.time_embedding(torch.ones(1, device=dev))
+            self.temb_table = torch.zeros((self.capacity,) + tuple(row.shape[1:]), device=dev)
         main = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(main)
@@ -201,6 +214,11 @@ class GraphedChain:
         if self.clip is not None:
             self.clip.copy_(clip_feat)
         self.table[:S].copy_(torch.from_numpy(np.ascontiguousarray(table, dtype=np.float32)), non_blocking=False)
+        if self.temb_table is not None:
+            was_training = self.model.training
+            self.model.eval()
+            self.temb_table[:S].copy_(self.model.time_embedding(self.table[:S, 0].contiguous()))
+            self.model.train(was_training)
         self.counter.zero_()
         words = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)
         self.seed.copy_(torch.from_numpy(words))

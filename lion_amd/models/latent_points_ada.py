@@ -96,6 +96,14 @@ class PVCNN2Unet(nn.Module):
             emb = nn.functional.pad(emb, (0, 1), "constant", 0)
         return emb
 
+    def time_embedding(self, t):
+        """[S] timesteps -> [S, embed_dim] (embedf of the sinusoidal embedding, reference :150-153): row i depends on t[i]
+        alone, so a chain runner computes the rows of a whole chain once (lion_amd/chain.py)"""
+        emb = self.get_timestep_embedding(t, t.device)
+        if pvcnn2_ada.own_kernels(emb) and len(self.embedf) == 3:  # Linear -> LeakyReLU(0.1) -> Linear: 2 launches
+            return pvcnn2_ada.linear(self.embedf[2], pvcnn2_ada.linear(self.embedf[0], emb, 2, self.embedf[1].negative_slope))
+        return self.embedf(emb)
+
     def sa_modules(self):
         """the PointNetSAModule of every set-abstraction stage, in order (lion_amd/geometry.py)"""
         return [blk[-1] if isinstance(blk, nn.Sequential) else blk for blk in self.sa_layers]
@@ -106,14 +114,14 @@ class PVCNN2Unet(nn.Module):
         features = inputs
         temb = kwargs.get('t', None)
         if temb is not None:
-            t = temb
-            if t.ndim == 0 and not len(t.shape) == 1:
-                t = t.view(1).expand(B)
-            emb = self.get_timestep_embedding(t, inputs.device)
-            if pvcnn2_ada.own_kernels(emb) and len(self.embedf) == 3:  # Linear -> LeakyReLU(0.1) -> Linear: 2 launches
-                emb = pvcnn2_ada.linear(self.embedf[2], pvcnn2_ada.linear(self.embedf[0], emb, 2, self.embedf[1].negative_slope))
-            else:
-                emb = self.embedf(emb)
+            emb = kwargs.get('temb', None)       # rows of time_embedding(t) from a caller that already has them
+            if emb is None:
+                t = temb
+                if t.ndim == 0 and not len(t.shape) == 1:
+                    t = t.view(1).expand(B)
+                emb = self.time_embedding(t)
+            elif emb.shape[0] == 1 and B > 1:
+                emb = emb.expand(B, -1)
             temb = emb[:, :, None].expand(-1, -1, inputs.shape[-1])
         style = kwargs['style']
         if self.clip_forge_enable:

@@ -49,5 +49,5 @@ class PVCNN2Prior(PVCNN2Unet):
         input_shape = x.shape
         x = x.view(-1, self.num_points, self.num_classes).permute(0, 2, 1).contiguous()
         out = super().forward(x, t=t, style=kwargs['condition_input'].squeeze(-1).squeeze(-1),
-                              clip_feat=kwargs.get('clip_feat', None))
+                              clip_feat=kwargs.get('clip_feat', None), temb=kwargs.get('temb', None))
         return out.permute(0, 2, 1).contiguous().view(input_shape)

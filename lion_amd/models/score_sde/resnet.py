@@ -127,10 +127,18 @@ class Prior(nn.Module):
         from ..pvcnn2_ada import route_1x1_convs
         route_1x1_convs(self)
 
-    def forward(self, x, t, **kwargs):
+    def time_embedding(self, t):
+        """[S] timesteps -> [S, nf, 1, 1]: row i depends on t[i] alone (the reference computes it per sample and per step,
+        resnet.py:199; a chain runner computes the S rows of a chain once -- lion_amd/chain.py)"""
         if t.dim() == 0:
             t = t.expand(1)
-        temb = self.temb_layer(self.temb_fun(t)[:, :, None, None])
+        return self.temb_layer(self.temb_fun(t)[:, :, None, None])
+
+    def forward(self, x, t, temb=None, **kwargs):
+        """temb (not in the reference): the rows of time_embedding(t) for this call, [B or 1, nf, 1, 1], from a caller that
+        already has them"""
+        if temb is None:
+            temb = self.time_embedding(t)
         if self.clip_forge_enable:
             clip_feat = kwargs['clip_feat']
             clip_feat = self.clip_feat_mapping(clip_feat[:, :, None])[:, :, :, None]
