@@ -20,8 +20,16 @@
 namespace {
 
 constexpr int CH_TILE = 1024; // targets per LDS tile (16 KiB as float4)
-constexpr int CH_QPL = 2;     // queries per lane
+constexpr int CH_QPL = 4;     // queries per lane
+constexpr int CH_QPB = 64 * CH_QPL; // queries per workgroup
 
+// Round 4.  B = 32 pairs of 2048-point clouds are only 131 k query points: with one query pair per lane (round 1-3:
+// 256 workgroups x 4 waves) every SIMD held ONE wave and waited out its own dependent-issue and LDS latencies (17.6 TF
+// of distance arithmetic, 11 % of the vector peak).  Now a workgroup's four waves share the SAME 256 queries -- four per
+// lane: four independent distance / compare chains per LDS broadcast -- and each wave scans its own quarter of every
+// target tile; the four partial (distance, index) results of a query are merged through LDS with the scan's own rule
+// (smaller distance wins, equal distances keep the lower index -- what strict '<' over ascending indices yields), so
+// dist and idx stay bit-exact.  512 workgroups at B = 32: two waves per SIMD.
 __global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2, int N,
                                                           int M, float *__restrict__ dist1,
@@ -29,9 +37,9 @@ __global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float *__restric
                                                           int32_t *__restrict__ idx1,
                                                           int32_t *__restrict__ idx2) {
   __shared__ float4 tile[CH_TILE];
-  const int tid = threadIdx.x, b = blockIdx.y, dir = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, dir = blockIdx.z;
   const int nq = dir == 0 ? N : M, nt = dir == 0 ? M : N;
-  if (blockIdx.x * 256 * CH_QPL >= nq) return; // uniform per block
+  if (blockIdx.x * CH_QPB >= nq) return; // uniform per block
   const float *q = (dir == 0 ? xyz1 : xyz2) + (size_t)b * nq * 3;
   const float *t = (dir == 0 ? xyz2 : xyz1) + (size_t)b * nt * 3;
   float *dout = (dir == 0 ? dist1 : dist2) + (size_t)b * nq;
@@ -41,12 +49,13 @@ __global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float *__restric
   int bi[CH_QPL];
 #pragma unroll
   for (int p = 0; p < CH_QPL; ++p) {
-    const int j = (blockIdx.x * CH_QPL + p) * 256 + tid;
+    const int j = blockIdx.x * CH_QPB + p * 64 + lane;
     qx[p] = qy[p] = qz[p] = 0.f;
     if (j < nq) { qx[p] = q[j * 3]; qy[p] = q[j * 3 + 1]; qz[p] = q[j * 3 + 2]; }
     best[p] = INFINITY; // the reference accepts element 0 unconditionally ("k==0 ||")
     bi[p] = 0;
   }
+  constexpr int SUB = CH_TILE / 4; // targets of a tile per wave
   for (int t0 = 0; t0 < nt; t0 += CH_TILE) {
     const int tn = min(CH_TILE, nt - t0);
     __syncthreads();
@@ -54,8 +63,9 @@ __global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float *__restric
       tile[k] = make_float4(t[(size_t)(t0 + k) * 3], t[(size_t)(t0 + k) * 3 + 1],
                             t[(size_t)(t0 + k) * 3 + 2], 0.f);
     __syncthreads();
+    const int k1 = min(tn, (wave + 1) * SUB);
 #pragma unroll 4
-    for (int k = 0; k < tn; ++k) {
+    for (int k = wave * SUB; k < k1; ++k) {
       const float4 v = tile[k];
 #pragma unroll
       for (int p = 0; p < CH_QPL; ++p) {
@@ -65,10 +75,27 @@ __global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float *__restric
       }
     }
   }
+  // merge the four waves' candidates of each query
+  __syncthreads(); // the last tile is no longer read: its memory carries the candidates
+  float *sd = reinterpret_cast<float *>(tile);                 // [4][CH_QPB]
+  int *si = reinterpret_cast<int *>(tile) + 4 * CH_QPB;        // [4][CH_QPB]
 #pragma unroll
   for (int p = 0; p < CH_QPL; ++p) {
-    const int j = (blockIdx.x * CH_QPL + p) * 256 + tid;
-    if (j < nq) { dout[j] = best[p]; iout[j] = bi[p]; }
+    sd[wave * CH_QPB + p * 64 + lane] = best[p];
+    si[wave * CH_QPB + p * 64 + lane] = bi[p];
+  }
+  __syncthreads();
+  for (int qq = tid; qq < CH_QPB; qq += 256) {
+    float d = sd[qq];
+    int i = si[qq];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float dw = sd[w * CH_QPB + qq];
+      const int iw = si[w * CH_QPB + qq];
+      if (dw < d || (dw == d && iw < i)) { d = dw; i = iw; }
+    }
+    const int j = blockIdx.x * CH_QPB + qq;
+    if (j < nq) { dout[j] = d; iout[j] = i; }
   }
 }
 
@@ -117,7 +144,7 @@ int lion_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int
   if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2 || B <= 0 || N <= 0 || M <= 0)
     return LION_EINVAL;
   const int nmax = N > M ? N : M;
-  chamfer_fwd_kernel<<<dim3(lion_cdiv(nmax, 256 * CH_QPL), B, 2), 256, 0,
+  chamfer_fwd_kernel<<<dim3(lion_cdiv(nmax, CH_QPB), B, 2), 256, 0,
                        static_cast<hipStream_t>(stream)>>>(xyz1, xyz2, N, M, dist1, dist2, idx1,
                                                            idx2);
   LION_LAUNCH_CHECK();

@@ -6,8 +6,8 @@
 //
 // MI355X design: the three passes of a level are separate launches with grid = (row tiles, batch)
 // so a batch of pairs fills the chip instead of 32 blocks; per row the loop over the other cloud
-// is in ascending index order exactly like the reference's, so each remainL/ratioL/remainR/ratioR
-// value is the same sequential float sum.  The other cloud is staged in LDS as float4 {x,y,z,w}
+// runs in ascending index order inside each of four fixed quarters of a tile (one per wave), the
+// four partial sums added in a fixed order (round 4; a single sequential chain before).  The other cloud is staged in LDS as float4 {x,y,z,w}
 // tiles (w = remainR / ratioL / ratioR) and read as broadcasts.  exp() is the hardware v_exp_f32
 // path (__expf), the same class of approximation as the reference's CUDA __expf.
 #include "common.h"
@@ -29,6 +29,21 @@ __global__ void emd_init_kernel(int n, int m, float multiL, float multiR, float 
   if (i < m) remainR[(size_t)b * m + i] = multiR;
 }
 
+// Round 4: the four waves of a workgroup share 64 rows (one per lane) and each scans its own quarter of every tile of the
+// other cloud; the four partial sums of a row are added in the fixed order ((w0 + w1) + w2) + w3.  With one row per thread
+// and whole tiles per wave (rounds 1-3) B = 32 pairs of 2048 points were 256 workgroups = ONE wave per SIMD, which waited
+// out its own LDS round trips and exp latencies (97 cycles per evaluation against ~34 of issue).  The sums are no longer
+// the reference's single sequential chain: they differ from it by fp32 rounding (1e-7 relative), far inside the tolerance
+// v_exp_f32 already imposes on this operator (tests: cost 1e-4, match 2e-3), and they do not depend on the batch size.
+constexpr int EMD_ROWS = 64;           // rows per workgroup
+constexpr int EMD_SUB = EMD_TILE / 4;  // elements of a tile per wave
+
+#define EMD_MERGE(red_, wave_, lane_, v_)        \
+  __syncthreads();                               \
+  red_[wave_ * EMD_ROWS + lane_] = v_;           \
+  __syncthreads();                               \
+  v_ = add_rn(add_rn(add_rn(red_[lane_], red_[EMD_ROWS + lane_]), red_[2 * EMD_ROWS + lane_]), red_[3 * EMD_ROWS + lane_]);
+
 // pass 1 (emd_kernel.cu:50-81): ratioL[k] = remainL[k] / (1e-9 + sum_l exp(level*d) * remainR[l])
 __global__ __launch_bounds__(256) void emd_pass1_kernel(const float *__restrict__ xyz1,
                                                         const float *__restrict__ xyz2, int n, int m,
@@ -37,11 +52,12 @@ __global__ __launch_bounds__(256) void emd_pass1_kernel(const float *__restrict_
                                                         const float *__restrict__ remainR,
                                                         float *__restrict__ ratioL) {
   __shared__ float4 tile[EMD_TILE];
-  const int tid = threadIdx.x, b = blockIdx.y, k = blockIdx.x * 256 + tid;
+  __shared__ float red[4 * EMD_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, k = blockIdx.x * EMD_ROWS + lane;
   const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
   float x1 = 0, y1 = 0, z1 = 0;
   if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
-  float suml = 1e-9f;
+  float suml = wave == 0 ? 1e-9f : 0.f;
   for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
     const int ln = min(EMD_TILE, m - l0);
     __syncthreads();
@@ -49,14 +65,16 @@ __global__ __launch_bounds__(256) void emd_pass1_kernel(const float *__restrict_
       tile[l] = make_float4(p2[(size_t)(l0 + l) * 3], p2[(size_t)(l0 + l) * 3 + 1],
                             p2[(size_t)(l0 + l) * 3 + 2], remainR[(size_t)b * m + l0 + l]);
     __syncthreads();
-#pragma unroll 4
-    for (int l = 0; l < ln; ++l) {
+    const int l1 = min(ln, (wave + 1) * EMD_SUB);
+#pragma unroll 8
+    for (int l = wave * EMD_SUB; l < l1; ++l) {
       const float4 v = tile[l];
       const float w = mul_rn(__expf(lvl_d(level, v.x, v.y, v.z, x1, y1, z1)), v.w);
       suml = add_rn(suml, w);
     }
   }
-  if (k < n) ratioL[(size_t)b * n + k] = div_rn(remainL[(size_t)b * n + k], suml);
+  EMD_MERGE(red, wave, lane, suml)
+  if (wave == 0 && k < n) ratioL[(size_t)b * n + k] = div_rn(remainL[(size_t)b * n + k], suml);
 }
 
 // pass 2 (emd_kernel.cu:83-117)
@@ -67,7 +85,8 @@ __global__ __launch_bounds__(256) void emd_pass2_kernel(const float *__restrict_
                                                         float *__restrict__ remainR,
                                                         float *__restrict__ ratioR) {
   __shared__ float4 tile[EMD_TILE];
-  const int tid = threadIdx.x, b = blockIdx.y, l = blockIdx.x * 256 + tid;
+  __shared__ float red[4 * EMD_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, l = blockIdx.x * EMD_ROWS + lane;
   const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
   float x2 = 0, y2 = 0, z2 = 0;
   if (l < m) { x2 = p2[l * 3]; y2 = p2[l * 3 + 1]; z2 = p2[l * 3 + 2]; }
@@ -79,14 +98,16 @@ __global__ __launch_bounds__(256) void emd_pass2_kernel(const float *__restrict_
       tile[k] = make_float4(p1[(size_t)(k0 + k) * 3], p1[(size_t)(k0 + k) * 3 + 1],
                             p1[(size_t)(k0 + k) * 3 + 2], ratioL[(size_t)b * n + k0 + k]);
     __syncthreads();
-#pragma unroll 4
-    for (int k = 0; k < kn; ++k) {
+    const int k1 = min(kn, (wave + 1) * EMD_SUB);
+#pragma unroll 8
+    for (int k = wave * EMD_SUB; k < k1; ++k) {
       const float4 v = tile[k];
       const float w = mul_rn(__expf(lvl_d(level, x2, y2, z2, v.x, v.y, v.z)), v.w);
       sumr = add_rn(sumr, w);
     }
   }
-  if (l < m) {
+  EMD_MERGE(red, wave, lane, sumr)
+  if (wave == 0 && l < m) {
     const float rr = remainR[(size_t)b * m + l];
     sumr = mul_rn(sumr, rr);
     const float consumption = fminf(div_rn(rr, add_rn(sumr, 1e-9f)), 1.0f);
@@ -105,7 +126,8 @@ __global__ __launch_bounds__(256) void emd_pass3_kernel(const float *__restrict_
                                                         float *__restrict__ remainL,
                                                         float *__restrict__ match) {
   __shared__ float4 tile[EMD_TILE];
-  const int tid = threadIdx.x, b = blockIdx.y, k = blockIdx.x * 256 + tid;
+  __shared__ float red[4 * EMD_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, k = blockIdx.x * EMD_ROWS + lane;
   const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
   float x1 = 0, y1 = 0, z1 = 0, rl = 0;
   if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; rl = ratioL[(size_t)b * n + k]; }
@@ -119,8 +141,9 @@ __global__ __launch_bounds__(256) void emd_pass3_kernel(const float *__restrict_
                             p2[(size_t)(l0 + l) * 3 + 2], ratioR[(size_t)b * m + l0 + l]);
     __syncthreads();
     if (k < n) {
+      const int l1 = min(ln, (wave + 1) * EMD_SUB);
 #pragma unroll 4
-      for (int l = 0; l < ln; ++l) {
+      for (int l = wave * EMD_SUB; l < l1; ++l) {
         const float4 v = tile[l];
         const float w = mul_rn(mul_rn(__expf(lvl_d(level, v.x, v.y, v.z, x1, y1, z1)), rl), v.w);
         float *dst = mt + (size_t)(l0 + l) * n + k;
@@ -130,13 +153,14 @@ __global__ __launch_bounds__(256) void emd_pass3_kernel(const float *__restrict_
       }
     }
   }
-  if (k < n) remainL[(size_t)b * n + k] = fmaxf(0.0f, sub_rn(remainL[(size_t)b * n + k], suml));
+  EMD_MERGE(red, wave, lane, suml)
+  if (wave == 0 && k < n) remainL[(size_t)b * n + k] = fmaxf(0.0f, sub_rn(remainL[(size_t)b * n + k], suml));
 }
 
 // pass 3 without the match matrix (evaluation path, emd_nograd.py:19-44 only needs the cost): the reference builds
 // match[b][l][k] (16.8 MB per pair at 2048^2, read and rewritten at each of the 10 levels) and then sums
 // match * d^2; the sum over levels commutes with that product, so row k accumulates sum_l w * d^2 on the fly
-// (ascending l, levels in order) and nothing of size N*M ever reaches memory.
+// (levels in order) and nothing of size N*M ever reaches memory.
 template <bool FIRST>
 __global__ __launch_bounds__(256) void emd_pass3_cost_kernel(const float *__restrict__ xyz1,
                                                              const float *__restrict__ xyz2, int n, int m,
@@ -145,7 +169,8 @@ __global__ __launch_bounds__(256) void emd_pass3_cost_kernel(const float *__rest
                                                              float *__restrict__ remainL,
                                                              float *__restrict__ costrow) {
   __shared__ float4 tile[EMD_TILE];
-  const int tid = threadIdx.x, b = blockIdx.y, k = blockIdx.x * 256 + tid;
+  __shared__ float red[4 * EMD_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, k = blockIdx.x * EMD_ROWS + lane;
   const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
   float x1 = 0, y1 = 0, z1 = 0, rl = 0;
   if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; rl = ratioL[(size_t)b * n + k]; }
@@ -157,8 +182,9 @@ __global__ __launch_bounds__(256) void emd_pass3_cost_kernel(const float *__rest
       tile[l] = make_float4(p2[(size_t)(l0 + l) * 3], p2[(size_t)(l0 + l) * 3 + 1],
                             p2[(size_t)(l0 + l) * 3 + 2], ratioR[(size_t)b * m + l0 + l]);
     __syncthreads();
-#pragma unroll 4
-    for (int l = 0; l < ln; ++l) {
+    const int l1 = min(ln, (wave + 1) * EMD_SUB);
+#pragma unroll 8
+    for (int l = wave * EMD_SUB; l < l1; ++l) {
       const float4 v = tile[l];
       const float d2 = sqdist3(v.x, v.y, v.z, x1, y1, z1);
       const float w = mul_rn(mul_rn(__expf(mul_rn(level, d2)), rl), v.w);
@@ -166,7 +192,9 @@ __global__ __launch_bounds__(256) void emd_pass3_cost_kernel(const float *__rest
       crow = add_rn(crow, mul_rn(d2, w));
     }
   }
-  if (k < n) {
+  EMD_MERGE(red, wave, lane, suml)
+  EMD_MERGE(red, wave, lane, crow)
+  if (wave == 0 && k < n) {
     remainL[(size_t)b * n + k] = fmaxf(0.0f, sub_rn(remainL[(size_t)b * n + k], suml));
     costrow[(size_t)b * n + k] = FIRST ? crow : add_rn(costrow[(size_t)b * n + k], crow);
   }
@@ -329,7 +357,7 @@ int lion_emd_approxmatch(const float *xyz1, const float *xyz2, int B, int N, int
   else { multiL = (float)(M / N); multiR = 1.f; }
   const int nmax = N > M ? N : M;
   emd_init_kernel<<<dim3(lion_cdiv(nmax, 256), B), 256, 0, st>>>(N, M, multiL, multiR, remainL, remainR);
-  const dim3 gn(lion_cdiv(N, 256), B), gm(lion_cdiv(M, 256), B);
+  const dim3 gn(lion_cdiv(N, EMD_ROWS), B), gm(lion_cdiv(M, EMD_ROWS), B);
   for (int j = 7; j >= -2; --j) {
     float level = -powf(4.0f, (float)j); // :45-48
     if (j == -2) level = 0.f;
@@ -360,7 +388,7 @@ int lion_emd_cost(const float *xyz1, const float *xyz2, int B, int N, int M, flo
   else { multiL = (float)(M / N); multiR = 1.f; }
   const int nmax = N > M ? N : M;
   emd_init_kernel<<<dim3(lion_cdiv(nmax, 256), B), 256, 0, st>>>(N, M, multiL, multiR, remainL, remainR);
-  const dim3 gn(lion_cdiv(N, 256), B), gm(lion_cdiv(M, 256), B);
+  const dim3 gn(lion_cdiv(N, EMD_ROWS), B), gm(lion_cdiv(M, EMD_ROWS), B);
   for (int j = 7; j >= -2; --j) {
     float level = -powf(4.0f, (float)j); // :45-48
     if (j == -2) level = 0.f;
