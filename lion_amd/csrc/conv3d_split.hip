@@ -89,6 +89,10 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   for (int iter = 0;; ++iter) {
   int b, tile, co0;
   if (queued) { // see csrc/conv3d.hip: occ = [B*tiles wave masks][B*tiles list, occupied tiles first][queue counter]
+    // (round 4: dealing the list round-robin to the resident workgroups instead -- no atomic, no dependent index load in
+    // front of an item -- was measured and LOSES on every sparse launch: conv1 Gaussian clouds 395 -> 440 us, r = 16 flat
+    // delta 171 -> 225 us, sampling step 6.82 -> 7.26 ms; dense 654 -> 648 us.  Items differ too much in cost -- wave
+    // masks, empty tiles -- for a static deal; the queue's round trip is not what the in-step forms pay over the plain kernel.)
     __syncthreads();
     if (tid == 0) s_work = atomicAdd(occ + 2 * B * ntiles, 1);
     __syncthreads();
