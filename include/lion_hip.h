@@ -290,6 +290,15 @@ int lion_pwconv_pack_weights(const float *w, int Cout, int Cin, float *wp, lionS
 int lion_pwconv_stat_tiles(int Cout, int Cin, int L);
 int lion_pwconv_forward(const float *x, const float *wp, const float *bias, int B, int Cin, int Cout, int L,
                         const float *pro_a, const float *pro_b, float *y, float *stats, lionStream_t stream);
+/* The LAST layer of a set-abstraction MLP without its output (pvcnn2_ada.py:120-164 + :375-377: conv -> AdaGN -> Swish
+ * -> max over the U = 32 neighbours of a centre; x f32[B,Cin,M*32]): call once with out_a == NULL -- only the GroupNorm
+ * sums are written (stats as lion_pwconv_forward) --, fold them (lion_groupnorm_fold), call again with out_a / out_b
+ * f32[B,Cout] = this layer's AdaGN scalars and ymax f32[B,Cout,M]: max_u swish(y*a+b), bit-identical to
+ * lion_pwconv_forward + lion_affine_swish_max, while y (268 MB in the first set-abstraction module) is never stored.
+ * LION_EUNSUPPORTED outside the large-activation tiling (L % 32 != 0, L <= 4096, small grids). */
+int lion_pwconv_forward_max(const float *x, const float *wp, const float *bias, int B, int Cin, int Cout, int L,
+                            const float *pro_a, const float *pro_b, const float *out_a, const float *out_b,
+                            float *stats, float *ymax, lionStream_t stream);
 /* G1 on the 16-bit matrix pipe at fp32 accuracy (csrc/pwconv_split.hip): same contract as lion_pwconv_forward with both
  * operands cut into fp16 hi / lo pieces (power-of-two block scaling per tensor for w, per column and 16-channel chunk for
  * the activation, fp32 accumulation; error within that of the fp32 MFMA chain).  w f32[Cout,Cin] -> wp once per weight

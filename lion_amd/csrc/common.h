@@ -99,6 +99,8 @@ __device__ __forceinline__ unsigned wave_max_u32_lane63(unsigned v) {
 __device__ __forceinline__ float row_pair_sum_odd_rows(float v) {
   return __fadd_rn(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true)));
 }
+#define LION_DPP_F32_ROWS(x, ctrl, rmask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, true))
 __device__ __forceinline__ float row16_max(float v) {
   float o;
   o = LION_DPP_F32(v, 0xB1); v = o > v ? o : v;

@@ -26,12 +26,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // workgroup is repaid only by many column tiles; with a handful of tiles it is pure latency, and a workgroup that needs
 // most of a CU's LDS cannot start beside the voxelize / devoxelize / convolution workgroups of the main stream (the
 // point branch of a PVConv runs on a side stream, in their shadow).
-template <int CB, int VB, bool PRO, bool STATS, bool WLDS>
+// OUT (round 4): 0 = store y; 1 = GroupNorm sums only, y is NOT stored; 2 = y is not stored either: this layer's own
+// AdaGN + Swish (out_a / out_b f32[B, CoutY]) is applied to the accumulators and the maximum over each block of 32
+// consecutive columns -- the 32 neighbours of a set-abstraction centre, reference pvcnn2_ada.py:375-377 -- goes to
+// ymax f32[B, CoutY, L / 32] (passed as y).  The last layer of a set-abstraction MLP is evaluated twice this way (sums,
+// fold, then activated maximum) and its [B, 64, 1024, 32] = 268 MB output never exists: 134 MB read twice instead of
+// 134 MB read + 268 MB written + 268 MB read.
+template <int CB, int VB, bool PRO, bool STATS, bool WLDS, int OUT = 0>
 __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict__ x, const float *__restrict__ wp,
                                                         const float *__restrict__ bias, float *__restrict__ y,
                                                         int Cin, int Cout, int CoutY, int L,
                                                         const float *__restrict__ pro_a,
-                                                        const float *__restrict__ pro_b, float *__restrict__ stats) {
+                                                        const float *__restrict__ pro_b, float *__restrict__ stats,
+                                                        const float *__restrict__ out_a = nullptr,
+                                                        const float *__restrict__ out_b = nullptr) {
   // Cout: channels of the packed weights (a multiple of 32, zero rows beyond CoutY); CoutY: channels of y / bias / stats
   constexpr int COUT = CB * 32; // output channels of this workgroup: [co0, co0 + COUT)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -54,6 +62,14 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
     for (int c = tid; c < Cin; c += 256) { spa[c] = pro_a[(size_t)b * Cin + c]; spb[c] = pro_b[(size_t)b * Cin + c]; }
   }
   for (int c = tid; c < COUT; c += 256) sbias[c] = (bias && co0 + c < CoutY) ? bias[co0 + c] : 0.f;
+  float *soa = sbias + COUT, *sob = soa + COUT; // [COUT] each: this layer's own AdaGN scalars (OUT == 2)
+  if (OUT == 2) {
+    for (int c = tid; c < COUT; c += 256) {
+      const bool ok = co0 + c < CoutY;
+      soa[c] = ok ? out_a[(size_t)b * CoutY + co0 + c] : 0.f;
+      sob[c] = ok ? out_b[(size_t)b * CoutY + co0 + c] : 0.f;
+    }
+  }
   __syncthreads();
   const int col0 = (blockIdx.x * 4 + wave) * VB * 32;
   int col[VB];
@@ -85,27 +101,41 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
 #pragma unroll
       for (int vb = 0; vb < VB; ++vb) bv[u][vb] = xb[(size_t)kc * L + col[vb]];
     }
+    // Round 4: the prologue of the WHOLE group first, the MFMAs afterwards.  Interleaved per operand (rounds 1-3) every
+    // pair of MFMAs sat behind its own dependent chain -- LDS read of the scalars, fma, v_exp, v_rcp, mul, select (the
+    // ISA: `ds_read x2, wait, v, wait, v v exp v rcp v v, MFMA MFMA` per (k-step, column block)) -- and the matrix pipe
+    // ran at ~40 % of its rate inside a wave: SA-0 layer 2 took 108 us without storing a byte, 4x its MFMA time.  As one
+    // batch the 64 chains are independent and pipeline; the MFMA sweep that follows is back to back.
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k = 2 * (s0 + u) + kh;
+      const bool kok = k < Cin; // odd Cin: zero operand (the packed weights are zero there too)
+      if (PRO) {
+        const int kc = min(k, Cin - 1);
+        const float pa_ = spa[kc], pb_ = spb[kc];
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) bv[u][vb] = swish_fast(bv[u][vb] * pa_ + pb_);
+      }
+#pragma unroll
+      for (int vb = 0; vb < VB; ++vb) {
+        bv[u][vb] = (kok && cok[vb]) ? bv[u][vb] : 0.f;
+        asm volatile("" : "+v"(bv[u][vb])); // materialised HERE: left alone the compiler sinks each chain back in front of its MFMAs
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       if (s0 + u < ksteps) { // uniform
         const int k = 2 * (s0 + u) + kh;
-        const bool kok = k < Cin; // odd Cin: zero operand (the packed weights are zero there too)
         float av[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
           av[cb] = WLDS ? sw[k * COUT + cb * 32 + cl] : wp[(size_t)k * Cout + co0 + cb * 32 + cl]; // rows exist to ceil2(Cin)
 #pragma unroll
         for (int vb = 0; vb < VB; ++vb) {
-          float v = bv[u][vb];
-          if (PRO) {
-            const int kc = min(k, Cin - 1);
-            const float t = v * spa[kc] + spb[kc];
-            v = swish_fast(t);
-          }
-          v = (kok && cok[vb]) ? v : 0.f;
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
-            acc[cb][vb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], v, acc[cb][vb], 0, 0, 0);
+            acc[cb][vb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[u][vb], acc[cb][vb], 0, 0, 0);
         }
       }
     }
@@ -114,6 +144,27 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
   // epilogue: + bias, [B, Cout, L] store.  acc register i of lane l: channel row (i&3) + 8*(i>>2) + 4*(l>>5),
   // column l&31 -> 32 consecutive columns per (register, half-wave).
   float *yb = y + ((size_t)b * CoutY + co0) * L;
+  if (OUT == 2) {
+    const int M = L >> 5; // centres: blocks of 32 columns (the launcher guarantees L % 32 == 0)
+    float *ym = y + ((size_t)b * CoutY + co0) * M;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+        const bool rok = co0 + co < CoutY;
+        const float bz = sbias[co], a2 = soa[co], b2 = sob[co];
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) {
+          float v = swish_fast((acc[cb][vb][i] + bz) * a2 + b2); // == affine_swish_max on the stored y, bit for bit
+          v = row16_max(v);                                       // max over the 32 columns of this half-wave:
+          v = fmaxf(v, LION_DPP_F32_ROWS(v, 0x142, 0xa));         // rows 1 / 3 take lane 15 of rows 0 / 2
+          const int m = (col0 + vb * 32) >> 5;
+          if (cl == 16 && rok && m < M) ym[(size_t)co * M + m] = v;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -125,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_kernel(const float *__restrict_
       for (int vb = 0; vb < VB; ++vb) {
         const float o = acc[cb][vb][i] + bz;
         acc[cb][vb][i] = cok[vb] ? o : 0.f;
-        if (cok[vb] && rok) yb[(size_t)co * L + col[vb]] = o;
+        if (OUT == 0 && cok[vb] && rok) yb[(size_t)co * L + col[vb]] = o;
       }
     }
   if (STATS) {
@@ -303,7 +354,7 @@ static int pw_pad(int Cout) { return (Cout + 31) / 32 * 32; }     // channel row
 static int pw_stride(int Cout) { return (Cout + 63) / 64 * 64; }  // row stride of the packed copy (zero columns beyond Cout)
 static size_t pw_lds(int cb, int Cin, bool pro, bool wlds = true) {
   const int ksteps = (Cin + 1) / 2;
-  return ((size_t)(wlds ? 2 * ksteps * cb * 32 : 0) + (pro ? 2 * Cin : 0) + 4 * cb * 32 * 2 + cb * 32) * 4;
+  return ((size_t)(wlds ? 2 * ksteps * cb * 32 : 0) + (pro ? 2 * Cin : 0) + 4 * cb * 32 * 2 + 3 * cb * 32) * 4;
 }
 constexpr size_t PW_LDS_MAX = 150 * 1024;
 // Cout: any; the channel tile is the largest of 256 / 128 / 64 / 32 rows that divides ceil32(Cout) and whose weight slice
@@ -346,9 +397,57 @@ static int launch_pw(const float *x, const float *wp, const float *bias, float *
   return 0;
 }
 
+// the two passes of the "activated maximum without the layer's output" form (OUT = 1, OUT = 2): large activations only
+// (weights through LDS), same tiling and the same column tiles of the statistics as launch_pw
+template <int CB, int VB>
+static int launch_pw_max(const float *x, const float *wp, const float *bias, float *ymax, int B, int Cin, int Cout, int L,
+                         const float *pa, const float *pb, float *stats, const float *oa, const float *ob, hipStream_t st) {
+  const int Cpad = pw_pad(Cout);
+  const dim3 grid(lion_cdiv(L, 4 * VB * 32), Cpad / (CB * 32), B);
+  if ((long)grid.x * B < 2048) return LION_EUNSUPPORTED;
+  const size_t lds = pw_lds(CB, Cin, pa != nullptr, true);
+#define LION_PWM_GO(PRO_, ST_, OUT_)                                                                      \
+  {                                                                                                        \
+    static LionLdsLimit cfg = {};                                                                          \
+    if (int e = lion_dynamic_lds(&pwconv_kernel<CB, VB, PRO_, ST_, true, OUT_>, lds, cfg)) return e;       \
+    pwconv_kernel<CB, VB, PRO_, ST_, true, OUT_><<<grid, 256, lds, st>>>(x, wp, bias, ymax, Cin, pw_stride(Cout), Cout, L, pa, pb, stats, oa, ob); \
+  }
+  if (oa) {
+    if (pa) LION_PWM_GO(true, false, 2) else LION_PWM_GO(false, false, 2)
+  } else {
+    if (pa) LION_PWM_GO(true, true, 1) else LION_PWM_GO(false, true, 1)
+  }
+#undef LION_PWM_GO
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
 } // namespace
 
 extern "C" {
+
+// The last layer of a set-abstraction MLP without its output (pvcnn2_ada.py:120-164 + :375-377: conv -> AdaGN -> Swish ->
+// max over the 32 neighbours): call once with out_a == NULL (GroupNorm sums into stats, nothing else written), fold
+// (lion_groupnorm_fold), call again with out_a / out_b f32[B,Cout] = this layer's AdaGN scalars and ymax f32[B,Cout,L/32].
+// Same arguments otherwise as lion_pwconv_forward; L % 32 == 0, L > 4096, large grids only (LION_EUNSUPPORTED otherwise:
+// the caller then stores y and runs lion_affine_swish_max).  Bit-identical to that three-kernel path.
+int lion_pwconv_forward_max(const float *x, const float *wp, const float *bias, int B, int Cin, int Cout, int L,
+                            const float *pro_a, const float *pro_b, const float *out_a, const float *out_b, float *stats,
+                            float *ymax, lionStream_t stream) {
+  if (!x || !wp || B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0) return LION_EINVAL;
+  if ((pro_a == nullptr) != (pro_b == nullptr) || (out_a == nullptr) != (out_b == nullptr)) return LION_EINVAL;
+  if (out_a ? !ymax : !stats) return LION_EINVAL;
+  if (L % 32 != 0 || L <= PW_SMALL_L) return LION_EUNSUPPORTED;
+  const PwPlan p = pw_plan(Cout, Cin);
+  if (!p.cb) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (p.cb) {
+  case 1: return launch_pw_max<1, 4>(x, wp, bias, ymax, B, Cin, Cout, L, pro_a, pro_b, stats, out_a, out_b, st);
+  case 2: return launch_pw_max<2, 4>(x, wp, bias, ymax, B, Cin, Cout, L, pro_a, pro_b, stats, out_a, out_b, st);
+  case 4: return launch_pw_max<4, 2>(x, wp, bias, ymax, B, Cin, Cout, L, pro_a, pro_b, stats, out_a, out_b, st);
+  default: return launch_pw_max<8, 1>(x, wp, bias, ymax, B, Cin, Cout, L, pro_a, pro_b, stats, out_a, out_b, st);
+  }
+}
 
 size_t lion_pwconv_packed_floats(int Cout, int Cin) { return (size_t)((Cin + 1) / 2 * 2) * pw_stride(Cout); }
 

@@ -249,6 +249,47 @@ def pwconv_fused(x, conv, pro=None, want_stats=True, split=None):
     return y, stats
 
 
+# The last layer of a set-abstraction MLP evaluated twice (sums, then activated maximum) instead of stored (round 4) --
+# built, bit-identical (tests/test_fold_se_gpu.py), and NOT faster: SA-0 layer 2 (32 -> 64 over 1 M columns) takes 100 us per
+# pass without storing a byte against 121 us with its 268 MB output + 42 us for the max pass (208 vs 163 us; the sampling
+# step is unchanged within noise).  The layer is not bound by its bytes: one wave = 64 loads, one wait, 128 MFMAs, with two
+# workgroups per CU to overlap those phases.  Off by default; LION_PW_MAX_RECOMPUTE=1 selects it (saves the 268 MB tensor).
+MAX_RECOMPUTE = __import__("os").environ.get("LION_PW_MAX_RECOMPUTE", "0") != "0"
+
+
+def pwconv_max_recompute(x, conv, gn, style, pro):
+    """max over the 32 neighbours of swish(AdaGN(conv(act(x)))) for x [B, Cin, M, 32] -> [B, Cout, M] without storing the
+    conv's output: pass 1 = GroupNorm sums only, fold, pass 2 = the same GEMM with this layer's AdaGN + Swish and the max in
+    the epilogue (lion_pwconv_forward_max).  None when the shape is outside that kernel's range."""
+    lib = _lib.load()
+    x = x.contiguous()
+    b, cin, m, u = x.shape
+    L = m * u
+    cout = conv.out_channels
+    wp = pw_packed_weight(conv.weight)
+    tiles = lib.lion_pwconv_stat_tiles(cout, cin, L)
+    if tiles <= 0:
+        return None
+    stats = torch.empty((b, cout, tiles, 2), device=x.device, dtype=torch.float32)
+    pa = pb = None
+    if pro is not None:
+        pa, pb = pro[0].contiguous(), pro[1].contiguous()
+    bias = conv.bias.detach().contiguous() if conv.bias is not None else None
+    st = _lib.stream_ptr(x.device)
+    rc = lib.lion_pwconv_forward_max(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), b, cin, cout, L, _lib.ptr(pa), _lib.ptr(pb),
+                                     None, None, _lib.ptr(stats), None, st)
+    if rc == -2:   # LION_EUNSUPPORTED: the caller takes the stored-output path
+        return None
+    _lib.check(rc, "pwconv_forward_max (sums)")
+    f, g = gn.affine(style)
+    A, Bs, _ = groupnorm_fold(stats, gn.norm, f, g, L)
+    y = torch.empty((b, cout, m), device=x.device, dtype=torch.float32)
+    _lib.check(lib.lion_pwconv_forward_max(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), b, cin, cout, L, _lib.ptr(pa),
+                                           _lib.ptr(pb), _lib.ptr(A), _lib.ptr(Bs), None, _lib.ptr(y), st),
+               "pwconv_forward_max (max)")
+    return y
+
+
 def pwconv_raw(x, w2d, bias=None, cached_param=None):
     """y[b] = w2d @ x[b] (+ bias) on the library's 1x1-convolution kernels for a plain [Cout, Cin] matrix; None when
     the shape is not supported.  cached_param: the nn.Parameter w2d is a view of (its packed form is cached per
@@ -371,7 +412,13 @@ def shared_mlp(x, convs, adagns, style, reduce_max=False, add=None):
     apply pass (optionally with the max over the neighbourhood)."""
     lib = _lib.load()
     pro = None
-    for conv, gn in zip(convs, adagns):
+    for li, (conv, gn) in enumerate(zip(convs, adagns)):
+        if (MAX_RECOMPUTE and reduce_max and add is None and li == len(convs) - 1 and x.dim() == 4 and x.shape[3] == 32
+                and pw_supported(conv, x)
+                and not pw_use_split(None, x.shape[0], x.shape[1], conv.out_channels, x[0, 0].numel())):
+            out = pwconv_max_recompute(x, conv, gn, style, pro)
+            if out is not None:
+                return out
         if pw_supported(conv, x):
             x, st = pwconv_fused(x, conv, pro)
         else:
