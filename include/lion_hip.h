@@ -363,6 +363,12 @@ int lion_pwconv_wgrad(const float *x, const float *gy, int B, int Cin, int Cout,
 int lion_gn_train_fold(const float *stats, const float *gw, const float *gb, const float *fac, int fac_stride,
                        const float *bias, int bias_stride, int B, int C, int G, int L, float eps, float *A, float *Bs,
                        float *mean, float *rstd, lionStream_t stream);
+/* the same with the row sums taken on shifted values and carried in double (|mean| >> std rows keep their variance):
+ * what lion_amd/train_ops.py uses */
+int lion_row_stats64(const float *x, int rows, int L, double *stats, lionStream_t stream);
+int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, const float *fac, int fac_stride,
+                         const float *bias, int bias_stride, int B, int C, int G, int L, float eps, float *A,
+                         float *Bs, float *mean, float *rstd, lionStream_t stream);
 int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
                            const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
                            float *dbias, float *pw, lionStream_t stream);

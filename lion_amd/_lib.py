@@ -88,6 +88,8 @@ SIGNATURES = {
     "lion_pwconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "lion_pwconv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "lion_gn_train_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "lion_row_stats64": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lion_gn_train_fold64": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "lion_gn_train_bwd_fold": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_affine_act": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -26,17 +26,51 @@ __device__ __forceinline__ float act_d(float a, int act) {
 __global__ __launch_bounds__(256) void affine_act_kernel(const float *__restrict__ x, const float *__restrict__ A,
                                                          const float *__restrict__ Bs, int L, int act,
                                                          float *__restrict__ y) {
-  const int row = blockIdx.y;
+  const int bpr = (((L + 3) >> 2) + 255) >> 8; // workgroups per row: the row index rides on blockIdx.x (B C > 65535 rows exist)
+  const int row = blockIdx.x / bpr;
   const float a = A[row], b = Bs[row];
   const float *p = x + (size_t)row * L;
   float *q = y + (size_t)row * L;
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int i = ((blockIdx.x - row * bpr) * 256 + threadIdx.x) * 4;
   if (i + 3 < L && (L & 3) == 0) {
     const float4 v = *reinterpret_cast<const float4 *>(p + i);
     *reinterpret_cast<float4 *>(q + i) = make_float4(act_f(v.x * a + b, act), act_f(v.y * a + b, act),
                                                      act_f(v.z * a + b, act), act_f(v.w * a + b, act));
   } else {
     for (int j = i; j < L && j < i + 4; ++j) q[j] = act_f(p[j] * a + b, act);
+  }
+}
+
+// one workgroup per row: stats[row] = {sum x, sum x^2} as DOUBLES.  The sums run over x - x0 (x0 = the row's first
+// element) in fp32 and are moved back in double: E[x^2] - E[x]^2 from plain fp32 sums loses (mean / std)^2 x 1e-7 of the
+// variance, i.e. everything once |mean| >> std (round-3 advisor finding; ATen's group_norm does not).
+__global__ __launch_bounds__(256) void row_stats64_kernel(const float *__restrict__ x, int L, double *__restrict__ stats) {
+  __shared__ float r1[4], r2[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *p = x + (size_t)row * L;
+  const float x0 = p[0];
+  float s1 = 0.f, s2 = 0.f;
+  if ((L & 3) == 0) {
+    for (int i = tid * 4; i < L; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4 *>(p + i);
+      const float a = v.x - x0, b = v.y - x0, c = v.z - x0, d = v.w - x0;
+      s1 += (a + b) + (c + d);
+      s2 += (a * a + b * b) + (c * c + d * d);
+    }
+  } else {
+    for (int i = tid; i < L; i += 256) { const float v = p[i] - x0; s1 += v; s2 += v * v; }
+  }
+  s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+#pragma unroll
+  for (int m = 16; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (lane == 0) { r1[wave] = s1; r2[wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    const double t1 = ((double)r1[0] + (double)r1[1]) + ((double)r1[2] + (double)r1[3]);
+    const double t2 = ((double)r2[0] + (double)r2[1]) + ((double)r2[2] + (double)r2[3]);
+    const double s = (double)x0, n = (double)L;
+    stats[(size_t)row * 2] = t1 + n * s;                       // sum x
+    stats[(size_t)row * 2 + 1] = t2 + 2.0 * s * t1 + n * s * s; // sum x^2
   }
 }
 
@@ -78,11 +112,12 @@ __global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *
                                                                    const float *__restrict__ Q,
                                                                    const float *__restrict__ R, int L, int act,
                                                                    float *__restrict__ dx) {
-  const int row = blockIdx.y;
+  const int bpr = (((L + 3) >> 2) + 255) >> 8;
+  const int row = blockIdx.x / bpr;
   const float a = A[row], b = Bs[row], qq = Q[row], rr = R[row];
   const float *p = x + (size_t)row * L, *g = gy + (size_t)row * L;
   float *o = dx + (size_t)row * L;
-  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int i = ((blockIdx.x - row * bpr) * 256 + threadIdx.x) * 4;
   if (i + 3 < L && (L & 3) == 0) {
     const float4 v = *reinterpret_cast<const float4 *>(p + i), w = *reinterpret_cast<const float4 *>(g + i);
     *reinterpret_cast<float4 *>(o + i) = make_float4(a * (w.x * act_d(v.x * a + b, act)) + qq + rr * v.x,
@@ -96,7 +131,8 @@ __global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *
 
 // the [B, C] scalar algebra of both directions, one workgroup per sample (C <= 1024 threads), in double
 // forward: stats [B,C,2] (row sums) -> A, Bs, mean, rstd [B,C]
-__global__ void gn_train_fold_kernel(const float *__restrict__ stats, const float *__restrict__ gw,
+template <typename ST>
+__global__ void gn_train_fold_kernel(const ST *__restrict__ stats, const float *__restrict__ gw,
                                      const float *__restrict__ gb, const float *__restrict__ fac, int fs,
                                      const float *__restrict__ bia, int bs, int C, int G, int L, float eps,
                                      float *__restrict__ A, float *__restrict__ Bs, float *__restrict__ mean,
@@ -165,7 +201,28 @@ int lion_gn_train_fold(const float *stats, const float *gw, const float *gb, con
   if (!stats || !gw || !gb || !A || !Bs || !mean || !rstd || B <= 0 || C <= 0 || G <= 0 || C % G || L <= 0) return LION_EINVAL;
   if (C > 1024) return LION_EUNSUPPORTED;
   const int T = (C + 63) / 64 * 64;
-  gn_train_fold_kernel<<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
+  gn_train_fold_kernel<float><<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
+      stats, gw, gb, fac, fac_stride, bias, bias_stride, C, G, L, eps, A, Bs, mean, rstd);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// the training path's statistics: row sums carried out on shifted values and handed over in double (see
+// row_stats64_kernel); lion_gn_train_fold64 = lion_gn_train_fold on those
+int lion_row_stats64(const float *x, int rows, int L, double *stats, lionStream_t stream) {
+  if (!x || !stats || rows <= 0 || L <= 0) return LION_EINVAL;
+  row_stats64_kernel<<<rows, 256, 0, static_cast<hipStream_t>(stream)>>>(x, L, stats);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, const float *fac, int fac_stride,
+                         const float *bias, int bias_stride, int B, int C, int G, int L, float eps, float *A, float *Bs,
+                         float *mean, float *rstd, lionStream_t stream) {
+  if (!stats || !gw || !gb || !A || !Bs || !mean || !rstd || B <= 0 || C <= 0 || G <= 0 || C % G || L <= 0) return LION_EINVAL;
+  if (C > 1024) return LION_EUNSUPPORTED;
+  const int T = (C + 63) / 64 * 64;
+  gn_train_fold_kernel<double><<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
       stats, gw, gb, fac, fac_stride, bias, bias_stride, C, G, L, eps, A, Bs, mean, rstd);
   LION_LAUNCH_CHECK();
   return 0;
@@ -187,7 +244,8 @@ int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd,
 int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
                     lionStream_t stream) {
   if (!x || !A || !Bs || !y || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
-  affine_act_kernel<<<dim3(lion_cdiv(lion_cdiv(L, 4), 256), rows), 256, 0, static_cast<hipStream_t>(stream)>>>(
+  if ((long)rows * lion_cdiv(lion_cdiv(L, 4), 256) > 0x7fffffffL) return LION_EUNSUPPORTED;
+  affine_act_kernel<<<(unsigned)(rows * lion_cdiv(lion_cdiv(L, 4), 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(
       x, A, Bs, L, act, y);
   LION_LAUNCH_CHECK();
   return 0;
@@ -204,7 +262,8 @@ int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, c
 int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
                               const float *R, int rows, int L, int act, float *dx, lionStream_t stream) {
   if (!x || !gy || !A || !Bs || !Q || !R || !dx || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
-  affine_act_bwd_apply_kernel<<<dim3(lion_cdiv(lion_cdiv(L, 4), 256), rows), 256, 0,
+  if ((long)rows * lion_cdiv(lion_cdiv(L, 4), 256) > 0x7fffffffL) return LION_EUNSUPPORTED;
+  affine_act_bwd_apply_kernel<<<(unsigned)(rows * lion_cdiv(lion_cdiv(L, 4), 256)), 256, 0,
                                 static_cast<hipStream_t>(stream)>>>(x, gy, A, Bs, Q, R, L, act, dx);
   LION_LAUNCH_CHECK();
   return 0;

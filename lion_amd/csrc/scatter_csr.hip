@@ -10,7 +10,7 @@
 // channel is a gather-sum over it -- in ascending entry order (the lists are sorted), i.e. deterministic, which the
 // atomics of the reference are not.
 //   build: workgroup (sample, 1 / P of the bins): histogram of the entries that fall into its bin range, scan, fill,
-//          per-bin insertion sort (lists are short);  start / count per bin, entry lists per (sample, range).
+//          every entry ranks itself inside its bin (ascending entry order);  start / count per bin, entry lists per (sample, range).
 //   apply: workgroup = (sample, CT channels): the gy rows streamed into LDS once, thread = bin gathers its entries from
 //          LDS (the entry list is read once per CT channels), gx written coalesced.
 #include "common.h"
@@ -67,9 +67,19 @@ __global__ __launch_bounds__(CSR_NT) void csr_build_kernel(const int32_t *__rest
   }
   __threadfence_block();
   __syncthreads();
-  // ascending entry order inside every bin (insertion sort; the lists hold a handful of entries, a few hundred at most)
+  // Ascending entry order inside every bin.  Short lists (the usual case: a handful of entries) by a thread-per-bin
+  // insertion sort.  Round 4 (advisor finding): that sort is O(c^2) DEPENDENT global steps for a bin of c entries, and ball
+  // query pads empty slots with the first neighbour, so a clustered cloud puts thousands of entries into a few bins --
+  // bins longer than CSR_SHORT are ordered by their ENTRIES instead: each finds its own rank (the number of smaller entry
+  // ids in its bin, 8 list reads in flight), all ranks first, then -- behind a barrier; the list region belongs to this
+  // workgroup -- all writes: O(c) independent reads per entry, entries in parallel.  (Ranking every bin this way costs the
+  // common case: K8 at SA-0 166 -> 218 us.)  Up to CSR_EPT entries per thread stay in registers; larger entry sets keep the
+  // insertion sort for their long bins too.
+  constexpr int CSR_EPT = 32, CSR_SHORT = 32;
+  const bool rank_long = E <= CSR_EPT * CSR_NT;
   for (int v = tid; v < nb; v += CSR_NT) {
     const int c = count[(size_t)b * bins + lo + v], st = start[(size_t)b * bins + lo + v];
+    if (c > CSR_SHORT && rank_long) continue;
     for (int i = 1; i < c; ++i) {
       const int key = pm[st + i];
       int j = i - 1;
@@ -77,6 +87,35 @@ __global__ __launch_bounds__(CSR_NT) void csr_build_kernel(const int32_t *__rest
       pm[st + j + 1] = key;
     }
   }
+  if (!rank_long) return;
+  int slot[CSR_EPT];
+#pragma unroll
+  for (int k = 0; k < CSR_EPT; ++k) {
+    const int e = tid + k * CSR_NT;
+    slot[k] = -1;
+    if (e < E) {
+      const int t = min(max(id[e], 0), bins - 1) - lo;
+      if (t >= 0 && t < nb) {
+        const int c = count[(size_t)b * bins + lo + t], st = start[(size_t)b * bins + lo + t];
+        if (c > CSR_SHORT) {
+          int rank = 0, q = 0;
+          for (; q + 8 <= c; q += 8) {
+            int v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pm[st + q + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rank += (v[j] < e) ? 1 : 0;
+          }
+          for (; q < c; ++q) rank += (pm[st + q] < e) ? 1 : 0;
+          slot[k] = st + rank;
+        }
+      }
+    }
+  }
+  __syncthreads(); // every rank is known: the long lists may be rewritten
+#pragma unroll
+  for (int k = 0; k < CSR_EPT; ++k)
+    if (slot[k] >= 0) pm[slot[k]] = tid + k * CSR_NT;
 }
 
 // apply: a workgroup owns CT channels of a sample; their gy rows are streamed into LDS once (coalesced -- 4-byte gathers from

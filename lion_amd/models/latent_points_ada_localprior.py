@@ -38,6 +38,8 @@ class PVCNN2Prior(PVCNN2Unet):
     def geometry_source(self, x):
         """(set-abstraction modules, coordinates f32[B,3,N]) exactly as forward() derives them from x: what a chain runner
         needs to compute the FPS / ball-query chain of a step ahead of the forward (lion_amd/chain.py, geometry.py)"""
+        if self.mixed_prediction and self.is_active is not None:   # forward() masks first: the geometry must see the same x
+            x = mask_inactive_variables(x, self.is_active)
         pts = x.view(-1, self.num_points, self.num_classes).permute(0, 2, 1).contiguous()
         return self.sa_modules(), pts[:, :self.input_dim, :].contiguous()
 

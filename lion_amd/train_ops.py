@@ -9,6 +9,7 @@ activation gradient; one fused apply) plus one small kernel per direction for th
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -28,6 +29,8 @@ def _rows(t):
 def _rowview(t, B, C):
     """(pointer holder, row stride) of a [B, C] float32 view whose channel stride is 1 (a chunk of the [B, 2C] AdaGN
     projection is such a view) -- anything else is made contiguous"""
+    if t.numel() != B * C:            # a broadcastable [1, C] / [B, 1] factor: materialise the [B, C] it stands for
+        t = t.expand(B, C) if t.dim() == 2 else t.reshape(-1, C).expand(B, C)
     t = t.reshape(B, C)
     if t.dtype != torch.float32 or t.stride(1) != 1:
         t = t.float().contiguous()
@@ -43,15 +46,15 @@ class _AdaGNAct(torch.autograd.Function):
         L = x[0, 0].numel()
         st = _lib.stream_ptr(x.device)
         dev = x.device
-        stats = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
-        _lib.check(lib.lion_row_stats(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats")
+        stats = torch.empty(B * C, 2, device=dev, dtype=torch.float64)   # shifted sums, double hand-over (csrc/norm_train.hip)
+        _lib.check(lib.lion_row_stats64(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats64")
         A, Bs, mean, rstd = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(4))
         gwc, gbc = gw.detach().float().contiguous(), gb.detach().float().contiguous()
         f, fs = _rowview(factor.detach(), B, C) if factor is not None else (None, 0)
         bb, bs = _rowview(bias.detach(), B, C) if bias is not None else (None, 0)
-        _lib.check(lib.lion_gn_train_fold(_lib.ptr(stats), _lib.ptr(gwc), _lib.ptr(gbc), _lib.ptr(f), fs, _lib.ptr(bb), bs,
+        _lib.check(lib.lion_gn_train_fold64(_lib.ptr(stats), _lib.ptr(gwc), _lib.ptr(gbc), _lib.ptr(f), fs, _lib.ptr(bb), bs,
                                           B, C, groups, L, eps, _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(mean), _lib.ptr(rstd),
-                                          st), "gn_train_fold")
+                                            st), "gn_train_fold64")
         y = torch.empty_like(x)
         _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), B * C, L, int(act), _lib.ptr(y), st), "affine_act")
         ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0))
@@ -60,6 +63,7 @@ class _AdaGNAct(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable   # raw kernels: a double backward must raise, not silently treat these gradients as constants
     def backward(ctx, gy):
         lib = _lib.load()
         x, A, Bs, mean, rstd, gwc, gbc, f = ctx.saved_tensors
@@ -87,8 +91,15 @@ class _AdaGNAct(torch.autograd.Function):
         dpw = pw.sum(0)                                                       # [C, 2]: d norm.weight, d norm.bias
         dgw = dpw[:, 0].contiguous() if ctx.needs_input_grad[1] else None
         dgb = dpw[:, 1].contiguous() if ctx.needs_input_grad[2] else None
-        dfac = dfac.reshape(f_shape) if has_f and ctx.needs_input_grad[3] else None
-        dbias = dbias.reshape(b_shape) if has_b and ctx.needs_input_grad[4] else None
+        def back(g, shape):   # the gradient of a broadcast [1, C] / [B, 1] factor is the sum over what it was spread over
+            n = 1
+            for d in shape:
+                n *= int(d)
+            if n == B * C:
+                return g.reshape(shape)
+            return (g.sum(0) if n == C else g.sum(1)).reshape(shape)
+        dfac = back(dfac, f_shape) if has_f and ctx.needs_input_grad[3] else None
+        dbias = back(dbias, b_shape) if has_b and ctx.needs_input_grad[4] else None
         return dx, dgw, dgb, dfac, dbias, None, None, None
 
 
@@ -114,6 +125,7 @@ class _PwConv(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         from . import fused_ops
         x, weight = ctx.saved_tensors

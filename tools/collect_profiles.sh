@@ -4,7 +4,7 @@
 # The driver's command runs UNTRACED first (<tag>_bench_steps20_line.json): rocprofv3 changes how graphs replay (round 2's
 # "9.22 ms" line had been taken under the tracer; untraced the same build gave 11.5), so the traced run of the same command is
 # stored as <tag>_bench_steps20_TRACED_line.json and only serves the per-kernel tables.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD; O=$R/gpurun_out/profiles; mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
 python bench.py > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
@@ -20,25 +20,32 @@ python tools/sparse_conv_bench.py > $O/${TAG}_sparse_conv_bench.txt 2>/dev/null
 python tools/kbench.py > $O/${TAG}_kbench.txt 2>/dev/null
 python tools/victims_beside_conv.py --replays 40 > $O/${TAG}_victims_beside_conv.txt 2>/dev/null
 python tools/pw_bench.py > $O/${TAG}_pw_bench.txt 2>/dev/null
-python tools/fps_under_dma.py > $O/${TAG}_fps_under_dma.txt 2>/dev/null
-./tools/exp/lds_probe > $O/${TAG}_exp_lds_b128_probe.txt 2>/dev/null
+./tools/exp/grid_barrier_probe > $O/${TAG}_grid_barrier_probe.txt 2>/dev/null
+python tools/vox_clump_bench.py --no-traj > $O/${TAG}_vox_clump_bench.txt 2>/dev/null
+python tools/determinism_probe.py 32 5 > $O/${TAG}_determinism_probe.json 2>/dev/null
+timeout 120 python tools/rccl_capture_probe.py > $O/${TAG}_rccl_capture_probe.json 2>/dev/null
 cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
+# HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes) of the kernels the bench line's rooflines are about -- the in-step
+# forms: bench.py reads profiles/r*_{conv_instep,vox_scatter_64_2048_32,devox_affine_64_2048_32}_traffic.json into roofline.traffic
+bash tools/prof_traffic.sh conv_instep conv3d_split_kernel -- python tools/one_conv_instep.py > /dev/null 2>&1
+bash tools/prof_traffic.sh vox_scatter_64_2048_32 vox_scatter -- python tools/one_vox.py 64 2048 32 scatter > /dev/null 2>&1
 bash tools/prof_traffic.sh vox_64_2048_32 vox_fused -- python tools/one_vox.py 64 2048 32 > /dev/null 2>&1
-bash tools/prof_traffic.sh devox_64_2048_32 devox -- python tools/one_devox.py 64 2048 32 > /dev/null 2>&1
+bash tools/prof_traffic.sh devox_affine_64_2048_32 devox_rows -- python tools/one_devox.py 64 2048 32 affine > /dev/null 2>&1
 bash tools/prof_traffic.sh global_prior skinny -- python tools/one_global_prior.py > /dev/null 2>&1
-for n in vox_64_2048_32 devox_64_2048_32 global_prior; do cp gpurun_out/traffic/$n.json $O/${TAG}_${n}_traffic.json; done
+for n in conv_instep vox_scatter_64_2048_32 vox_64_2048_32 devox_affine_64_2048_32 global_prior; do cp gpurun_out/traffic/$n.json $O/${TAG}_${n}_traffic.json; done
 # MFMA-busy of the dominant conv on both kernels (own PMC passes, no tracing)
 ( cd /tmp; export TMPDIR=/tmp
-  for k in split fp32; do
+  for k in split fp32 instep; do
     S=1; [ $k = fp32 ] && S=0
-    LION_CONV_SPLIT=$S timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_$k -- python $R/tools/one_conv.py 64 64 32 > /dev/null 2>&1
-    LION_CONV_SPLIT=$S timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$k -- python $R/tools/one_conv.py 64 64 32 > /dev/null 2>&1
+    DRV="$R/tools/one_conv.py 64 64 32"; [ $k = instep ] && DRV="$R/tools/one_conv_instep.py"
+    LION_CONV_SPLIT=$S timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_$k -- python $DRV > /dev/null 2>&1
+    LION_CONV_SPLIT=$S timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$k -- python $DRV > /dev/null 2>&1
   done )
 python - "$TAG" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]; O = "gpurun_out/profiles"
 out = {}
-for k in ("split", "fp32"):
+for k in ("split", "fp32", "instep"):
     acc = collections.defaultdict(list)
     for f in glob.glob(f"{O}/pmc_{k}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
