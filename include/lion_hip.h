@@ -199,6 +199,11 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
 size_t lion_conv3d_wgrad_workspace_floats(int B, int Cin, int Cout, int r);
 int lion_conv3d_k3_wgrad(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
                          size_t ws_floats, lionStream_t stream);
+/* the same gradient on the 16-bit matrix pipe at fp32 accuracy (round 4): both operands cut into fp16 pairs in registers
+ * (one power-of-two scale per tensor), v_mfma_f32_32x32x16_f16 with 16 voxels on K, fp32 accumulation; same arguments and
+ * workspace as lion_conv3d_k3_wgrad; Cin % 8 == 0, x / gy 16-byte aligned (LION_EUNSUPPORTED otherwise). */
+int lion_conv3d_k3_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
+                               size_t ws_floats, lionStream_t stream);
 
 /* ---- P2+P3+P4 folded into C3 / K4 (inference): PVConv.forward voxel branch, pvcnn2_ada.py:211-226 ----
  * conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize without a single stand-alone pass over

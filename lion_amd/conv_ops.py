@@ -139,8 +139,14 @@ def conv3d_k3_dgrad(gy, weight):
                      packed=lambda kind: (_DGRAD_SPLIT_CACHE if kind == "split" else _DGRAD_PACK_CACHE).get(weight))
 
 
-def conv3d_k3_wgrad(x, gy, weight_shape):
-    """weight gradient [Cout,Cin,3,3,3] of the 3x3x3 / pad 1 conv on the MFMA kernel (x [B,Cin,r,r,r], Cin % 4 == 0)."""
+# weight gradient on the 16-bit matrix pipe at fp32 accuracy where Cin % 8 == 0 (csrc/conv3d_wgrad.hip, round 4);
+# LION_WGRAD_SPLIT=0: the exact-fp32 MFMA kernel everywhere
+WGRAD_SPLIT = os.environ.get("LION_WGRAD_SPLIT", "1") != "0"
+
+
+def conv3d_k3_wgrad(x, gy, weight_shape, split=None):
+    """weight gradient [Cout,Cin,3,3,3] of the 3x3x3 / pad 1 conv on the MFMA kernels (x [B,Cin,r,r,r], Cin % 4 == 0).
+    split: None = WGRAD_SPLIT, True / False = the split-operand kernel where it applies / the exact-fp32 kernel."""
     lib = _lib.load()
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = gy.shape[1]
@@ -148,8 +154,14 @@ def conv3d_k3_wgrad(x, gy, weight_shape):
     n = lib.lion_conv3d_wgrad_workspace_floats(b, cin, cout, r)
     ws = torch.empty((n,), device=x.device, dtype=torch.float32)
     x_c, gy_c = x.contiguous(), gy.contiguous()
-    _lib.check(lib.lion_conv3d_k3_wgrad(_lib.ptr(x_c), _lib.ptr(gy_c), b, cin, cout, r, _lib.ptr(gw), _lib.ptr(ws), n,
-                                        _lib.stream_ptr(x.device)), "conv3d_k3_wgrad")
+    st = _lib.stream_ptr(x.device)
+    if (WGRAD_SPLIT if split is None else split) and cin % 8 == 0:
+        rc = lib.lion_conv3d_k3_wgrad_split(_lib.ptr(x_c), _lib.ptr(gy_c), b, cin, cout, r, _lib.ptr(gw), _lib.ptr(ws), n, st)
+        if rc != -2:   # LION_EUNSUPPORTED (alignment): the fp32 kernel below
+            _lib.check(rc, "conv3d_k3_wgrad_split")
+            return gw
+    _lib.check(lib.lion_conv3d_k3_wgrad(_lib.ptr(x_c), _lib.ptr(gy_c), b, cin, cout, r, _lib.ptr(gw), _lib.ptr(ws), n, st),
+               "conv3d_k3_wgrad")
     return gw
 
 

@@ -12,11 +12,9 @@
 // waves split each 256-voxel tile (combined through LDS in fixed order at the end), so there are B * splits partial
 // results per (co, ci) tile, summed in a fixed order by a second kernel (deterministic, no atomics).  The next tile's
 // loads travel through registers under the current tile's MFMAs.  Exact fp32 products, like the forward.
-#include "common.h"
+#include "split_ops.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int TD, int TH, int TW, int CIT>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
@@ -138,6 +136,214 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float *__res
   }
 }
 
+// ---- round 4: the same weight gradient on the 16-bit matrix pipe at fp32 accuracy ---------------------------------------
+// Forward and data gradient moved to fp16 x 2 split operands in round 2 (csrc/conv3d_split.hip); the weight gradient stayed
+// on v_mfma_f32_32x32x2_f32 (0.67 of the 157 TF fp32 peak: 29 % of a VAE training step).  Here both operands are cut into
+// fp16 pieces IN REGISTERS, from the same fp32 LDS tiles, right in front of v_mfma_f32_32x32x16_f16 (16 voxels per MFMA):
+//   g = g_h + g_l,  x = x_h + x_l  (after one power-of-two scale per TENSOR: max |.| * 2^e in [2^13, 2^14)),
+//   acc += g_h x_h + g_h x_l + g_l x_h        (the dropped g_l x_l is 2^-22 relative)
+// -- 3 MFMAs of 32 cycles per 16 voxels and column block instead of 8 of 64.  Differences to the forward's split: (i) ONE
+// scale per tensor, not per tile -- the result is a sum over ~10^6 voxels, an element 2^-17 below the tensor's maximum
+// loses low bits that are 2^-39 of the largest term; (ii) the low pieces are NOT scaled up by 2048 (they are normal fp16
+// down to 2^-3 of the scaled value, subnormal steps below are 2^-38 of the maximum), so main and correction products share
+// one accumulator: 112 accumulator registers, as the fp32 kernel.  A fragment = 8 consecutive voxels of a row (TW % 8 == 0):
+// gy rows at stride 260 floats (16-byte aligned, conflict-free b128 reads), x windows at the column's tap offset (dword reads).
+constexpr int WG_GS = 260;
+__device__ __forceinline__ void cut2u(float a, float b, unsigned &hi2, unsigned &lo2) { // split_ops.h::cut2 without the 2048
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const h2_t h = __builtin_convertvector(f2_t{a, b}, h2_t);
+  const h2_t l = __builtin_convertvector(f2_t{a - (float)h[0], b - (float)h[1]}, h2_t);
+  hi2 = __builtin_bit_cast(unsigned, h);
+  lo2 = __builtin_bit_cast(unsigned, l);
+}
+
+// max |v| over a tensor as bits (finite values only), one atomic per workgroup; out must be zeroed
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ p, size_t n, unsigned *__restrict__ out) {
+  __shared__ unsigned sm[4];
+  unsigned m = 0u;
+  const size_t n4 = n >> 2;
+  const float4 *p4 = reinterpret_cast<const float4 *>(p);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = p4[i];
+    const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
+    const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
+    m = (a > m && a <= 0x7f7fffffu) ? a : m; m = (b > m && b <= 0x7f7fffffu) ? b : m;
+    m = (c > m && c <= 0x7f7fffffu) ? c : m; m = (d > m && d <= 0x7f7fffffu) ? d : m;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const unsigned a = __float_as_uint(p[(n4 << 2) + threadIdx.x]) & 0x7fffffffu;
+    m = (a > m && a <= 0x7f7fffffu) ? a : m;
+  }
+  for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) m = sm[k] > m ? sm[k] : m;
+    if (m) atomicMax(out, m);
+  }
+}
+// sc[0..1]: max bits of x, gy  ->  sc[2] = 2^ex, sc[3] = 2^eg, sc[4] = 2^-ex, sc[5] = 2^-eg
+__global__ void wgrad_scales_kernel(float *__restrict__ sc) {
+  const unsigned *u = reinterpret_cast<const unsigned *>(sc);
+  const float mx = __uint_as_float(u[0]), mg = __uint_as_float(u[1]);
+  const int ex = mx > 0.f ? scale_exp(mx) : 0, eg = mg > 0.f ? scale_exp(mg) : 0;
+  sc[2] = pow2f(ex); sc[3] = pow2f(eg); sc[4] = pow2f(-ex); sc[5] = pow2f(-eg);
+}
+
+template <int TD, int TH, int TW, int CIT>
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                    int Cin, int Cout, int r, int TS, int units,
+                                                                    const float *__restrict__ sc,
+                                                                    float *__restrict__ partial) {
+  constexpr int TV = TD * TH * TW; // 256 voxels per tile
+  static_assert(TV == 256 && TW % 8 == 0, "4 waves x 64 voxels; fragments of 8 voxels stay inside a row");
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
+  constexpr int NCOL = CIT * 27, NB = (NCOL + 31) / 32;
+  constexpr int GS = WG_GS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *sgy = smem;            // [32][GS]  gy * 2^eg
+  float *sx = sgy + 32 * GS;    // [CIT][HALO]  x * 2^ex
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Workgroup ids go round-robin over the 8 XCDs (private L2s).  A gy tile (32 KiB of the 59 staged per tile) is needed by
+  // all Cin / CIT workgroups of a (sample split, output-channel tile) unit: those sit on ONE XCD, next to each other in
+  // its launch order, and walk the tiles together -- the gy tile comes in from memory once per unit instead of once per
+  // workgroup (64 -> 64 @ 32^3: 3.9 GB of staging reads, 3.3 TB/s, were the kernel's bound at 1160 us).
+  const int NCI = Cin / CIT; // units = B * TS * (Cout / 32)
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  const int cit = j % NCI, unit = (j / NCI) * 8 + xcd;
+  if (unit >= units) return;
+  const int nbts = units / (Cout / 32);
+  const int bts = unit % nbts, cot = unit / nbts;
+  const int b = bts / TS, ts = bts % TS, part = bts;
+  const int ci0 = cit * CIT, co0 = cot * 32;
+  const int r2 = r * r, r3 = r2 * r;
+  const int ntw = r / TW, nth = r / TH, ntiles = (r / TD) * nth * ntw;
+  const int cl = lane & 31, kh = lane >> 5;
+  const float sxs = sc[2], sgs = sc[3];
+
+  int cofs[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int c = min(nb * 32 + cl, NCOL - 1); // padded columns recompute the last one; never stored
+    const int ci = c / 27, tap = c - ci * 27;
+    cofs[nb] = ci * HALO + ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+  }
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(x + ((size_t)b * Cin + ci0) * r3), 0, CIT * r3 * 4, 0x00020000);
+  const float *gyb = gy + ((size_t)b * Cout + co0) * r3;
+
+  // Staging through registers, one dword per (thread, channel): 16-byte row loads (the forward kernel's staging) were
+  // tried here and are SLOWER (1176 -> 1346 us at 64 -> 64 @ 32^3): this kernel is bound by the VALU of its in-register
+  // cuts and by its dword LDS reads, not by the texture-address path.
+  constexpr int NXI = (HALO + 255) / 256;
+  float rgy[32], rx[NXI][CIT];
+  auto load_tile = [&](int t) {
+    const int tw_i = t % ntw, th_i = (t / ntw) % nth, td_i = t / (ntw * nth);
+    const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+    {
+      const int v = tid, d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
+      const int gv = ((d0 + d) * r + (h0 + h)) * r + (w0 + w);
+#pragma unroll
+      for (int c = 0; c < 32; ++c) rgy[c] = gyb[(size_t)c * r3 + gv];
+    }
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int p = tid + 256 * i;
+      const int hd = p / (HH * HW), hh = (p / HW) % HH, hw = p % HW;
+      const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+      const bool ok = p < HALO && gd >= 0 && gd < r && gh >= 0 && gh < r && gw >= 0 && gw < r;
+      const int off = ok ? ((gd * r + gh) * r + gw) * 4 : 0x7fffff00;
+#pragma unroll
+      for (int c = 0; c < CIT; ++c)
+        rx[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, c * r3 * 4, 0));
+    }
+  };
+  auto store_tile = [&]() { // scaled: the cuts in front of the MFMAs need no multiply
+#pragma unroll
+    for (int c = 0; c < 32; ++c) sgy[c * GS + tid] = rgy[c] * sgs;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int p = tid + 256 * i;
+      if (p < HALO) {
+#pragma unroll
+        for (int c = 0; c < CIT; ++c) sx[c * HALO + p] = rx[i][c] * sxs;
+      }
+    }
+  };
+  if (ts < ntiles) load_tile(ts);
+  for (int t = ts; t < ntiles; t += TS) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (t + TS < ntiles) load_tile(t + TS);
+    // 4 k-steps of 16 voxels over this wave's 64 voxels; a lane's fragment = voxels v0 .. v0 + 7 of one row
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      const int v0 = wave * 64 + 16 * s + 8 * kh;
+      const int d = v0 / (TH * TW), h = (v0 / TW) % TH, w = v0 % TW;
+      const int vb = (d * HH + h) * HW + w;
+      const float4 g0 = *reinterpret_cast<const float4 *>(sgy + cl * GS + v0);
+      const float4 g1 = *reinterpret_cast<const float4 *>(sgy + cl * GS + v0 + 4);
+      u4 ah, al;
+      { unsigned hh_, ll_; cut2u(g0.x, g0.y, hh_, ll_); ah[0] = hh_; al[0] = ll_;
+        cut2u(g0.z, g0.w, hh_, ll_); ah[1] = hh_; al[1] = ll_;
+        cut2u(g1.x, g1.y, hh_, ll_); ah[2] = hh_; al[2] = ll_;
+        cut2u(g1.z, g1.w, hh_, ll_); ah[3] = hh_; al[3] = ll_; }
+      // column blocks in two groups (4 + the rest): the fragments of a group live in registers while its 3 x G MFMAs run,
+      // and an accumulator is touched again G MFMAs later
+      constexpr int G0 = NB < 4 ? NB : 4;
+#pragma unroll
+      for (int n0 = 0; n0 < NB; n0 += G0) {
+        u4 bh[G0], bl[G0];
+#pragma unroll
+        for (int q = 0; q < G0; ++q) {
+          const int nb = min(n0 + q, NB - 1);
+          const float *xp = sx + cofs[nb] + vb;
+          float xv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xv[j] = xp[j];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { unsigned hh_, ll_; cut2u(xv[2 * m], xv[2 * m + 1], hh_, ll_); bh[q][m] = hh_; bl[q][m] = ll_; }
+        }
+#pragma unroll
+        for (int q = 0; q < G0; ++q) if (n0 + q < NB) acc[n0 + q] = mma(ah, bh[q], acc[n0 + q]);
+#pragma unroll
+        for (int q = 0; q < G0; ++q) if (n0 + q < NB) acc[n0 + q] = mma(ah, bl[q], acc[n0 + q]);
+#pragma unroll
+        for (int q = 0; q < G0; ++q) if (n0 + q < NB) acc[n0 + q] = mma(al, bh[q], acc[n0 + q]);
+      }
+    }
+  }
+  // waves -> one partial per workgroup, unscaled (two exact power-of-two factors: their product may leave fp32's range)
+  const float ux = sc[4], ug = sc[5];
+  float *pt = partial + (size_t)part * Cout * Cin * 27;
+  float *red = smem; // [4 waves][16][64]
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = acc[nb][i];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = tid + 256 * k, i = e >> 6, ln = e & 63;
+      const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+      const int c = nb * 32 + (ln & 31);
+      if (c < NCOL) {
+        const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5);
+        pt[((size_t)co * Cin + ci0) * 27 + c] = (v * ux) * ug;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *__restrict__ partial, int nparts,
                                                                   size_t n, float *__restrict__ gw) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -160,6 +366,21 @@ static int launch_wgrad(const float *x, const float *gy, int B, int Cin, int Cou
   return 0;
 }
 
+template <int TD, int TH, int TW, int CIT>
+static int launch_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, int TS, const float *sc,
+                              float *partial, hipStream_t st) {
+  constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
+  size_t lds = (size_t)(32 * WG_GS + CIT * HALO) * 4;
+  if (lds < (size_t)4 * 16 * 64 * 4) lds = (size_t)4 * 16 * 64 * 4; // the epilogue's [4][16][64] reduction buffer
+  static LionLdsLimit cfg = {};
+  if (int e = lion_dynamic_lds(&conv3d_wgrad_split_kernel<TD, TH, TW, CIT>, lds, cfg)) return e;
+  const int units = B * TS * (Cout / 32), nci = Cin / CIT;
+  conv3d_wgrad_split_kernel<TD, TH, TW, CIT><<<dim3((unsigned)(((units + 7) / 8) * 8 * nci)), 256, lds, st>>>(
+      x, gy, Cin, Cout, r, TS, units, sc, partial);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -177,7 +398,7 @@ static int wgrad_splits(int B, int Cin, int Cout, int r) {
 // floats of scratch: B * splits partial copies of the [Cout,Cin,27] gradient (one per workgroup)
 size_t lion_conv3d_wgrad_workspace_floats(int B, int Cin, int Cout, int r) {
   if (Cin % 4 != 0 || Cout % 32 != 0 || (r != 8 && r != 16 && r != 32)) return 0;
-  return (size_t)B * wgrad_splits(B, Cin, Cout, r) * Cout * Cin * 27;
+  return (size_t)B * wgrad_splits(B, Cin, Cout, r) * Cout * Cin * 27 + 64; // + the split kernel's maxima / scales
 }
 
 // x f32[B,Cin,r,r,r] (Cin % 4 == 0), gy f32[B,Cout,r,r,r] (Cout % 32 == 0), r in {8,16,32} -> gw f32[Cout,Cin,3,3,3]
@@ -193,6 +414,34 @@ int lion_conv3d_k3_wgrad(const float *x, const float *gy, int B, int Cin, int Co
   if (r == 32) rc = c8 ? launch_wgrad<2, 4, 32, 8>(x, gy, B, Cin, Cout, r, TS, ws, st) : launch_wgrad<2, 4, 32, 4>(x, gy, B, Cin, Cout, r, TS, ws, st);
   else if (r == 16) rc = c8 ? launch_wgrad<4, 4, 16, 8>(x, gy, B, Cin, Cout, r, TS, ws, st) : launch_wgrad<4, 4, 16, 4>(x, gy, B, Cin, Cout, r, TS, ws, st);
   else rc = c8 ? launch_wgrad<4, 8, 8, 8>(x, gy, B, Cin, Cout, r, TS, ws, st) : launch_wgrad<4, 8, 8, 4>(x, gy, B, Cin, Cout, r, TS, ws, st);
+  if (rc) return rc;
+  const size_t n = (size_t)Cout * Cin * 27;
+  conv3d_wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ws, B * TS, n, gw);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same gradient on the 16-bit matrix pipe at fp32 accuracy (conv3d_wgrad_split_kernel above): same arguments and
+// workspace; Cin % 8 == 0 (LION_EUNSUPPORTED otherwise: the caller uses lion_conv3d_k3_wgrad).
+int lion_conv3d_k3_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
+                               size_t ws_floats, lionStream_t stream) {
+  if (!x || !gy || !gw || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
+  if (Cin % 8 != 0 || Cout % 32 != 0 || (r != 8 && r != 16 && r != 32)) return LION_EUNSUPPORTED;
+  if (!ws || ws_floats < lion_conv3d_wgrad_workspace_floats(B, Cin, Cout, r)) return LION_EWORKSPACE;
+  if (((((uintptr_t)x) | ((uintptr_t)gy)) & 15) != 0) return LION_EUNSUPPORTED;
+  const int TS = wgrad_splits(B, Cin, Cout, r);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t nparts = (size_t)B * TS * Cout * Cin * 27;
+  float *sc = ws + nparts;
+  if (hipMemsetAsync(sc, 0, 8, st) != hipSuccess) return LION_EINVAL;
+  const size_t nx = (size_t)B * Cin * r * r * r, ng = (size_t)B * Cout * r * r * r;
+  absmax_kernel<<<1024, 256, 0, st>>>(x, nx, reinterpret_cast<unsigned *>(sc));
+  absmax_kernel<<<1024, 256, 0, st>>>(gy, ng, reinterpret_cast<unsigned *>(sc) + 1);
+  wgrad_scales_kernel<<<1, 1, 0, st>>>(sc);
+  int rc;
+  if (r == 32) rc = launch_wgrad_split<2, 4, 32, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
+  else if (r == 16) rc = launch_wgrad_split<4, 4, 16, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
+  else rc = launch_wgrad_split<4, 8, 8, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
   if (rc) return rc;
   const size_t n = (size_t)Cout * Cin * 27;
   conv3d_wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ws, B * TS, n, gw);
