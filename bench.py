@@ -15,18 +15,26 @@ runs a K-step DDIM chain (uniform skip) and the line says "extrapolated":
 Each rank samples its own B shapes (independent units, no data-path collective): scaling = weak.
 `python bench.py --gpus N` starts its own N ranks when no launcher set WORLD_SIZE; under torchrun it is one rank.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel of the step (3x3x3 Conv3d 64->64 @32^3, 97 % of the FLOPs) timed
-                with HIP events on the launch stream: fp32-equivalent TFLOP/s of the split-operand kernel vs
-                2500 / 3 TF (fp16 MFMA peak over the 3 products per fp32 product); roofline_fp32_kernel: the
-                exact-fp32 kernel vs the 157.3 TF fp32 MFMA peak;
-  roofline_voxelize  the kernel the metric names: fused voxelize (64, 2048, 32), algorithmic bytes
-                (SURVEY.md 8d) / measured time vs 8 TB/s HBM;
-  roofline_devoxelize, roofline_backward_operators (K5, K8, K12-grad)  the same for the devoxelize forward and the
-                backward scatters of the training path; these operators (60-200 us) are timed as 20 / 10 launches inside
-                ONE hipGraph replay bracketed by HIP events: the kernels' time, not the host's launch rate;
+Extra objects on the JSON line (round 4):
+  roofline      the Conv3d instantiation a sampling step RUNS (64->64 @32^3, B=32: AdaGN+Swish prologue, constant + delta,
+                GroupNorm sums, work queue, every tile occupied) timed with HIP events on the launch stream: fp32-equivalent
+                TFLOP/s vs 2500 / 3 TF (fp16 MFMA peak over the 3 products per fp32 product); roofline_conv1_form = the other
+                in-step instantiation, roofline_plain_kernel = the same layer without prologue / sums / queue,
+                roofline_fp32_kernel = the exact-fp32 kernel vs the 157.3 TF fp32 MFMA peak; whole_step_mfma_frac = 1909
+                GFLOP of a step / ms_per_step_dense_convs / 833 TF; roofline.traffic = HBM bytes per launch from
+                profiles/r*_conv_instep_traffic.json (separate rocprofv3 --pmc passes; the file is named on the line);
+  roofline_voxelize  the kernel the step runs and the metric names: vox_scatter_kernel (64, 2048, 32) from the index plan,
+                algorithmic bytes / measured time vs 8 TB/s HBM; index kernel time and the fused single call as side keys;
+  roofline_devoxelize  the affine form a PVConv runs (plain eval as side key); roofline_backward_operators (K5, K8,
+                K12-grad); roofline_chamfer / roofline_emd (fp32 vector peak / v_exp issue rate); latency_bound_operators
+                (K6, K9, K11 as times).  Operators of 30-200 us are timed as 10-20 launches inside ONE hipGraph replay
+                bracketed by HIP events: the kernels' time, not the host's launch rate;
   config.ms_per_step_all_runs  the timed call is repeated --repeats (3) times, `value` is the median;
-  cpu_baseline  the same step on the host cores (PyTorch-CPU dense layers + the C oracle operators).
+  config.full_chain_1000  with --steps < 1000: one real 1000-step chain of the product sampler, run after the timed region
+                (the short chain is the dense start of the trajectory; SURVEY.md 8d wants the real chain beside it);
+  config.streams  the graphs / streams the captured chains actually replay;
+  cpu_baseline  ONE DDIM step at B = 32 (and a few at B = 1) on the host cores (PyTorch-CPU dense layers + the C oracle
+                operators) and the oracle's own time for voxelize / devoxelize at (64, 2048, 32).
 """
 import argparse
 import json

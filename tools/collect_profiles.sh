@@ -20,6 +20,7 @@ python tools/sparse_conv_bench.py > $O/${TAG}_sparse_conv_bench.txt 2>/dev/null
 python tools/kbench.py > $O/${TAG}_kbench.txt 2>/dev/null
 python tools/victims_beside_conv.py --replays 40 > $O/${TAG}_victims_beside_conv.txt 2>/dev/null
 python tools/pw_bench.py > $O/${TAG}_pw_bench.txt 2>/dev/null
+python tools/wgrad_bench.py > $O/${TAG}_wgrad_bench.txt 2>/dev/null
 ./tools/exp/grid_barrier_probe > $O/${TAG}_grid_barrier_probe.txt 2>/dev/null
 python tools/vox_clump_bench.py --no-traj > $O/${TAG}_vox_clump_bench.txt 2>/dev/null
 python tools/determinism_probe.py 32 5 > $O/${TAG}_determinism_probe.json 2>/dev/null
