@@ -104,8 +104,8 @@ def test_host_side_plan_functions():
     assert lib.lion_conv3d_occupancy_ints(32, 64, 32) == 2 * 32 * 128 + 1
     assert lib.lion_conv3d_occupancy_ints(8, 64, 32) == 0                  # never sparse at r = 8
     assert lib.lion_conv3d_packed_floats(64, 3) == 4 * 27 * 64             # Cin padded to 4
-    assert lib.lion_conv3d_wgrad_workspace_floats(32, 64, 64, 32) == 32 * 1 * 64 * 64 * 27   # one partial per workgroup (round 3)
-    assert lib.lion_conv3d_wgrad_workspace_floats(32, 32, 32, 32) == 32 * 4 * 32 * 32 * 27  # 4 spatial splits
+    assert lib.lion_conv3d_wgrad_workspace_floats(32, 64, 64, 32) == 32 * 1 * 64 * 64 * 27 + 64   # one partial per workgroup (round 3) + the split kernel's maxima / scales (round 4)
+    assert lib.lion_conv3d_wgrad_workspace_floats(32, 32, 32, 32) == 32 * 4 * 32 * 32 * 27 + 64  # 4 spatial splits
     assert lib.lion_conv3d_wgrad_workspace_floats(32, 3, 32, 32) == 0      # Cin % 4 != 0: library fallback
     # pointwise conv: column tiles of 4 waves x VB x 32 columns
     assert lib.lion_pwconv_stat_tiles(64, 35, 32768) == 32768 // 512
