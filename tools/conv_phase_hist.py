@@ -9,7 +9,7 @@ from lion_amd import _lib, fused_ops as fo
 from lion_amd.conv_ops import conv3d_k3
 from lion_amd.functional.backend import _backend as bk
 lib = _lib.load()
-for f in (lib.lion_debug_split_phases, lib.lion_debug_split_hist):
+for f in (lib.lion_debug_split_phases, lib.lion_debug_split_hist, lib.lion_debug_split_clk):
     f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, ctypes.c_int]
 names = ["item prologue", "barrier A (chunk start)", "loads+wait+activate+max", "barrier B (max)", "cut + LDS write",
          "group barrier (weights)", "taps", "epilogue"]
@@ -19,18 +19,18 @@ def measure(label, fn, items, n=5):
         for _ in range(3): fn()
         torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * 8)(); h = (ctypes.c_ulonglong * 8)()
-        lib.lion_debug_split_phases(buf, 1); lib.lion_debug_split_hist(h, 1)
+        lib.lion_debug_split_phases(buf, 1); lib.lion_debug_split_hist(h, 1); ck = (ctypes.c_ulonglong * 2)(); lib.lion_debug_split_clk(ck, 1)
         a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(n): fn()
         b.record(); torch.cuda.synchronize()
-        lib.lion_debug_split_phases(buf, 1); lib.lion_debug_split_hist(h, 1)
+        lib.lion_debug_split_phases(buf, 1); lib.lion_debug_split_hist(h, 1); lib.lion_debug_split_clk(ck, 1)
     tot = sum(buf); ht = max(sum(h), 1)
-    print(f"{label}: {a.elapsed_time(b) / n * 1e3:.0f} us (instrumented), wave-0 cycles per item {tot / n / items:.0f}")
+    print(f"{label}: {a.elapsed_time(b) / n * 1e3:.0f} us (instrumented), wave-0 cycles per item {tot / n / items:.0f}; s_memtime ticks per us of workgroup lifetime {100.0 * ck[0] / max(ck[1], 1):.0f}, workgroup lifetimes sum {ck[1] / 100.0 / n:.0f} us per launch")
     print("   " + " | ".join(f"{names[k]} {buf[k] / n / items:.0f}" for k in range(8)))
     print("   tap groups by cycles/MFMA: " + " | ".join(f"{edges[k]} {100.0 * h[k] / ht:.1f}%" for k in range(8)), flush=True)
 B = 32
-for c, r, n_pts in ((64, 32, 2048), (128, 16, 1024)):
+for c, r, n_pts in ((64, 32, 2048), (128, 16, 1024))[:int(os.environ.get('PHASE_HIST_SHAPES', '2'))]:
     conv1 = torch.nn.Conv3d(c, c, 3, padding=1).cuda(); conv2 = torch.nn.Conv3d(c, c, 3, padding=1).cuda()
     x = torch.randn(B, c, r, r, r, device="cuda")
     A = torch.rand(B, c, device="cuda") + 0.5; Bs = torch.randn(B, c, device="cuda") * 0.5

@@ -12,6 +12,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/exp/mfma_issue_probe.hip -o tools/exp/mfma_issue_probe && ./tools/exp/mfma_issue_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(64 * NW, REGS_OCC) void probe(unsigned long long *o
   if (wave < 4 || PARTNER == 3) tap_stream<CB, VB, READS, PRIO>(lds, lane, taps, sink, &cyc);
   else if (PARTNER == 1) valu_stream(valu_iters, sink, lane);
   if (lane == 0) out[blockIdx.x * NW + wave] = cyc;
-  if (threadIdx.x == 0 && blockIdx.x == 0) wall[0] = wall_clock64() - w0;
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) wall[0] = wall_clock64() - w0; // a workgroup from the middle of the launch
 }
 
 struct Res { double cyc_per_mfma_med, cyc_per_mfma_max, ms, tf; };
@@ -160,13 +161,16 @@ static void run(const char *name, int taps, int valu_iters) {
   printf("%-58s regs %3d scratch %3zu | cyc/MFMA/wave med %6.1f p10 %6.1f p90 %6.1f | %7.3f ms  %7.1f TF fp16 | blk0 wall %.1f us\n",
          name, fa.numRegs, (size_t)fa.localSizeBytes, c[c.size() / 2], c[c.size() / 10], c[c.size() * 9 / 10], ms,
          flops / (ms * 1e-3) / 1e12, hw / 100.0);
+  // clock = s_memtime ticks of the middle workgroup's MFMA wave / its wall time (the tap stream is nearly its whole life)
+  printf("%58s   in-kernel clock of a mid-launch workgroup: %.0f MHz\n", "", (double)h[(blocks / 2) * NW] / (hw / 100.0));
   hipFree(out);
   hipFree(wall);
   hipFree(sink);
 }
 
-int main() {
-  const int taps = 27 * 16; // 4 chunks of 27 taps x 4
+int main(int argc, char **argv) {
+  const int mult = argc > 1 ? atoi(argv[1]) : 1;
+  const int taps = 27 * 16 * mult; // 4 chunks of 27 taps x 4 (x mult: sustained runs show the clock the chip settles at)
   // valu partner iterations sized to last about as long as the MFMA wave: 16 values x ~7 VALU per iteration
   const int vi = 1500;
   printf("tap pattern CB x VB: per tap 3 CB VB MFMAs, 2 (CB + VB) ds_read_b128; one workgroup per CU, 1024 workgroups\n");
