@@ -579,7 +579,7 @@ def main():
             gv5 = gridv.view(B, C, r, r, r)
             tda = ev_time_graph(lambda: fused_ops.devoxelize_affine(gv5, nc, r, sc_, sh_), 20)
             roofd = hbm_roofline("trilinear_devoxelize with the AdaGN x SE affine folded in (what a PVConv runs) C=64 N=2048 "
-                                 "r=32: devox_rows_kernel<true>", dbytes + 8.0 * B * C, tda)
+                                 "r=32: devox_ring_kernel<true, 8>", dbytes + 8.0 * B * C, tda)
             roofd["plain_eval"] = hbm_roofline("trilinear_devoxelize C=64 N=2048 r=32 (eval, the reference's entry point)",
                                                dbytes, td)
             del plan, gv5

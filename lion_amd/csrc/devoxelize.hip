@@ -3,13 +3,13 @@
 // Reference: third_party/pvcnn/functional/src/interpolate/trilinear_devox.cu:21-162,
 //            trilinear_devox.cpp:18-95.
 //
-// Forward: the [r^3] grid of a (batch, channel) is streamed through LDS (devox_slab_kernel: LDS-DMA,
-// double buffered, slabs of <= 9 x-planes at r=32, several whole channel grids at r<=16) and the 8
+// Forward: r = 32: only the 32-byte pieces of z-rows that some point reads are moved, compacted by LDS-DMA into a ring of
+// LDS buffers (devox_ring_kernel); r <= 16: the [r^3] grid of a (batch, channel) is streamed through LDS
+// (devox_slab_kernel: LDS-DMA, double buffered, several whole channel grids per round) and the 8
 // corners are gathered from LDS -- global 4-byte gathers cost one TA cycle per lane, which bounds
 // the plain gather kernel (devox_fwd_kernel, kept as the fallback for N > 2048 / odd r) at ~2x the
-// time.  A lane owns up to 8 points (grouped by x-slab so that waves are uniformly active); the
-// corner indices / weights use the same expressions and the same left-to-right evaluation as the
-// reference: bit-exact vs the oracle.  (64,2048,32), B=32: 112 us -> 59 us.
+// time.  A lane owns up to 8 points; the corner indices / weights use the same expressions and the same left-to-right
+// evaluation as the reference: bit-exact vs the oracle.
 //
 // Backward: the reference issues 8*C global float atomics per point into a memset grid.  Here one
 // workgroup owns one (batch, channel) slab, accumulates it in LDS with ds_add_f32 (16 KiB at r=16,
@@ -19,6 +19,8 @@
 #include "common.h"
 
 namespace {
+
+template <bool V> struct BoolT { static constexpr bool value = V; };
 
 struct Corners {
   int ix[8];
@@ -299,51 +301,81 @@ __global__ __launch_bounds__(256) void devox_slab_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// devox_rows_kernel (r = 32): only the z-rows that some point interpolates from are moved at all.
-// A cloud of N = 2048 points touches <= 4 (x, y) pairs per point: 37-52 % of the 1024 z-rows (128 B each) of a
-// channel grid for Gaussian latents, less for surface-like clouds.  The slab kernel above, even with its DMA lanes
-// predicated on that set, stays at 51 us for (64, 2048, 32): it is bound by its 16 barrier-separated slab rounds per
-// workgroup (a round trip each), not by bytes (143 MB moved, rocprofv3 FETCH/WRITE).  Here the needed rows of a WHOLE
-// channel are compacted into one LDS buffer (slot = rank of the row in the cloud's row bitmap; <= CAP rows = 72 KiB),
-// so a workgroup makes one round per channel with 3-4x the bytes in flight, the points keep their natural order
-// (lane = point mod 256: the [C, N] rows are written with coalesced stores) and need no slab sort.
-// Same corner expressions / evaluation order as corners_of(): bit-exact vs the oracle.  A cloud that needs more than
-// CAP rows (N > 2048-like densities) takes the in-kernel global-gather path.
+// devox_ring_kernel (r = 32): only the PIECES of z-rows that some point interpolates from are moved at all, through a
+// ring of D LDS buffers with D - 1 channels in flight.
+// A cloud of N = 2048 points touches <= 4 (x, y) rows per point: 37-52 % of the 1024 z-rows (128 B each) of a channel
+// grid for Gaussian latents, 15 % for surface-like clouds -- and of a row only the 32-byte piece(s) around z_lo, z_lo+1
+// (Gaussian: 1025 of 4096 pieces = 32 KiB per channel against 56 KiB of whole rows).  Round 2-3 moved whole rows through
+// two 72-KiB buffers: one channel in flight, 57 KB per CU, one DMA round trip (~3 us) per channel -- latency x
+// concurrency, not bytes, set the 34 us.  Here (round 4):
+//   * per cloud: piece bitmap (LDS atomicOr), ranks by popcount prefix -> slot per needed piece, piece list;
+//   * a channel's needed pieces are compacted by LDS-DMA (global_load_lds_dwordx4 ... nt, per-lane addresses computed
+//     once) into one of D = min(4, 144 KiB / channel bytes) buffers; channels ci+1 .. ci+D-1 are in flight while channel
+//     ci is gathered (8 ds_read_b32 per point from precomputed 16-bit offsets) and written with coalesced [C, N] row
+//     stores.  The wait for channel ci is COUNTED: every wave issues the same number of DMA instructions per channel
+//     (lanes beyond the list read element 0 into a slot nobody reads) and the same PP stores per channel (buffer stores:
+//     lanes beyond N carry an out-of-range offset and are dropped), vector memory operations retire in order, so
+//     "channel ci has landed" = at most (operations issued behind it) outstanding.  The barrier is the bare instruction:
+//     __syncthreads() carries a fence that the compiler lowers to vmcnt(0), which would drain the ring.
+// Same corner expressions / evaluation order as corners_of(): bit-exact vs the oracle.  A cloud whose pieces exceed one
+// 72-KiB buffer and points with z beyond the clamp range take the in-kernel global-gather path.
 // ---------------------------------------------------------------------------------------------
-constexpr int DVR_CAP = 576; // rows per buffer: 2 x 72 KiB
-constexpr int DVR_R = 32, DVR_NT = 512, DVR_PP = 2048 / DVR_NT;      // r, threads, points per lane (N <= 2048)
-constexpr int DVR_NJ = (DVR_CAP * (DVR_R / 4) + DVR_NT - 1) / DVR_NT; // DMA instructions per thread and channel (9)
+constexpr int DVR_R = 32, DVR_NT = 512, DVR_PP = 2048 / DVR_NT; // r, threads, points per lane (N <= 2048)
+constexpr int DVR_RING_BYTES = 144 * 1024;                      // the ring; one workgroup per CU
+constexpr int DVR_NJ = 9;                                       // DMA instructions per thread and channel, at most (72 KiB)
 
-template <bool AFF>
-__global__ __launch_bounds__(DVR_NT) void devox_rows_kernel(const float *__restrict__ coords,
+__device__ __forceinline__ void wait_vm_uniform(int n) { // n: wave-uniform number of operations that may stay outstanding
+  n = __builtin_amdgcn_readfirstlane(n);
+#define LION_WVM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : n) {
+    LION_WVM(0) LION_WVM(1) LION_WVM(2) LION_WVM(3) LION_WVM(4) LION_WVM(5) LION_WVM(6) LION_WVM(7) LION_WVM(8) LION_WVM(9)
+    LION_WVM(10) LION_WVM(11) LION_WVM(12) LION_WVM(13) LION_WVM(14) LION_WVM(15) LION_WVM(16) LION_WVM(17) LION_WVM(18)
+    LION_WVM(19) LION_WVM(20) LION_WVM(21) LION_WVM(22) LION_WVM(23) LION_WVM(24) LION_WVM(25) LION_WVM(26) LION_WVM(27)
+    LION_WVM(28) LION_WVM(29) LION_WVM(30) LION_WVM(31) LION_WVM(32) LION_WVM(33) LION_WVM(34) LION_WVM(35) LION_WVM(36)
+    LION_WVM(37) LION_WVM(38) LION_WVM(39)
+  default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break; // stricter than asked for: never wrong
+  }
+#undef LION_WVM
+}
+
+// G = floats per piece (8: 32-byte pieces; 32: whole z-rows)
+template <bool AFF, int G>
+__global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restrict__ coords,
                                                             const float *__restrict__ feat, int C, int N, int CT,
                                                             int training, float *__restrict__ out,
                                                             int32_t *__restrict__ inds, float *__restrict__ wgts,
                                                             const float *__restrict__ scale,
-                                                            const float *__restrict__ shift) {
+                                                            const float *__restrict__ shift, int dmax) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int PP = DVR_PP, r = DVR_R, r2 = r * r, r3 = r2 * r, nwords = r2 / 32, NT = DVR_NT;
+  constexpr int PP = DVR_PP, r = DVR_R, r2 = r * r, r3 = r2 * r, NT = DVR_NT;
+  constexpr int PPR = r / G, NP = r2 * PPR, nwords = NP / 32, LP = G / 4; // pieces per row / per grid, DMA lanes per piece
+  constexpr int NPMAX = DVR_NJ * NT / LP;                                 // pieces one buffer can hold
+  static_assert(nwords <= 128, "two bitmap words per lane of the ranking wave");
   float *lds = reinterpret_cast<float *>(smem);
   const int tid = threadIdx.x, b = blockIdx.y, c0 = blockIdx.x * CT;
   const int nch = min(CT, C - c0);
-  constexpr int buf_floats = DVR_CAP * r;
-  unsigned *need = reinterpret_cast<unsigned *>(lds + 2 * buf_floats); // [nwords] bit (x*r + y)
-  unsigned *base = need + nwords;                                       // [nwords] rank of the word's first row
-  uint16_t *rowlist = reinterpret_cast<uint16_t *>(base + nwords);      // [DVR_CAP] row id of each slot
-  int *s_nrows = reinterpret_cast<int *>(rowlist + DVR_CAP);
+  unsigned *need = reinterpret_cast<unsigned *>(smem + DVR_RING_BYTES); // [nwords] bit = piece id (x*r + y) * PPR + z / G
+  unsigned *base = need + nwords;                                      // [nwords] rank of the word's first piece
+  uint16_t *plist = reinterpret_cast<uint16_t *>(base + nwords);       // [NPMAX] piece id of each slot
+  float *s_sc = reinterpret_cast<float *>(plist + NPMAX);              // [16] scale, [16] shift of this workgroup's channels
+  int *s_np = reinterpret_cast<int *>(s_sc + 32);
   const float *co = coords + (size_t)b * 3 * N;
 
   if (tid < nwords) need[tid] = 0u;
+  if (AFF && tid < 2 * 16) {
+    const int ci = tid & 15;
+    s_sc[tid] = ci < nch ? (tid < 16 ? scale : shift)[(size_t)b * C + c0 + ci] : 0.f;
+  }
   __syncthreads();
   float xd1[PP], yd1[PP], zd1[PP];
-  int ra[PP], rb[PP], rc[PP], rd[PP], zl_[PP], st[PP]; // st: 1 = regular point, 0 = none, -2 = out of the grid's memory,
-                                                       // 2 = z_lo + 1 runs into the next row (flat indexing, global path)
+  int row4[PP][4], zl_[PP], st[PP]; // st: 1 = regular point, 0 = none, -2 = out of the grid's memory,
+                                    // 2 = z_lo + 1 runs into the next row (flat indexing, global path)
 #pragma unroll
   for (int p = 0; p < PP; ++p) {
     const int i = tid + p * NT;
     st[p] = 0;
     xd1[p] = yd1[p] = zd1[p] = 0.f;
-    ra[p] = rb[p] = rc[p] = rd[p] = zl_[p] = 0;
+    row4[p][0] = row4[p][1] = row4[p][2] = row4[p][3] = zl_[p] = 0;
     if (i < N) {
       const float x = co[i], y = co[i + N], z = co[i + 2 * N];
       const Corners kk = corners_of(x, y, z, r, r2);
@@ -365,124 +397,157 @@ __global__ __launch_bounds__(DVR_NT) void devox_rows_kernel(const float *__restr
         const int x0 = (int)xl, y0 = (int)yl;
         const int x1 = x0 + (xd1[p] > 0.0f ? 1 : 0), y1 = y0 + (yd1[p] > 0.0f ? 1 : 0); // ix[7] < r3 keeps them in range
         zl_[p] = (int)zl;
-        ra[p] = x0 * r + y0; rb[p] = x0 * r + y1; rc[p] = x1 * r + y0; rd[p] = x1 * r + y1;
+        row4[p][0] = x0 * r + y0; row4[p][1] = x0 * r + y1; row4[p][2] = x1 * r + y0; row4[p][3] = x1 * r + y1;
         // Voxelization clamps coordinates to [0, r-1], so z_lo = r-1 comes with a zero fraction.  A caller that hands
         // over z in (r-1, r) gets the reference's flat indexing (the "+1" element is the first of the next row):
-        // such points read the grid directly instead of the compacted rows.
+        // such points read the grid directly instead of the compacted pieces.
         if (zl_[p] == r - 1 && zd1[p] > 0.0f) st[p] = 2;
       }
       if (st[p] == 1) {
-        atomicOr(&need[ra[p] >> 5], 1u << (ra[p] & 31));
-        atomicOr(&need[rb[p] >> 5], 1u << (rb[p] & 31));
-        atomicOr(&need[rc[p] >> 5], 1u << (rc[p] & 31));
-        atomicOr(&need[rd[p] >> 5], 1u << (rd[p] & 31));
+        const int zh = zl_[p] + (zd1[p] > 0.0f ? 1 : 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int pl = row4[p][k] * PPR + zl_[p] / G, ph = row4[p][k] * PPR + zh / G;
+          atomicOr(&need[pl >> 5], 1u << (pl & 31));
+          if (ph != pl) atomicOr(&need[ph >> 5], 1u << (ph & 31));
+        }
       }
     }
   }
   __syncthreads();
-  if (tid < 64) { // ranks: exclusive prefix of the words' popcounts (32 words)
-    int cnt = tid < nwords ? __popc(need[tid]) : 0;
-    const int inc = wave_incl_scan(cnt, tid);
-    if (tid < nwords) base[tid] = (unsigned)(inc - cnt);
-    if (tid == 63) *s_nrows = inc;
+  if (tid < 64) { // ranks: exclusive prefix of the words' popcounts, two words per lane
+    const int w0 = 2 * tid, w1 = 2 * tid + 1;
+    const int c0_ = w0 < nwords ? __popc(need[w0]) : 0, c1_ = w1 < nwords ? __popc(need[w1]) : 0;
+    const int inc = wave_incl_scan(c0_ + c1_, tid);
+    if (w0 < nwords) base[w0] = (unsigned)(inc - c0_ - c1_);
+    if (w1 < nwords) base[w1] = (unsigned)(inc - c1_);
+    if (tid == 63) *s_np = inc;
   }
   __syncthreads();
-  const int nrows = *s_nrows;
-  const bool fits = nrows <= DVR_CAP;
-  auto slot_of = [&](int row) { return (int)(base[row >> 5] + __popc(need[row >> 5] & ((1u << (row & 31)) - 1u))); };
+  const int np = *s_np;
+  const int nj = (np * LP + NT - 1) / NT;         // DMA instructions per thread and channel (wave-uniform)
+  const int buf_bytes = nj * NT * 16;             // every lane of every instruction lands inside the buffer
+  const int D = nj == 0 ? 2 : min(min(dmax, 4), DVR_RING_BYTES / (nj ? buf_bytes : 1));
+  const bool fits = nj <= DVR_NJ && D >= 2;
+  auto slot_of = [&](int pc) { return (int)(base[pc >> 5] + __popc(need[pc >> 5] & ((1u << (pc & 31)) - 1u))); };
   if (fits)
-    for (int row = tid; row < r2; row += NT)
-      if ((need[row >> 5] >> (row & 31)) & 1u) rowlist[slot_of(row)] = (uint16_t)row;
+    for (int pc = tid; pc < NP; pc += NT)
+      if ((need[pc >> 5] >> (pc & 31)) & 1u) plist[slot_of(pc)] = (uint16_t)pc;
   __syncthreads();
 
-  // the float4 this lane moves in DMA instruction j is the same for every channel: (row, part) -> float offset inside
+  // the float4 this lane moves in DMA instruction j is the same for every channel: (piece, part) -> float offset inside
   // a channel grid, computed once (no index arithmetic, no LDS lookup in the per-channel issue loop)
-  const int n4 = fits ? nrows * (r / 4) : 0;
+  const int n4 = fits ? np * LP : 0;
   int goff[DVR_NJ];
 #pragma unroll
   for (int j = 0; j < DVR_NJ; ++j) {
     const int f = tid + j * NT;
-    goff[j] = f < n4 ? (int)rowlist[f >> 3] * r + (f & 7) * 4 : -1;
+    goff[j] = f < n4 ? (int)plist[f / LP] * G + (f % LP) * 4 : 0;
   }
   typedef __attribute__((address_space(3))) float lds_float;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_float *)lds;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int ops = 0;        // vector memory operations this wave has issued inside the ring (DMA instructions and stores)
+  int mark[4] = {0, 0, 0, 0}; // ops right behind the DMA of the channel that lives in ring slot k
   auto issue = [&](int ci) {
     const float *src = feat + ((size_t)b * C + c0 + ci) * r3;
-    const uint32_t dst0 = lds_base + (uint32_t)((ci & 1) * buf_floats * 4 + wave * 1024);
+    const uint32_t dst0 = lds_base + (uint32_t)((ci % D) * buf_bytes + wave * 1024);
 #pragma unroll
     for (int j = 0; j < DVR_NJ; ++j) {
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * (NT * 16));
-      if (goff[j] >= 0) {
+      if (j < nj) { // wave-uniform: every wave issues nj instructions per channel
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * (NT * 16));
         const float *gp = src + goff[j];
-        unsigned keep; // nt: every row is read exactly once per call
+        unsigned keep; // nt: every piece is read exactly once per call
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
       }
     }
+    ops += nj;
+    mark[ci % D] = ops;
   };
-  if (fits) issue(0); // channel 0 is in flight during the rest of the per-point setup
-  if (fits) {
-    // rows -> LDS float offsets of the four z-rows of each point (at its z_lo)
+  if (fits)
+    for (int k = 0; k < D - 1 && k < nch; ++k) issue(k); // the first channels are in flight during the rest of the setup
+  // pieces -> LDS float offsets (inside a ring buffer) of the 8 corners: (row k, z_lo) in the low half, (row k, z_hi)
+  // in the high half of off[p][k]; flat offsets inside a channel grid for the global path
+  // ... and the 8 corner weights (+ their sum for the affine form) of each point: computed once, not per channel
+  unsigned boff[PP][8]; // BYTE offsets inside a ring buffer
+  float wq[PP][8], wsum4[PP];
 #pragma unroll
-    for (int p = 0; p < PP; ++p)
-      if (st[p] == 1) {
-        ra[p] = slot_of(ra[p]) * r + zl_[p]; rb[p] = slot_of(rb[p]) * r + zl_[p];
-        rc[p] = slot_of(rc[p]) * r + zl_[p]; rd[p] = slot_of(rd[p]) * r + zl_[p];
+  for (int p = 0; p < PP; ++p) {
+    const int zh = zl_[p] + (zd1[p] > 0.0f ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      boff[p][2 * k] = boff[p][2 * k + 1] = 0u;
+      if (fits && st[p] == 1) {
+        boff[p][2 * k] = (unsigned)(slot_of(row4[p][k] * PPR + zl_[p] / G) * G + zl_[p] % G) * 4u;
+        boff[p][2 * k + 1] = (unsigned)(slot_of(row4[p][k] * PPR + zh / G) * G + zh % G) * 4u;
       }
-  }
-#pragma unroll
-  for (int p = 0; p < PP; ++p)
-    if (!fits || st[p] == 2) { // flat float offsets inside a channel grid
-      ra[p] = ra[p] * r + zl_[p]; rb[p] = rb[p] * r + zl_[p]; rc[p] = rc[p] * r + zl_[p]; rd[p] = rd[p] * r + zl_[p];
+      row4[p][k] = row4[p][k] * r + zl_[p]; // flat offset of (row k, z_lo)
     }
+    const float xd0 = sub_rn(1.0f, xd1[p]), yd0 = sub_rn(1.0f, yd1[p]), zd0 = sub_rn(1.0f, zd1[p]);
+    wq[p][0] = mul_rn(mul_rn(xd0, yd0), zd0); wq[p][1] = mul_rn(mul_rn(xd0, yd0), zd1[p]);
+    wq[p][2] = mul_rn(mul_rn(xd0, yd1[p]), zd0); wq[p][3] = mul_rn(mul_rn(xd0, yd1[p]), zd1[p]);
+    wq[p][4] = mul_rn(mul_rn(xd1[p], yd0), zd0); wq[p][5] = mul_rn(mul_rn(xd1[p], yd0), zd1[p]);
+    wq[p][6] = mul_rn(mul_rn(xd1[p], yd1[p]), zd0); wq[p][7] = mul_rn(mul_rn(xd1[p], yd1[p]), zd1[p]);
+    float ws = wq[p][0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) ws += wq[p][q];
+    wsum4[p] = ws;
+  }
+  bool any2 = false;
+#pragma unroll
+  for (int p = 0; p < PP; ++p) any2 |= st[p] == 2;
+  const bool wave_generic = !fits || __ballot(any2) != 0ull; // wave-uniform
+  float *ob = out + ((size_t)b * C + c0) * N;
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(ob, 0, nch * N * 4, 0x00020000);
   for (int ci = 0; ci < nch; ++ci) {
     const float *gsrc = feat + ((size_t)b * C + c0 + ci) * r3;
-    const float *lbuf = lds + (ci & 1) * buf_floats; // LDS address space stays visible to the compiler: ds_read, not flat
+    // an LDS-address-space pointer: with a generic one the compiler merges the two gather paths below into flat loads,
+    // whose vmcnt(0) drains the ring
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    const uint32_t lbase = lds_base + (uint32_t)((ci % D) * buf_bytes);
     if (fits) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of channel ci has landed
-      __syncthreads();                                  // ... everybody's; and channel ci-1's buffer is free again
-      if (ci + 1 < nch) issue(ci + 1);
+      wait_vm_uniform(ops - mark[ci % D]);                         // this wave's share of channel ci has landed
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // ... everybody's; channel ci-1's buffer is free again
+      if (ci + D - 1 < nch) issue(ci + D - 1);
     }
-    float *o = out + ((size_t)b * C + c0 + ci) * N;
     float sc = 1.f, sh = 0.f;
-    if (AFF) { sc = scale[(size_t)b * C + c0 + ci]; sh = shift[(size_t)b * C + c0 + ci]; }
+    if (AFF) { sc = s_sc[ci]; sh = s_sc[16 + ci]; }
+    float a4[PP];
+    // Two copies of the gather, chosen per WAVE: the one every regular wave runs holds no global load at all -- with the
+    // two paths in one body the compiler waits (vmcnt) for the possibly-pending global loads where the paths meet,
+    // and any vmcnt wait it places drains the ring.
+    auto gather = [&](auto generic_c) {
+      constexpr bool GENERIC = decltype(generic_c)::value;
+#pragma unroll
+      for (int p = 0; p < PP; ++p) {
+        float a = 0.f; // st == -2: out-of-contract coordinates (the reference would read out of bounds)
+        if (st[p] > 0) {
+          float v[8];
+          if (!GENERIC || (fits && st[p] == 1)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *(lds_cfloat *)(uintptr_t)(lbase + boff[p][q]);
+          } else { // rare: dense clouds (more pieces than a buffer holds) or z beyond the clamp range
+            const int zo = (zd1[p] > 0.0f) ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] = gsrc[row4[p][k]]; v[2 * k + 1] = gsrc[row4[p][k] + zo]; }
+          }
+          a = mul_rn(wq[p][0], v[0]); // trilinear_devox.cu:96-103, left to right
+#pragma unroll
+          for (int q = 1; q < 8; ++q) a = add_rn(a, mul_rn(wq[p][q], v[q]));
+          if (AFF) a = a * sc + sh * wsum4[p];
+        }
+        a4[p] = a;
+      }
+    };
+    if (wave_generic) gather(BoolT<true>{}); else gather(BoolT<false>{});
+    // one store per (point slot, channel) from every wave: the counted waits above rely on it
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
       const int i = tid + p * NT;
-      if (st[p] > 0) {
-        const int zo = (zd1[p] > 0.0f) ? 1 : 0;
-        float v0, v1, v2, v3, v4, v5, v6, v7;
-        if (fits && st[p] == 1) {
-          v0 = lbuf[ra[p]]; v1 = lbuf[ra[p] + zo]; v2 = lbuf[rb[p]]; v3 = lbuf[rb[p] + zo];
-          v4 = lbuf[rc[p]]; v5 = lbuf[rc[p] + zo]; v6 = lbuf[rd[p]]; v7 = lbuf[rd[p] + zo];
-        } else { // rare: dense clouds (more than DVR_CAP rows) or z beyond the clamp range
-          v0 = gsrc[ra[p]]; v1 = gsrc[ra[p] + zo]; v2 = gsrc[rb[p]]; v3 = gsrc[rb[p] + zo];
-          v4 = gsrc[rc[p]]; v5 = gsrc[rc[p] + zo]; v6 = gsrc[rd[p]]; v7 = gsrc[rd[p] + zo];
-        }
-        const float xd0 = sub_rn(1.0f, xd1[p]), yd0 = sub_rn(1.0f, yd1[p]), zd0 = sub_rn(1.0f, zd1[p]);
-        const float w0 = mul_rn(mul_rn(xd0, yd0), zd0), w1 = mul_rn(mul_rn(xd0, yd0), zd1[p]);
-        const float w2 = mul_rn(mul_rn(xd0, yd1[p]), zd0), w3 = mul_rn(mul_rn(xd0, yd1[p]), zd1[p]);
-        const float w4 = mul_rn(mul_rn(xd1[p], yd0), zd0), w5 = mul_rn(mul_rn(xd1[p], yd0), zd1[p]);
-        const float w6 = mul_rn(mul_rn(xd1[p], yd1[p]), zd0), w7 = mul_rn(mul_rn(xd1[p], yd1[p]), zd1[p]);
-        float a = mul_rn(w0, v0); // trilinear_devox.cu:96-103, left to right
-        a = add_rn(a, mul_rn(w1, v1));
-        a = add_rn(a, mul_rn(w2, v2));
-        a = add_rn(a, mul_rn(w3, v3));
-        a = add_rn(a, mul_rn(w4, v4));
-        a = add_rn(a, mul_rn(w5, v5));
-        a = add_rn(a, mul_rn(w6, v6));
-        a = add_rn(a, mul_rn(w7, v7));
-        if (AFF) {
-          float wsum = w0;
-          wsum += w1; wsum += w2; wsum += w3; wsum += w4; wsum += w5; wsum += w6; wsum += w7;
-          a = a * sc + sh * wsum;
-        }
-        o[i] = a;
-      } else if (st[p] == -2) {
-        o[i] = 0.f; // out-of-contract coordinates (the reference would read out of bounds)
-      }
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a4[p]), ors, i < N ? (ci * N + i) * 4 : 0x7fffff00, 0, 0);
     }
+    ops += PP;
   }
 }
 
@@ -544,19 +609,22 @@ static int devox_launch(const float *coords, const float *feat, int B, int C, in
                         int training, float *out, int32_t *inds, float *wgts, const float *scale,
                         const float *shift, hipStream_t st) {
   const int r2 = r * r;
-  // r = 32 (the large calls): compacted needed rows, one round per channel
+  // r = 32 (the large calls): compacted needed pieces of rows through a ring of LDS buffers
   if (r == DVR_R && N <= 2048 && (((uintptr_t)feat) & 15) == 0) {
-    const size_t lds = (size_t)2 * DVR_CAP * r * 4 + (size_t)2 * ((r2 + 31) / 32) * 4 + (size_t)DVR_CAP * 2 + 16;
-    int CT = 8; // one workgroup per CU (144 KiB of LDS): the per-cloud setup is amortised over CT channels
+    constexpr int G = 8; // 32-byte pieces
+    const size_t lds = (size_t)DVR_RING_BYTES + (size_t)2 * (r2 * (r / G) / 32) * 4 + (size_t)(DVR_NJ * DVR_NT / (G / 4)) * 2 +
+                       32 * 4 + 16;
+    int CT = 8; // one workgroup per CU: the per-cloud setup is amortised over CT channels
     while (CT > 1 && (long)B * lion_cdiv(C, CT) < 256) CT >>= 1;
     dim3 grid(lion_cdiv(C, CT), B);
     static LionLdsLimit cfgr0 = {}, cfgr1 = {};
+    static const int dmax = getenv("LION_DEVOX_RING") ? atoi(getenv("LION_DEVOX_RING")) : 4;
     if (scale) {
-      if (int e = lion_dynamic_lds(&devox_rows_kernel<true>, lds, cfgr1)) return e;
-      devox_rows_kernel<true><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift);
+      if (int e = lion_dynamic_lds(&devox_ring_kernel<true, G>, lds, cfgr1)) return e;
+      devox_ring_kernel<true, G><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift, dmax);
     } else {
-      if (int e = lion_dynamic_lds(&devox_rows_kernel<false>, lds, cfgr0)) return e;
-      devox_rows_kernel<false><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift);
+      if (int e = lion_dynamic_lds(&devox_ring_kernel<false, G>, lds, cfgr0)) return e;
+      devox_ring_kernel<false, G><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift, dmax);
     }
     LION_LAUNCH_CHECK();
     return 0;

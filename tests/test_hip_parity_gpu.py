@@ -182,8 +182,8 @@ def test_trilinear_devoxelize_forward_bit_exact(bk, orc, C, N, r, training):
 
 @pytest.mark.parametrize("training", [False, True])
 def test_trilinear_devoxelize_r32_row_paths(bk, orc, training):
-    """devox_rows_kernel (r = 32) moves only the z-rows some point reads, compacted in LDS.  Its three other paths:
-    (a) a cloud spread over every (x, y) column needs more rows than the LDS buffers hold -> in-kernel global gather;
+    """devox_ring_kernel (r = 32) moves only the 32-byte pieces of z-rows some point reads, compacted in LDS.  Its three other paths:
+    (a) a cloud spread over every (x, y) column needs more pieces than an LDS buffer holds -> in-kernel global gather;
     (b) z in (r-1, r): the reference's flat index arithmetic makes the "+1" corner the first element of the NEXT row
         (Voxelization clamps to r-1, so only a foreign caller gets there) -> per-point global path, same flat indices;
     (c) coordinates whose corners leave the grid's memory -> 0 instead of an out-of-bounds read (documented deviation:

@@ -31,7 +31,7 @@ cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 
 bash tools/prof_traffic.sh conv_instep conv3d_split_kernel -- python tools/one_conv_instep.py > /dev/null 2>&1
 bash tools/prof_traffic.sh vox_scatter_64_2048_32 vox_scatter -- python tools/one_vox.py 64 2048 32 scatter > /dev/null 2>&1
 bash tools/prof_traffic.sh vox_64_2048_32 vox_fused -- python tools/one_vox.py 64 2048 32 > /dev/null 2>&1
-bash tools/prof_traffic.sh devox_affine_64_2048_32 devox_rows -- python tools/one_devox.py 64 2048 32 affine > /dev/null 2>&1
+bash tools/prof_traffic.sh devox_affine_64_2048_32 devox_ring -- python tools/one_devox.py 64 2048 32 affine > /dev/null 2>&1
 bash tools/prof_traffic.sh global_prior skinny -- python tools/one_global_prior.py > /dev/null 2>&1
 for n in conv_instep vox_scatter_64_2048_32 vox_64_2048_32 devox_affine_64_2048_32 global_prior; do cp gpurun_out/traffic/$n.json $O/${TAG}_${n}_traffic.json; done
 # MFMA-busy of the dominant conv on both kernels (own PMC passes, no tracing)
