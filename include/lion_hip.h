@@ -278,6 +278,19 @@ int lion_se_gate(const float *chmean, const float *w1, const float *w2, int B, i
 int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *feat, const float *scale,
                                              const float *shift, int B, int C, int N, int r, float *out,
                                              lionStream_t stream);
+/* K4 in two steps (r = 32, N <= 2048; inference): everything the coordinates alone decide -- which 32-byte pieces of the
+ * z-rows some point interpolates from (trilinear_devox.cu:36-66), their slots in the kernel's LDS ring, every point's 8
+ * corner offsets -- is computed once per cloud (lion_trilinear_devoxelize_plan), and each feature tensor devoxelised at
+ * those coordinates starts its first DMA one round trip after the kernel begins (PVConv: four devoxelisations per
+ * (cloud, r = 32) and forward, pvcnn2_ada.py:235-243).  plan: lion_devoxelize_plan_bytes(B, N, r) bytes (0 = shape not
+ * covered), 16-byte aligned; coords must be the tensor the plan was made from; scale / shift both or neither (the affine
+ * form of lion_trilinear_devoxelize_affine_forward).  Bit-identical to the one-step entry points. */
+size_t lion_devoxelize_plan_bytes(int B, int N, int r);
+int lion_trilinear_devoxelize_plan(const float *coords, int B, int N, int r, void *plan, size_t plan_bytes,
+                                   lionStream_t stream);
+int lion_trilinear_devoxelize_planned_forward(const void *plan, size_t plan_bytes, const float *coords, const float *feat,
+                                              const float *scale, const float *shift, int B, int C, int N, int r,
+                                              float *out, lionStream_t stream);
 
 /* ---- P2+P3(+P6) for 1-D / 2-D SharedMLP layers (inference), pvcnn2_ada.py:120-164, :375-377 --------
  * after the 1x1 convolution: row sums -> lion_groupnorm_fold (T = 1) -> y = swish(x*A+Bs), optionally

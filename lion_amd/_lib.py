@@ -68,6 +68,9 @@ SIGNATURES = {
     "lion_skinny_finish": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "lion_se_gate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_trilinear_devoxelize_affine_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_devoxelize_plan_bytes": (_sz, [_i, _i, _i]),
+    "lion_trilinear_devoxelize_plan": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp]),
+    "lion_trilinear_devoxelize_planned_forward": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_row_stats": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_pwconv_packed_floats": (_sz, [_i, _i]),
     "lion_pwconv_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),

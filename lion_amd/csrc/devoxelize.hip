@@ -339,13 +339,23 @@ __device__ __forceinline__ void wait_vm_uniform(int n) { // n: wave-uniform numb
 }
 
 // G = floats per piece (8: 32-byte pieces; 32: whole z-rows)
-template <bool AFF, int G>
+// MODE 0: self-contained (the C-ABI drop-in entry points); MODE 2: one workgroup per cloud writes the cloud's PLAN -- piece
+// list, per-point corner offsets and status, everything the coordinates alone decide -- and ends; MODE 1: starts from
+// a plan: the first channels' DMA leaves one global round trip after the kernel begins (the plan's piece list) instead of
+// behind coordinates -> bitmap -> ranks -> list (three barriers), and the per-point work runs under it.  The models
+// devoxelise the same (cloud, r = 32) four times per forward (lion_amd/models/pvcnn2_ada.py).
+// plan of a cloud (devox_plan_stride() bytes): int np, int fits, 8 bytes of padding, u16 plist[NPMAX], u16 off[N_max = 2048][8] (float offsets
+// of the 8 corners inside a ring buffer), i8 st[2048].
+template <int G> constexpr int devox_plan_stride() { return 16 + (DVR_NJ * DVR_NT / (G / 4)) * 2 + 2048 * 16 + 2048; } // 16-byte multiples
+
+template <bool AFF, int G, int MODE>
 __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restrict__ coords,
                                                             const float *__restrict__ feat, int C, int N, int CT,
                                                             int training, float *__restrict__ out,
                                                             int32_t *__restrict__ inds, float *__restrict__ wgts,
                                                             const float *__restrict__ scale,
-                                                            const float *__restrict__ shift, int dmax) {
+                                                            const float *__restrict__ shift, int dmax,
+                                                            unsigned char *__restrict__ plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int PP = DVR_PP, r = DVR_R, r2 = r * r, r3 = r2 * r, NT = DVR_NT;
   constexpr int PPR = r / G, NP = r2 * PPR, nwords = NP / 32, LP = G / 4; // pieces per row / per grid, DMA lanes per piece
@@ -360,6 +370,10 @@ __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restr
   float *s_sc = reinterpret_cast<float *>(plist + NPMAX);              // [16] scale, [16] shift of this workgroup's channels
   int *s_np = reinterpret_cast<int *>(s_sc + 32);
   const float *co = coords + (size_t)b * 3 * N;
+  unsigned char *pl_b = (MODE != 0) ? plan + (size_t)b * devox_plan_stride<G>() : nullptr;
+  const uint16_t *pl_list = reinterpret_cast<const uint16_t *>(pl_b + 16);
+  uint16_t *pl_off = reinterpret_cast<uint16_t *>(pl_b + 16 + NPMAX * 2);
+  signed char *pl_st = reinterpret_cast<signed char *>(pl_b + 16 + NPMAX * 2 + 2048 * 16);
 
   if (tid < nwords) need[tid] = 0u;
   if (AFF && tid < 2 * 16) {
@@ -367,6 +381,54 @@ __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restr
     s_sc[tid] = ci < nch ? (tid < 16 ? scale : shift)[(size_t)b * C + c0 + ci] : 0.f;
   }
   __syncthreads();
+  // ---- the ring (declared here: MODE 1 starts it before the per-point work) ----
+  int np = 0, nj = 0, buf_bytes = 0, D = 2;
+  bool fits = false;
+  int goff[DVR_NJ];
+  typedef __attribute__((address_space(3))) float lds_float;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_float *)lds;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int ops = 0;        // vector memory operations this wave has issued inside the ring (DMA instructions and stores)
+  int mark[4] = {0, 0, 0, 0}; // ops right behind the DMA of the channel that lives in ring slot k
+  auto ring_shape = [&]() {
+    nj = (np * LP + NT - 1) / NT;         // DMA instructions per thread and channel (wave-uniform)
+    buf_bytes = nj * NT * 16;             // every lane of every instruction lands inside the buffer
+    D = nj == 0 ? 2 : min(min(dmax, 4), DVR_RING_BYTES / (nj ? buf_bytes : 1));
+    fits = nj <= DVR_NJ && D >= 2;
+  };
+  auto issue = [&](int ci) {
+    const float *src = feat + ((size_t)b * C + c0 + ci) * r3;
+    const uint32_t dst0 = lds_base + (uint32_t)((ci % D) * buf_bytes + wave * 1024);
+#pragma unroll
+    for (int j = 0; j < DVR_NJ; ++j) {
+      if (j < nj) { // wave-uniform: every wave issues nj instructions per channel
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * (NT * 16));
+        const float *gp = src + goff[j];
+        unsigned keep; // nt: every piece is read exactly once per call
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+      }
+    }
+    ops += nj;
+    mark[ci % D] = ops;
+  };
+  if (MODE == 1) {
+    const int *hdr = reinterpret_cast<const int *>(pl_b);
+    unsigned pl[DVR_NJ];
+#pragma unroll
+    for (int j = 0; j < DVR_NJ; ++j) pl[j] = pl_list[(tid + j * NT) / LP]; // always inside the list's allocation
+    np = __builtin_amdgcn_readfirstlane(hdr[0]);
+    ring_shape();
+    fits = fits && hdr[1] != 0;
+    const int n4 = fits ? np * LP : 0;
+#pragma unroll
+    for (int j = 0; j < DVR_NJ; ++j) {
+      const int f = tid + j * NT;
+      goff[j] = f < n4 ? (int)pl[j] * G + (f % LP) * 4 : 0;
+    }
+    if (fits)
+      for (int k = 0; k < D - 1 && k < nch; ++k) issue(k);
+  }
   float xd1[PP], yd1[PP], zd1[PP];
   int row4[PP][4], zl_[PP], st[PP]; // st: 1 = regular point, 0 = none, -2 = out of the grid's memory,
                                     // 2 = z_lo + 1 runs into the next row (flat indexing, global path)
@@ -403,7 +465,7 @@ __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restr
         // such points read the grid directly instead of the compacted pieces.
         if (zl_[p] == r - 1 && zd1[p] > 0.0f) st[p] = 2;
       }
-      if (st[p] == 1) {
+      if (MODE != 1 && st[p] == 1) {
         const int zh = zl_[p] + (zd1[p] > 0.0f ? 1 : 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -414,59 +476,35 @@ __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restr
       }
     }
   }
-  __syncthreads();
-  if (tid < 64) { // ranks: exclusive prefix of the words' popcounts, two words per lane
-    const int w0 = 2 * tid, w1 = 2 * tid + 1;
-    const int c0_ = w0 < nwords ? __popc(need[w0]) : 0, c1_ = w1 < nwords ? __popc(need[w1]) : 0;
-    const int inc = wave_incl_scan(c0_ + c1_, tid);
-    if (w0 < nwords) base[w0] = (unsigned)(inc - c0_ - c1_);
-    if (w1 < nwords) base[w1] = (unsigned)(inc - c1_);
-    if (tid == 63) *s_np = inc;
-  }
-  __syncthreads();
-  const int np = *s_np;
-  const int nj = (np * LP + NT - 1) / NT;         // DMA instructions per thread and channel (wave-uniform)
-  const int buf_bytes = nj * NT * 16;             // every lane of every instruction lands inside the buffer
-  const int D = nj == 0 ? 2 : min(min(dmax, 4), DVR_RING_BYTES / (nj ? buf_bytes : 1));
-  const bool fits = nj <= DVR_NJ && D >= 2;
   auto slot_of = [&](int pc) { return (int)(base[pc >> 5] + __popc(need[pc >> 5] & ((1u << (pc & 31)) - 1u))); };
-  if (fits)
-    for (int pc = tid; pc < NP; pc += NT)
-      if ((need[pc >> 5] >> (pc & 31)) & 1u) plist[slot_of(pc)] = (uint16_t)pc;
-  __syncthreads();
-
-  // the float4 this lane moves in DMA instruction j is the same for every channel: (piece, part) -> float offset inside
-  // a channel grid, computed once (no index arithmetic, no LDS lookup in the per-channel issue loop)
-  const int n4 = fits ? np * LP : 0;
-  int goff[DVR_NJ];
-#pragma unroll
-  for (int j = 0; j < DVR_NJ; ++j) {
-    const int f = tid + j * NT;
-    goff[j] = f < n4 ? (int)plist[f / LP] * G + (f % LP) * 4 : 0;
-  }
-  typedef __attribute__((address_space(3))) float lds_float;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_float *)lds;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int ops = 0;        // vector memory operations this wave has issued inside the ring (DMA instructions and stores)
-  int mark[4] = {0, 0, 0, 0}; // ops right behind the DMA of the channel that lives in ring slot k
-  auto issue = [&](int ci) {
-    const float *src = feat + ((size_t)b * C + c0 + ci) * r3;
-    const uint32_t dst0 = lds_base + (uint32_t)((ci % D) * buf_bytes + wave * 1024);
+  if (MODE != 1) {
+    __syncthreads();
+    if (tid < 64) { // ranks: exclusive prefix of the words' popcounts, two words per lane
+      const int w0 = 2 * tid, w1 = 2 * tid + 1;
+      const int c0_ = w0 < nwords ? __popc(need[w0]) : 0, c1_ = w1 < nwords ? __popc(need[w1]) : 0;
+      const int inc = wave_incl_scan(c0_ + c1_, tid);
+      if (w0 < nwords) base[w0] = (unsigned)(inc - c0_ - c1_);
+      if (w1 < nwords) base[w1] = (unsigned)(inc - c1_);
+      if (tid == 63) *s_np = inc;
+    }
+    __syncthreads();
+    np = *s_np;
+    ring_shape();
+    if (fits)
+      for (int pc = tid; pc < NP; pc += NT)
+        if ((need[pc >> 5] >> (pc & 31)) & 1u) plist[slot_of(pc)] = (uint16_t)pc;
+    __syncthreads();
+    // the float4 this lane moves in DMA instruction j is the same for every channel: (piece, part) -> float offset inside
+    // a channel grid, computed once (no index arithmetic, no LDS lookup in the per-channel issue loop)
+    const int n4 = fits ? np * LP : 0;
 #pragma unroll
     for (int j = 0; j < DVR_NJ; ++j) {
-      if (j < nj) { // wave-uniform: every wave issues nj instructions per channel
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(dst0 + j * (NT * 16));
-        const float *gp = src + goff[j];
-        unsigned keep; // nt: every piece is read exactly once per call
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
-      }
+      const int f = tid + j * NT;
+      goff[j] = f < n4 ? (int)plist[f / LP] * G + (f % LP) * 4 : 0;
     }
-    ops += nj;
-    mark[ci % D] = ops;
-  };
-  if (fits)
-    for (int k = 0; k < D - 1 && k < nch; ++k) issue(k); // the first channels are in flight during the rest of the setup
+    if (MODE == 0 && fits)
+      for (int k = 0; k < D - 1 && k < nch; ++k) issue(k); // the first channels are in flight during the rest of the setup
+  }
   // pieces -> LDS float offsets (inside a ring buffer) of the 8 corners: (row k, z_lo) in the low half, (row k, z_hi)
   // in the high half of off[p][k]; flat offsets inside a channel grid for the global path
   // ... and the 8 corner weights (+ their sum for the affine form) of each point: computed once, not per channel
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restr
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       boff[p][2 * k] = boff[p][2 * k + 1] = 0u;
-      if (fits && st[p] == 1) {
+      if (MODE != 1 && fits && st[p] == 1) {
         boff[p][2 * k] = (unsigned)(slot_of(row4[p][k] * PPR + zl_[p] / G) * G + zl_[p] % G) * 4u;
         boff[p][2 * k + 1] = (unsigned)(slot_of(row4[p][k] * PPR + zh / G) * G + zh % G) * 4u;
       }
@@ -493,6 +531,32 @@ __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restr
 #pragma unroll
     for (int q = 1; q < 8; ++q) ws += wq[p][q];
     wsum4[p] = ws;
+  }
+  if (MODE == 1) { // corner offsets from the plan (st is recomputed above from the same coordinates)
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const int i = tid + p * NT;
+      const uint4 o4 = *reinterpret_cast<const uint4 *>(pl_off + (size_t)(i < 2048 ? i : 0) * 8);
+      boff[p][0] = (o4.x & 0xffffu) * 4u; boff[p][1] = (o4.x >> 16) * 4u; boff[p][2] = (o4.y & 0xffffu) * 4u; boff[p][3] = (o4.y >> 16) * 4u;
+      boff[p][4] = (o4.z & 0xffffu) * 4u; boff[p][5] = (o4.z >> 16) * 4u; boff[p][6] = (o4.w & 0xffffu) * 4u; boff[p][7] = (o4.w >> 16) * 4u;
+    }
+  }
+  if (MODE == 2) { // write the plan and end
+    if (tid == 0) { int *hdr = reinterpret_cast<int *>(pl_b); hdr[0] = np; hdr[1] = fits ? 1 : 0; }
+    uint16_t *wl = reinterpret_cast<uint16_t *>(pl_b + 16);
+    for (int s_ = tid; s_ < NPMAX; s_ += NT) wl[s_] = (fits && s_ < np) ? plist[s_] : (uint16_t)0;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      const int i = tid + p * NT;
+      if (i < 2048) {
+        uint4 o4;
+        o4.x = (boff[p][0] >> 2) | ((boff[p][1] >> 2) << 16); o4.y = (boff[p][2] >> 2) | ((boff[p][3] >> 2) << 16);
+        o4.z = (boff[p][4] >> 2) | ((boff[p][5] >> 2) << 16); o4.w = (boff[p][6] >> 2) | ((boff[p][7] >> 2) << 16);
+        *reinterpret_cast<uint4 *>(pl_off + (size_t)i * 8) = o4;
+        pl_st[i] = (signed char)st[p];
+      }
+    }
+    return;
   }
   bool any2 = false;
 #pragma unroll
@@ -603,6 +667,14 @@ __global__ void devox_bwd_atomic_kernel(const float *__restrict__ gy,
 
 } // namespace
 
+constexpr int DVR_G = 8; // floats per piece: 32-byte pieces
+constexpr size_t DVR_LDS = (size_t)DVR_RING_BYTES + (size_t)2 * (DVR_R * DVR_R * (DVR_R / DVR_G) / 32) * 4 +
+                           (size_t)(DVR_NJ * DVR_NT / (DVR_G / 4)) * 2 + 32 * 4 + 16;
+static int devox_ring_depth() { // LION_DEVOX_RING: A/B switch (2 = one channel in flight, the round-3 schedule)
+  static const int d = getenv("LION_DEVOX_RING") ? atoi(getenv("LION_DEVOX_RING")) : 4;
+  return d < 2 ? 2 : d;
+}
+
 extern "C" {
 
 static int devox_launch(const float *coords, const float *feat, int B, int C, int N, int r,
@@ -611,20 +683,16 @@ static int devox_launch(const float *coords, const float *feat, int B, int C, in
   const int r2 = r * r;
   // r = 32 (the large calls): compacted needed pieces of rows through a ring of LDS buffers
   if (r == DVR_R && N <= 2048 && (((uintptr_t)feat) & 15) == 0) {
-    constexpr int G = 8; // 32-byte pieces
-    const size_t lds = (size_t)DVR_RING_BYTES + (size_t)2 * (r2 * (r / G) / 32) * 4 + (size_t)(DVR_NJ * DVR_NT / (G / 4)) * 2 +
-                       32 * 4 + 16;
     int CT = 8; // one workgroup per CU: the per-cloud setup is amortised over CT channels
     while (CT > 1 && (long)B * lion_cdiv(C, CT) < 256) CT >>= 1;
     dim3 grid(lion_cdiv(C, CT), B);
     static LionLdsLimit cfgr0 = {}, cfgr1 = {};
-    static const int dmax = getenv("LION_DEVOX_RING") ? atoi(getenv("LION_DEVOX_RING")) : 4;
     if (scale) {
-      if (int e = lion_dynamic_lds(&devox_ring_kernel<true, G>, lds, cfgr1)) return e;
-      devox_ring_kernel<true, G><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift, dmax);
+      if (int e = lion_dynamic_lds(&devox_ring_kernel<true, DVR_G, 0>, DVR_LDS, cfgr1)) return e;
+      devox_ring_kernel<true, DVR_G, 0><<<grid, DVR_NT, DVR_LDS, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift, devox_ring_depth(), nullptr);
     } else {
-      if (int e = lion_dynamic_lds(&devox_ring_kernel<false, G>, lds, cfgr0)) return e;
-      devox_ring_kernel<false, G><<<grid, DVR_NT, lds, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift, dmax);
+      if (int e = lion_dynamic_lds(&devox_ring_kernel<false, DVR_G, 0>, DVR_LDS, cfgr0)) return e;
+      devox_ring_kernel<false, DVR_G, 0><<<grid, DVR_NT, DVR_LDS, st>>>(coords, feat, C, N, CT, training, out, inds, wgts, scale, shift, devox_ring_depth(), nullptr);
     }
     LION_LAUNCH_CHECK();
     return 0;
@@ -701,6 +769,56 @@ int lion_trilinear_devoxelize_affine_forward(const float *coords, const float *f
   if (!coords || !feat || !out || !scale || !shift || B <= 0 || C <= 0 || N <= 0 || r <= 0) return LION_EINVAL;
   return devox_launch(coords, feat, B, C, N, r, 0, out, nullptr, nullptr, scale, shift,
                       static_cast<hipStream_t>(stream));
+}
+
+// ---- the same in two steps (r = 32, N <= 2048): what the coordinates alone decide is computed once per cloud ----
+size_t lion_devoxelize_plan_bytes(int B, int N, int r) {
+  if (B <= 0 || N <= 0 || N > 2048 || r != DVR_R) return 0;
+  return (size_t)B * devox_plan_stride<DVR_G>();
+}
+
+// coords f32[B,3,N] (voxel coordinates, as lion_trilinear_devoxelize_forward) -> plan (lion_devoxelize_plan_bytes bytes,
+// 16-byte aligned)
+int lion_trilinear_devoxelize_plan(const float *coords, int B, int N, int r, void *plan, size_t plan_bytes,
+                                   lionStream_t stream) {
+  if (!coords || !plan || B <= 0 || N <= 0) return LION_EINVAL;
+  const size_t need = lion_devoxelize_plan_bytes(B, N, r);
+  if (!need || (((uintptr_t)plan) & 15) != 0) return LION_EUNSUPPORTED;
+  if (plan_bytes < need) return LION_EWORKSPACE;
+  static LionLdsLimit cfg = {};
+  if (int e = lion_dynamic_lds(&devox_ring_kernel<false, DVR_G, 2>, DVR_LDS, cfg)) return e;
+  devox_ring_kernel<false, DVR_G, 2><<<dim3(1, B), DVR_NT, DVR_LDS, static_cast<hipStream_t>(stream)>>>(
+      coords, nullptr, 1, N, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, devox_ring_depth(),
+      static_cast<unsigned char *>(plan));
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// trilinear_devoxelize (eval) of feat f32[B,C,32^3] at the plan's coordinates (the SAME coords the plan was made from);
+// scale / shift f32[B,C] (both or neither): the affine form.  Bit-identical to the one-step entry points.
+int lion_trilinear_devoxelize_planned_forward(const void *plan, size_t plan_bytes, const float *coords, const float *feat,
+                                              const float *scale, const float *shift, int B, int C, int N, int r,
+                                              float *out, lionStream_t stream) {
+  if (!plan || !coords || !feat || !out || B <= 0 || C <= 0 || N <= 0) return LION_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return LION_EINVAL;
+  const size_t need = lion_devoxelize_plan_bytes(B, N, r);
+  if (!need || (((uintptr_t)plan) & 15) != 0 || (((uintptr_t)feat) & 15) != 0) return LION_EUNSUPPORTED;
+  if (plan_bytes < need) return LION_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int CT = 8;
+  while (CT > 1 && (long)B * lion_cdiv(C, CT) < 256) CT >>= 1;
+  dim3 grid(lion_cdiv(C, CT), B);
+  unsigned char *pl = const_cast<unsigned char *>(static_cast<const unsigned char *>(plan));
+  static LionLdsLimit cfg0 = {}, cfg1 = {};
+  if (scale) {
+    if (int e = lion_dynamic_lds(&devox_ring_kernel<true, DVR_G, 1>, DVR_LDS, cfg1)) return e;
+    devox_ring_kernel<true, DVR_G, 1><<<grid, DVR_NT, DVR_LDS, st>>>(coords, feat, C, N, CT, 0, out, nullptr, nullptr, scale, shift, devox_ring_depth(), pl);
+  } else {
+    if (int e = lion_dynamic_lds(&devox_ring_kernel<false, DVR_G, 1>, DVR_LDS, cfg0)) return e;
+    devox_ring_kernel<false, DVR_G, 1><<<grid, DVR_NT, DVR_LDS, st>>>(coords, feat, C, N, CT, 0, out, nullptr, nullptr, nullptr, nullptr, devox_ring_depth(), pl);
+  }
+  LION_LAUNCH_CHECK();
+  return 0;
 }
 
 int lion_trilinear_devoxelize_backward(const float *gy, const int32_t *inds, const float *wgts,

@@ -144,12 +144,34 @@ def se_gate_(A, Bs, chmean, se):
     return A, Bs
 
 
-def devoxelize_affine(grid, coords, r, scale, shift):
-    """trilinear_devoxelize(scale[b,c]*grid + shift[b,c]) without materialising the scaled grid."""
+def devoxelize_plan(coords, r):
+    """what the voxel coordinates [B,3,N] alone decide about a devoxelisation at resolution r (needed row pieces, LDS
+    slots, corner offsets per point): computed once per (cloud, r), used by every devoxelize_affine(..., plan=) at these
+    coordinates.  None when the shape is outside the planned kernel's range (r = 32, N <= 2048)."""
+    lib = _lib.load()
+    b, _, n = coords.shape
+    nbytes = lib.lion_devoxelize_plan_bytes(b, n, int(r))
+    if nbytes == 0 or not coords.is_contiguous() or coords.dtype != torch.float32:
+        return None
+    buf = torch.empty((nbytes,), device=coords.device, dtype=torch.uint8)
+    _lib.check(lib.lion_trilinear_devoxelize_plan(_lib.ptr(coords), b, n, int(r), _lib.ptr(buf), nbytes,
+                                                  _lib.stream_ptr(coords.device)), "trilinear_devoxelize_plan")
+    return {"buf": buf, "coords": coords, "shape": (b, n, int(r))}
+
+
+def devoxelize_affine(grid, coords, r, scale, shift, plan=None):
+    """trilinear_devoxelize(scale[b,c]*grid + shift[b,c]) without materialising the scaled grid.  plan (devoxelize_plan
+    of these coordinates): the two-step form, bit-identical."""
     b, c = grid.shape[:2]
     n = coords.shape[2]
     out = torch.empty((b, c, n), device=grid.device, dtype=torch.float32)
     co_c, gr_c, sc_c, sh_c = coords.contiguous(), grid.contiguous(), scale.contiguous(), shift.contiguous()
+    if plan is not None and plan["shape"] == (b, n, int(r)) and plan["coords"].data_ptr() == co_c.data_ptr():
+        buf = plan["buf"]
+        _lib.check(_lib.load().lion_trilinear_devoxelize_planned_forward(
+            _lib.ptr(buf), buf.numel(), _lib.ptr(co_c), _lib.ptr(gr_c), _lib.ptr(sc_c), _lib.ptr(sh_c), b, c, n, int(r),
+            _lib.ptr(out), _lib.stream_ptr(grid.device)), "trilinear_devoxelize_planned_forward")
+        return out
     _lib.check(_lib.load().lion_trilinear_devoxelize_affine_forward(
         _lib.ptr(co_c), _lib.ptr(gr_c), _lib.ptr(sc_c), _lib.ptr(sh_c), b, c, n, int(r), _lib.ptr(out),
         _lib.stream_ptr(grid.device)),

@@ -37,6 +37,7 @@ _POINT_STREAMS = {}
 # the entry, so its address cannot be handed to another tensor while the entry exists.
 _VOX_PLANS = None
 VOX_PLAN = os.environ.get("LION_VOX_PLAN", "1") != "0"   # A/B switch: 0 = every voxelisation recomputes its indices
+DEVOX_PLAN = os.environ.get("LION_DEVOX_PLAN", "1") != "0"   # A/B switch: 0 = every r = 32 devoxelisation redoes its per-cloud setup
 
 
 @contextlib.contextmanager
@@ -47,6 +48,20 @@ def voxel_plans():
         yield
     finally:
         _VOX_PLANS = prev
+
+
+def _devox_plan(voxel_coords, r):
+    """the devoxelisation plan of (voxel coordinates, r) of the forward in flight (kept beside the voxel index plans: the
+    same four (cloud, r) pairs, the r = 32 pair devoxelised four times), or None."""
+    if _VOX_PLANS is None or not DEVOX_PLAN or r != 32 or voxel_coords.shape[2] > 2048 or not voxel_coords.is_contiguous():
+        return None
+    key = ("devox", voxel_coords.data_ptr(), tuple(voxel_coords.shape), int(r))
+    hit = _VOX_PLANS.get(key)
+    if hit is None:
+        plan = fused_ops.devoxelize_plan(voxel_coords, r)
+        hit = (voxel_coords, plan)      # the coordinates tensor stays alive with the entry
+        _VOX_PLANS[key] = hit
+    return hit[1]
 
 
 def _point_stream(device):
@@ -365,7 +380,7 @@ class PVConv(nn.Module):
             a2, b2, m2 = fused_ops.groupnorm_fold(st2, gn2.norm, f2, g2, r ** 3)
             if se is not None:
                 a2, b2 = fused_ops.se_gate_(a2, b2, m2, se)  # mean over the grid of AdaGN2(y2) is affine in mean(y2)
-        return fused_ops.devoxelize_affine(y2, voxel_coords, r, a2, b2)
+        return fused_ops.devoxelize_affine(y2, voxel_coords, r, a2, b2, plan=_devox_plan(voxel_coords, r))
 
     def forward(self, inputs):
         features, coords_input, time_emb, style = inputs

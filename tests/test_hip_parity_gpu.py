@@ -213,6 +213,47 @@ def test_trilinear_devoxelize_r32_row_paths(bk, orc, training):
     assert np.array_equal(o2[0][:, keep], o_out[2][:, keep])
 
 
+@pytest.mark.parametrize("N", [2048, 999])
+def test_trilinear_devoxelize_planned_equals_one_step(bk, orc, N):
+    """K4 in two steps (lion_trilinear_devoxelize_plan + ..._planned_forward, what a PVConv at r = 32 runs): the plan of a
+    cloud serves every feature tensor devoxelised at its coordinates; plain and affine forms are bit-identical to the
+    one-step entry points and to the oracle -- regular clouds, a cloud dense enough for the global-gather path, points
+    with z beyond the clamp range and out-of-contract coordinates."""
+    import torch
+    from lion_amd import fused_ops as fo, _lib
+    rng = np.random.default_rng(N)
+    B, r = 4, 32
+    co = voxel_coords(rng, B, N, r)
+    co[0] = rng.uniform(0, r - 1, (3, N)).astype(np.float32)            # dense: more pieces than a ring buffer holds
+    co[1, 2, :40] = (r - 1) + rng.uniform(0.1, 0.9, 40).astype(np.float32)  # z beyond the clamp range (flat indexing)
+    co[1, 0, :40] = np.minimum(co[1, 0, :40], r - 3)
+    co[2, :, 5] = (r - 1) + 0.5                                          # corners outside the grid's memory -> 0
+    co[2, :, :4] = np.array([[0.0, r - 1, 1.0, 2.5]] * 3, np.float32)     # exact / edge coordinates
+    d_co = dev(co)
+    plan = fo.devoxelize_plan(d_co, r)
+    assert plan is not None
+    lib = _lib.load()
+    for C in (10, 64):
+        feat = rng.standard_normal((B, C, r ** 3)).astype(np.float32)
+        d_feat = dev(feat)
+        o_out, _, _ = orc.trilinear_devoxelize_forward(r, False, co, feat)
+        one, _, _ = bk.trilinear_devoxelize_forward(r, False, d_co, d_feat)
+        two = torch.empty_like(one)
+        _lib.check(lib.lion_trilinear_devoxelize_planned_forward(
+            _lib.ptr(plan["buf"]), plan["buf"].numel(), _lib.ptr(d_co), _lib.ptr(d_feat), None, None, B, C, N, r,
+            _lib.ptr(two), _lib.stream_ptr(d_co.device)), "planned")
+        assert torch.equal(one, two)
+        keep = np.ones(N, bool); keep[5] = False
+        assert np.array_equal(host(two)[:, :, keep][[0, 1, 3]], o_out[:, :, keep][[0, 1, 3]])
+        assert np.array_equal(host(two)[2][:, keep], o_out[2][:, keep]) and np.all(host(two)[2][:, 5] == 0)
+        scale = dev(rng.uniform(0.5, 1.5, (B, C)).astype(np.float32)); shift = dev(rng.standard_normal((B, C)).astype(np.float32))
+        g5 = d_feat.view(B, C, r, r, r)
+        a1 = fo.devoxelize_affine(g5, d_co, r, scale, shift)
+        a2 = fo.devoxelize_affine(g5, d_co, r, scale, shift, plan=plan)
+        assert torch.equal(a1, a2)
+    assert fo.devoxelize_plan(dev(co[:, :, :64].copy()), 16) is None     # outside the planned kernel's range
+
+
 @pytest.mark.parametrize("C,N,r", [(32, 2048, 32), (64, 1024, 16), (16, 300, 8)])
 def test_trilinear_devoxelize_backward(bk, orc, C, N, r):
     rng = np.random.default_rng(5)

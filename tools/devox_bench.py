@@ -23,6 +23,8 @@ for C in (64, 32):
         scl, shf = torch.rand(B, C, device="cuda") + 0.5, torch.randn(B, C, device="cuda")
         g5 = grid.view(B, C, r, r, r)
         nbytes = 4 * B * (3 * N + C * 8 * N + C * N)
-        for label, fn in (("plain", lambda: bk.trilinear_devoxelize_forward(r, False, nc, grid)), ("affine", lambda: fo.devoxelize_affine(g5, nc, r, scl, shf))):
+        plan = fo.devoxelize_plan(nc, r)
+        for label, fn in (("affine", lambda: fo.devoxelize_affine(g5, nc, r, scl, shf)), ("planned", lambda: fo.devoxelize_affine(g5, nc, r, scl, shf, plan=plan)),
+                          ("plan", lambda: fo.devoxelize_plan(nc, r))):
             mn, md = t1(fn)
             print(f"C={C} {name:5s} {label:6s} min {mn:6.1f} us  median {md:6.1f} us  -> {nbytes / md / 1e3:6.0f} GB/s = {nbytes / md / 1e3 / 8000:.3f} of 8 TB/s (min: {nbytes / mn / 1e3 / 8000:.3f})", flush=True)
