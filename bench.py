@@ -25,7 +25,9 @@ Extra objects on the JSON line (round 4):
                 profiles/r*_conv_instep_traffic.json (separate rocprofv3 --pmc passes; the file is named on the line);
   roofline_voxelize  the kernel the step runs and the metric names: vox_scatter_kernel (64, 2048, 32) from the index plan,
                 algorithmic bytes / measured time vs 8 TB/s HBM; index kernel time and the fused single call as side keys;
-  roofline_devoxelize  the affine form a PVConv runs (plain eval as side key); roofline_backward_operators (K5, K8,
+  roofline_devoxelize  the planned affine form a PVConv runs (lion_trilinear_devoxelize_plan once per (cloud, r = 32), the
+                planned forward per feature tensor); one-step affine and plain eval as side keys; roofline_plain_kernel.zero_input:
+                the conv on all-zero operands (what power management takes on random data); roofline_backward_operators (K5, K8,
                 K12-grad); roofline_chamfer / roofline_emd (fp32 vector peak / v_exp issue rate); latency_bound_operators
                 (K6, K9, K11 as times).  Operators of 30-200 us are timed as 10-20 launches inside ONE hipGraph replay
                 bracketed by HIP events: the kernels' time, not the host's launch rate;
@@ -525,6 +527,19 @@ def main():
             else:
                 roof = roof32
             roof_plain = roof
+            if conv_ops.SPLIT:
+                # the same launch on an all-zero input: identical instruction stream and MFMA count, no operand toggling.  The
+                # ratio is what the chip's power management takes from this kernel on random data (the in-kernel
+                # clock, s_memtime against the 100 MHz wall clock, falls to 1.45-1.9 GHz under the dense random-data launch
+                # and stays at 2.1-2.4 GHz on sparse / zero data; a bare MFMA stream sustains 2.4 GHz).
+                xz = torch.zeros_like(xin)
+                tz = ev_time(lambda: conv_ops.conv3d_k3(xz, conv.weight, conv.bias, split=True), 20, warm=5)
+                roof_plain = dict(roof)
+                roof_plain["zero_input"] = {"us_per_launch": tz * 1e6, "frac": flops / tz / 1e12 / (MFMA_F16_PEAK_TF / 3.0),
+                                            "note": "same kernel, same MFMA count, all-zero activations: the difference to "
+                                                    "us_per_launch is clock the power management takes on random operands"}
+                roof = roof_plain
+                del xz
             # The instantiations a sampling step RUNS (round-3 verdict: the plain kernel above is not one of them): conv1 of a
             # PVConv = GroupNorm sums + work queue over occupied tiles; conv2 = AdaGN + Swish prologue, constant + delta,
             # GroupNorm sums, work queue -- timed here with EVERY tile occupied (dense), so that the FLOP count is the
@@ -578,11 +593,19 @@ def main():
             sc_, sh_ = torch.rand(B, C, device=dev) + 0.5, torch.randn(B, C, device=dev)
             gv5 = gridv.view(B, C, r, r, r)
             tda = ev_time_graph(lambda: fused_ops.devoxelize_affine(gv5, nc, r, sc_, sh_), 20)
-            roofd = hbm_roofline("trilinear_devoxelize with the AdaGN x SE affine folded in (what a PVConv runs) C=64 N=2048 "
-                                 "r=32: devox_ring_kernel<true, 8>", dbytes + 8.0 * B * C, tda)
+            # a forward devoxelises the same (cloud, r = 32) four times: the step runs lion_trilinear_devoxelize_plan once per
+            # pair and the planned forward per feature tensor (round 4); the plan adds its own bytes to the count
+            dplan = fused_ops.devoxelize_plan(nc, r)
+            tdp = ev_time_graph(lambda: fused_ops.devoxelize_affine(gv5, nc, r, sc_, sh_, plan=dplan), 20)
+            tdi = ev_time_graph(lambda: fused_ops.devoxelize_plan(nc, r), 20)
+            roofd = hbm_roofline("trilinear_devoxelize, planned, with the AdaGN x SE affine folded in (what a PVConv runs) C=64 "
+                                 "N=2048 r=32: devox_ring_kernel<true, 8, 1>", dbytes + 8.0 * B * C + 16.0 * B * N, tdp)
+            roofd["plan_kernel_us (once per (cloud, r = 32) pair and forward)"] = tdi * 1e6
+            roofd["one_step_affine"] = hbm_roofline("trilinear_devoxelize_affine (one launch, per-cloud setup inside) C=64 N=2048 "
+                                                    "r=32: devox_ring_kernel<true, 8, 0>", dbytes + 8.0 * B * C, tda)
             roofd["plain_eval"] = hbm_roofline("trilinear_devoxelize C=64 N=2048 r=32 (eval, the reference's entry point)",
                                                dbytes, td)
-            del plan, gv5
+            del plan, gv5, dplan
             # backward scatters of the training path (K5, K8, K12-grad) at the largest shapes of a forward; algorithmic bytes =
             # gradient in + indices / weights + dense gradient out, each once (tools/kbench.py --only bwd uses the same)
             _, inds, wgts = bk.trilinear_devoxelize_forward(r, True, nc, gridv)
