@@ -18,7 +18,9 @@ Each rank samples its own B shapes (independent units, no data-path collective):
 Extra objects on the JSON line (round 4):
   roofline      the Conv3d instantiation a sampling step RUNS (64->64 @32^3, B=32: AdaGN+Swish prologue, constant + delta,
                 GroupNorm sums, work queue, every tile occupied) timed with HIP events on the launch stream: fp32-equivalent
-                TFLOP/s vs 2500 / 3 TF (fp16 MFMA peak over the 3 products per fp32 product); roofline_conv1_form = the other
+                TFLOP/s vs 2500 / 3 TF (fp16 MFMA peak over the 3 products per fp32 product), on dense random operands (power
+                capped: frac_of_power_limited_mfma_rate relates it to mfma_ceiling, the bare MFMA stream's sustained rate measured
+                in the same run; roofline_conv1_form_voxelized_input = the launch on the model's own operands); roofline_conv1_form = the other
                 in-step instantiation, roofline_plain_kernel = the same layer without prologue / sums / queue,
                 roofline_fp32_kernel = the exact-fp32 kernel vs the 157.3 TF fp32 MFMA peak; whole_step_mfma_frac = 1909
                 GFLOP of a step / ms_per_step_dense_convs / 833 TF; roofline.traffic = HBM bytes per launch from
@@ -545,6 +547,23 @@ def main():
             # GroupNorm sums, work queue -- timed here with EVERY tile occupied (dense), so that the FLOP count is the
             # layer's.  Each launch consumes an occupancy / queue buffer: [occupancy + conv] and [occupancy] are captured
             # in graphs and subtracted.
+            # what the matrix pipe itself sustains on this board: the bare tap stream of the split convolution (MFMAs + their
+            # fragment reads, pipe 100 % busy at 32.5 cycles per MFMA) on random fp16 operands runs into the 1400-W cap at
+            # ~1.56 GHz; on constant operands it holds 2.4 GHz (tools/exp/mfma_issue_probe.hip)
+            mfma_ceiling = None
+            try:
+                import ctypes
+                pl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "exp", "libmfma_probe.so"))
+                pl.mfma_ceiling.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+                mfma_ceiling = {}
+                for nm, rnd in (("random_fp16_operands", 1), ("constant_operands", 0)):
+                    tf_, mhz_ = ctypes.c_double(0), ctypes.c_double(0)
+                    if pl.mfma_ceiling(rnd, 30, ctypes.byref(tf_), ctypes.byref(mhz_)) == 0:
+                        mfma_ceiling[nm] = {"TFLOP/s fp16": tf_.value, "sclk_MHz": mhz_.value}
+                mfma_ceiling["note"] = ("sustained rate of a bare v_mfma_f32_32x32x16_f16 stream with its LDS fragment reads, one wave per "
+                                        "SIMD, 2 x ~50 ms launches; the clock is s_memtime ticks per wall-clock microsecond inside the kernel")
+            except Exception as e:  # the probe library is optional (tools/exp/libmfma_probe.so from __graft_entry__.build())
+                mfma_ceiling = {"error": repr(e)}
             roof_step = {}
             if conv_ops.SPLIT:
                 ones = torch.ones(B, 32 ** 3, device=dev, dtype=torch.int32)
@@ -564,10 +583,35 @@ def main():
                                       "unit": "TFLOP/s (fp32-equivalent conv FLOPs)",
                                       "frac": flops / tt / 1e12 / (MFMA_F16_PEAK_TF / 3.0), "traffic": None,
                                       "us_per_launch": tt * 1e6}
+                # the same in-step launches on the operands the model feeds them: conv1 reads a voxelised 2048-point cloud
+                # (94 % exact zeros), every tile still computed (all-ones occupancy) -- the MFMA count of the dense layer at the
+                # operand statistics of the workload (random dense operands are the power-limited worst case)
+                cov = torch.randn(B, 3, 2048, device=dev)
+                fv = torch.randn(B, 64, 2048, device=dev)
+                gridz, _, _, _ = bk.voxelize_points_forward(fv, cov, 32, True, 0.0)
+                gz5 = gridz.view(B, 64, 32, 32, 32)
+                t_c1v = ev_time_graph(lambda: fused_ops.conv3d_fused(gz5, conv, None, True,
+                                                                     fused_ops.conv3d_occupancy(ones, 32, 64, B)[0]), 10) - t_occ
+                roof_step["conv1_form_voxelized_input"] = {
+                    "kernel": "conv3d_split_kernel<..., PRO=false, STATS=true, OCC=2>: Conv3d 3x3x3 64->64 @32^3, B=32, every tile "
+                              "computed, input = the voxelised features of 2048-point clouds (what conv1 of a PVConv reads)",
+                    "bound": "mfma", "achieved": flops / t_c1v / 1e12, "peak": MFMA_F16_PEAK_TF / 3.0,
+                    "unit": "TFLOP/s (fp32-equivalent conv FLOPs)", "frac": flops / t_c1v / 1e12 / (MFMA_F16_PEAK_TF / 3.0),
+                    "traffic": None, "us_per_launch": t_c1v * 1e6}
+                del cov, fv, gridz, gz5
                 roof = dict(roof_step["conv2_form"])
-                roof["note"] = ("the in-step instantiation (conv2 of a PVConv); peak = dense fp16 MFMA peak (2500 TF) / 3 MFMA "
-                                "products per fp32-equivalent product; roofline_plain_kernel = the same layer without "
-                                "prologue / statistics / queue, roofline_conv1_form = the other in-step instantiation")
+                roof["note"] = ("the in-step instantiation (conv2 of a PVConv) on dense RANDOM operands -- the worst case for the "
+                                "board's power management, which holds this launch at 1400 W and ~1.8 GHz; peak = dense fp16 "
+                                "MFMA peak (2500 TF) / 3 MFMA products per fp32-equivalent product; roofline_plain_kernel = the "
+                                "same layer without prologue / statistics / queue (+ zero_input), roofline_conv1_form = the other "
+                                "in-step instantiation, roofline_conv1_form_voxelized_input = the same launch on the operands the "
+                                "model feeds it; mfma_ceiling = what a bare MFMA stream sustains on this board")
+                if mfma_ceiling and "random_fp16_operands" in mfma_ceiling:
+                    ceil_tf = mfma_ceiling["random_fp16_operands"]["TFLOP/s fp16"]
+                    roof["frac_of_power_limited_mfma_rate"] = {
+                        "frac": 3.0 * roof["achieved"] / ceil_tf,
+                        "note": "3 x achieved (fp16 MFMA TFLOP/s of the launch) / the bare MFMA stream's sustained rate on random "
+                                "fp16 operands measured in this run (mfma_ceiling)"}
                 del ones
             del xin
             C, N, r = 64, 2048, 32
@@ -716,6 +760,7 @@ def main():
                                "the exact empty-tile skip saves a trajectory-dependent share of the conv work: "
                                "ms_per_step_dense_convs is the same call with every tile computed (short chain)"},
             "roofline": roof, "roofline_plain_kernel": roof_plain, "roofline_conv1_form": roof_step.get("conv1_form"),
+            "roofline_conv1_form_voxelized_input": roof_step.get("conv1_form_voxelized_input"), "mfma_ceiling": mfma_ceiling,
             "whole_step_mfma_frac": (None if ms_dense is None or B != 32 else
                                      {"frac": 1909.0 / ms_dense / (MFMA_F16_PEAK_TF / 3.0),
                                       "note": "1909 GFLOP of a B=32 step (SURVEY.md 8d) / ms_per_step_dense_convs / (2500/3 TF)"}),

@@ -26,7 +26,7 @@ __device__ __forceinline__ f32x16 mma(u4 a, u4 b, f32x16 c) {
 }
 
 template <int CB, int VB, bool READS, int PRIO>
-__device__ __forceinline__ void tap_stream(const u4 *lds, int lane, int taps, float *sink, unsigned long long *cyc) {
+__device__ __forceinline__ void tap_stream(const u4 *lds, int lane, int taps, float *sink, unsigned long long *cyc, int rnd) {
   f32x16 acc[CB][VB], cor[CB][VB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
@@ -48,7 +48,9 @@ __device__ __forceinline__ void tap_stream(const u4 *lds, int lane, int taps, fl
   for (int r_ = 0; r_ < NR; ++r_) frag(0, r_, 0);
   if (PRIO) __builtin_amdgcn_s_setprio(2);
   const unsigned long long t0 = clock64();
+  const uint32_t base0 = base;
   for (int t2 = 0; t2 < taps; t2 += 2) {
+    if (rnd) base = base0 + (uint32_t)((t2 * 1040) & 0x7ff0); // random-data runs: the fragments change from tap to tap
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int cur = tt, nxt = tt ^ 1;
@@ -105,17 +107,27 @@ __device__ __forceinline__ void valu_stream(int iters, float *sink, int lane) {
 // NW waves per workgroup (4 = one per SIMD, 8 = two per SIMD); waves >= 4 play PARTNER
 template <int NW, int CB, int VB, bool READS, int PARTNER, int PRIO, int REGS_OCC>
 __global__ __launch_bounds__(64 * NW, REGS_OCC) void probe(unsigned long long *out, float *sink, int taps, int valu_iters,
-                                                          unsigned long long *wall) {
+                                                          unsigned long long *wall, int rnd) {
   extern __shared__ __attribute__((aligned(16))) u4 lds[];
-  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 96 * 64; i += blockDim.x) {
     const unsigned short h = 0x2c00 + (i & 7); // small fp16 numbers
-    lds[i] = u4{(unsigned)h | ((unsigned)h << 16), (unsigned)h | ((unsigned)h << 16), (unsigned)h | ((unsigned)h << 16), (unsigned)h | ((unsigned)h << 16)};
+    u4 v = u4{(unsigned)h | ((unsigned)h << 16), (unsigned)h | ((unsigned)h << 16), (unsigned)h | ((unsigned)h << 16), (unsigned)h | ((unsigned)h << 16)};
+    if (rnd) { // pseudo-random fp16 of magnitude 2^-4 .. 2^0, both signs, full mantissas: the operand statistics of real data
+      unsigned x = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+      for (int k = 0; k < 4; ++k) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const unsigned lo = (x & 0x83ffu) | ((11u + ((x >> 10) & 3u)) << 10);
+        const unsigned hi = ((x >> 16) & 0x83ffu) | ((11u + ((x >> 26) & 3u)) << 10);
+        v[k] = lo | (hi << 16);
+      }
+    }
+    lds[i] = v;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long w0 = wall_clock64();
   unsigned long long cyc = 0;
-  if (wave < 4 || PARTNER == 3) tap_stream<CB, VB, READS, PRIO>(lds, lane, taps, sink, &cyc);
+  if (wave < 4 || PARTNER == 3) tap_stream<CB, VB, READS, PRIO>(lds, lane, taps, sink, &cyc, rnd);
   else if (PARTNER == 1) valu_stream(valu_iters, sink, lane);
   if (lane == 0) out[blockIdx.x * NW + wave] = cyc;
   if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) wall[0] = wall_clock64() - w0; // a workgroup from the middle of the launch
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, REGS_OCC) void probe(unsigned long long *o
 struct Res { double cyc_per_mfma_med, cyc_per_mfma_max, ms, tf; };
 
 template <int NW, int CB, int VB, bool READS, int PARTNER, int PRIO, int REGS_OCC>
-static void run(const char *name, int taps, int valu_iters) {
+static void run(const char *name, int taps, int valu_iters, int rnd = 0) {
   const int blocks = 256 * 4;
   unsigned long long *out, *wall;
   float *sink;
@@ -137,10 +149,10 @@ static void run(const char *name, int taps, int valu_iters) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k<<<blocks, 64 * NW, LDS>>>(out, sink, taps, valu_iters, wall); // warm
+  k<<<blocks, 64 * NW, LDS>>>(out, sink, taps, valu_iters, wall, rnd); // warm
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<<<blocks, 64 * NW, LDS>>>(out, sink, taps, valu_iters, wall);
+  k<<<blocks, 64 * NW, LDS>>>(out, sink, taps, valu_iters, wall, rnd);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms = 0;
@@ -168,12 +180,51 @@ static void run(const char *name, int taps, int valu_iters) {
   hipFree(sink);
 }
 
+// what bench.py calls (tools/exp/libmfma_probe.so, built by __graft_entry__.build()): the rate the matrix pipe sustains on
+// the bare tap stream (1 wave per SIMD, 2 x 2 pattern with its fragment reads) for taps = 432 * mult taps per wave
+extern "C" int mfma_ceiling(int random_operands, int mult, double *tf, double *mhz) {
+  constexpr int NW = 4, CB = 2, VB = 2;
+  const int blocks = 256 * 4, taps = 27 * 16 * (mult < 1 ? 1 : mult);
+  unsigned long long *out, *wall;
+  float *sink;
+  if (hipMalloc(&out, blocks * NW * 8) != hipSuccess || hipMalloc(&wall, 8) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) return -1;
+  auto k = probe<NW, CB, VB, true, 0, 0, 1>;
+  const size_t LDS = 100 * 1024;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS) != hipSuccess) return -2;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k<<<blocks, 64 * NW, LDS>>>(out, sink, taps, 0, wall, random_operands); // warm: the clock settles
+  hipEventRecord(e0);
+  k<<<blocks, 64 * NW, LDS>>>(out, sink, taps, 0, wall, random_operands);
+  hipEventRecord(e1);
+  if (hipDeviceSynchronize() != hipSuccess) return -3;
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long hw = 0, c0 = 0;
+  hipMemcpy(&hw, wall, 8, hipMemcpyDeviceToHost);
+  hipMemcpy(&c0, out + (blocks / 2) * NW, 8, hipMemcpyDeviceToHost);
+  *tf = (double)blocks * NW * taps * 3 * CB * VB * 32768.0 / (ms * 1e-3) / 1e12;
+  *mhz = (double)c0 / (hw / 100.0);
+  hipFree(out); hipFree(wall); hipFree(sink);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
+
+#ifndef MFMA_PROBE_LIB
 int main(int argc, char **argv) {
   const int mult = argc > 1 ? atoi(argv[1]) : 1;
   const int taps = 27 * 16 * mult; // 4 chunks of 27 taps x 4 (x mult: sustained runs show the clock the chip settles at)
   // valu partner iterations sized to last about as long as the MFMA wave: 16 values x ~7 VALU per iteration
   const int vi = 1500;
   printf("tap pattern CB x VB: per tap 3 CB VB MFMAs, 2 (CB + VB) ds_read_b128; one workgroup per CU, 1024 workgroups\n");
+  if (argc > 2) { // random-operand runs only: what the matrix pipe sustains under the board's power cap on real-looking data
+    run<4, 2, 2, true, 0, 0, 1>("1 wave/SIMD  2x2 + reads, RANDOM fp16 operands", taps, vi, 1);
+    run<8, 2, 2, true, 3, 0, 1>("2 waves/SIMD 2x2 + reads, both MFMA, RANDOM fp16 operands", taps, vi, 1);
+    run<4, 2, 4, true, 0, 0, 1>("1 wave/SIMD  2x4 + reads (512 regs), RANDOM fp16 operands", taps, vi, 1);
+    run<4, 2, 2, true, 0, 0, 1>("1 wave/SIMD  2x2 + reads, constant operands (again)", taps, vi, 0);
+    return 0;
+  }
   run<4, 2, 2, false, 0, 0, 1>("1 wave/SIMD  2x2 bare", taps, vi);
   run<4, 2, 2, true, 0, 0, 1>("1 wave/SIMD  2x2 + reads", taps, vi);
   run<4, 2, 2, true, 0, 2, 1>("1 wave/SIMD  2x2 + reads prio2", taps, vi);
@@ -191,3 +242,4 @@ int main(int argc, char **argv) {
   run<8, 1, 1, true, 3, 0, 1>("2 waves/SIMD 1x1 + reads, both MFMA", taps, vi);
   return 0;
 }
+#endif
