@@ -598,14 +598,27 @@ def main():
                     "bound": "mfma", "achieved": flops / t_c1v / 1e12, "peak": MFMA_F16_PEAK_TF / 3.0,
                     "unit": "TFLOP/s (fp32-equivalent conv FLOPs)", "frac": flops / t_c1v / 1e12 / (MFMA_F16_PEAK_TF / 3.0),
                     "traffic": None, "us_per_launch": t_c1v * 1e6}
-                del cov, fv, gridz, gz5
+                # ... and conv2 on what conv1 leaves behind for it: its output is exactly bias1 away from the points, so the
+                # activated input minus the constant (delta mode) is exactly zero there
+                y1v = fused_ops.conv3d_fused(gz5, conv, None, True, fused_ops.conv3d_occupancy(ones, 32, 64, B)[0])[0]
+                t_c2v = ev_time_graph(lambda: fused_ops.conv3d_fused(y1v, conv, (pa, pb), True,
+                                                                     fused_ops.conv3d_occupancy(ones, 32, 64, B)[1],
+                                                                     prev_conv=conv), 10) - t_occ
+                roof_step["conv2_form_voxelized_input"] = {
+                    "kernel": "conv3d_split_kernel<..., PRO=true, STATS=true, OCC=2>: Conv3d 3x3x3 64->64 @32^3, B=32, every tile "
+                              "computed, input = conv1's output on the voxelised clouds (AdaGN+Swish prologue, constant + delta: what "
+                              "conv2 of a PVConv reads)",
+                    "bound": "mfma", "achieved": flops / t_c2v / 1e12, "peak": MFMA_F16_PEAK_TF / 3.0,
+                    "unit": "TFLOP/s (fp32-equivalent conv FLOPs)", "frac": flops / t_c2v / 1e12 / (MFMA_F16_PEAK_TF / 3.0),
+                    "traffic": None, "us_per_launch": t_c2v * 1e6}
+                del cov, fv, gridz, gz5, y1v
                 roof = dict(roof_step["conv2_form"])
                 roof["note"] = ("the in-step instantiation (conv2 of a PVConv) on dense RANDOM operands -- the worst case for the "
                                 "board's power management, which holds this launch at 1400 W and ~1.8 GHz; peak = dense fp16 "
                                 "MFMA peak (2500 TF) / 3 MFMA products per fp32-equivalent product; roofline_plain_kernel = the "
                                 "same layer without prologue / statistics / queue (+ zero_input), roofline_conv1_form = the other "
-                                "in-step instantiation, roofline_conv1_form_voxelized_input = the same launch on the operands the "
-                                "model feeds it; mfma_ceiling = what a bare MFMA stream sustains on this board")
+                                "in-step instantiation, roofline_conv{1,2}_form_voxelized_input = the same launches on the operands the "
+                                "model feeds them; mfma_ceiling = what a bare MFMA stream sustains on this board")
                 if mfma_ceiling and "random_fp16_operands" in mfma_ceiling:
                     ceil_tf = mfma_ceiling["random_fp16_operands"]["TFLOP/s fp16"]
                     roof["frac_of_power_limited_mfma_rate"] = {
@@ -760,7 +773,8 @@ def main():
                                "the exact empty-tile skip saves a trajectory-dependent share of the conv work: "
                                "ms_per_step_dense_convs is the same call with every tile computed (short chain)"},
             "roofline": roof, "roofline_plain_kernel": roof_plain, "roofline_conv1_form": roof_step.get("conv1_form"),
-            "roofline_conv1_form_voxelized_input": roof_step.get("conv1_form_voxelized_input"), "mfma_ceiling": mfma_ceiling,
+            "roofline_conv1_form_voxelized_input": roof_step.get("conv1_form_voxelized_input"),
+            "roofline_conv2_form_voxelized_input": roof_step.get("conv2_form_voxelized_input"), "mfma_ceiling": mfma_ceiling,
             "whole_step_mfma_frac": (None if ms_dense is None or B != 32 else
                                      {"frac": 1909.0 / ms_dense / (MFMA_F16_PEAK_TF / 3.0),
                                       "note": "1909 GFLOP of a B=32 step (SURVEY.md 8d) / ms_per_step_dense_convs / (2500/3 TF)"}),

@@ -4,39 +4,43 @@
 # The driver's command runs UNTRACED first (<tag>_bench_steps20_line.json): rocprofv3 changes how graphs replay (round 2's
 # "9.22 ms" line had been taken under the tracer; untraced the same build gave 11.5), so the traced run of the same command is
 # stored as <tag>_bench_steps20_TRACED_line.json and only serves the per-kernel tables.
+# SHORT=1 (second argument "short"): only what a change of the sampling path's kernels moves -- the two bench lines, the traced step,
+# operator / conv benches, traffic and MFMA-busy passes (training lines, probes and the 1x1 / wgrad benches keep their last set).
 TAG=${1:-r04}
+SHORT=0; [ "${2:-}" = short ] && SHORT=1
 R=$PWD; O=$R/gpurun_out/profiles; mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
 python bench.py > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
-python bench.py --mode demo > $O/${TAG}_bench_demo.json 2>> $O/${TAG}_bench_default.err
-python bench.py --mode train_vae > $O/${TAG}_bench_train_vae.json 2>> $O/${TAG}_bench_default.err
-python bench.py --mode train_prior > $O/${TAG}_bench_train_prior.json 2>> $O/${TAG}_bench_default.err
-python bench.py --mode train_prior_clip > $O/${TAG}_bench_train_prior_clip.json 2>> $O/${TAG}_bench_default.err
+[ $SHORT = 1 ] || python bench.py --mode demo > $O/${TAG}_bench_demo.json 2>> $O/${TAG}_bench_default.err
+[ $SHORT = 1 ] || python bench.py --mode train_vae > $O/${TAG}_bench_train_vae.json 2>> $O/${TAG}_bench_default.err
+[ $SHORT = 1 ] || python bench.py --mode train_prior > $O/${TAG}_bench_train_prior.json 2>> $O/${TAG}_bench_default.err
+[ $SHORT = 1 ] || python bench.py --mode train_prior_clip > $O/${TAG}_bench_train_prior_clip.json 2>> $O/${TAG}_bench_default.err
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-dense-check > $O/${TAG}_bench_steps20_TRACED_line.json 2> /dev/null )
 python tools/kstats.py $O/step_trace 70 > $O/${TAG}_bench_steps20_kernel_stats.txt 2>&1
 python tools/trace_gaps.py $O/step_trace begin_step_kernel --top 45 --last 9 > $O/${TAG}_bench_steps20_timeline.txt 2>&1
 python tools/conv_split_bench.py > $O/${TAG}_conv_split_bench.txt 2>/dev/null
 python tools/sparse_conv_bench.py > $O/${TAG}_sparse_conv_bench.txt 2>/dev/null
 python tools/kbench.py > $O/${TAG}_kbench.txt 2>/dev/null
-python tools/victims_beside_conv.py --replays 40 > $O/${TAG}_victims_beside_conv.txt 2>/dev/null
-python tools/pw_bench.py > $O/${TAG}_pw_bench.txt 2>/dev/null
-python tools/wgrad_bench.py > $O/${TAG}_wgrad_bench.txt 2>/dev/null
-./tools/exp/grid_barrier_probe > $O/${TAG}_grid_barrier_probe.txt 2>/dev/null
-python tools/vox_clump_bench.py --no-traj > $O/${TAG}_vox_clump_bench.txt 2>/dev/null
-python tools/determinism_probe.py 32 5 > $O/${TAG}_determinism_probe.json 2>/dev/null
-timeout 120 python tools/rccl_capture_probe.py > $O/${TAG}_rccl_capture_probe.json 2>/dev/null
+[ $SHORT = 1 ] || python tools/victims_beside_conv.py --replays 40 > $O/${TAG}_victims_beside_conv.txt 2>/dev/null
+[ $SHORT = 1 ] || python tools/pw_bench.py > $O/${TAG}_pw_bench.txt 2>/dev/null
+[ $SHORT = 1 ] || python tools/wgrad_bench.py > $O/${TAG}_wgrad_bench.txt 2>/dev/null
+[ $SHORT = 1 ] || ./tools/exp/grid_barrier_probe > $O/${TAG}_grid_barrier_probe.txt 2>/dev/null
+[ $SHORT = 1 ] || python tools/vox_clump_bench.py --no-traj > $O/${TAG}_vox_clump_bench.txt 2>/dev/null
+[ $SHORT = 1 ] || python tools/determinism_probe.py 32 5 > $O/${TAG}_determinism_probe.json 2>/dev/null
+[ $SHORT = 1 ] || timeout 120 python tools/rccl_capture_probe.py > $O/${TAG}_rccl_capture_probe.json 2>/dev/null
 cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
 # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes) of the kernels the bench line's rooflines are about -- the in-step
 # forms: bench.py reads profiles/r*_{conv_instep,vox_scatter_64_2048_32,devox_affine_64_2048_32}_traffic.json into roofline.traffic
 bash tools/prof_traffic.sh conv_instep conv3d_split_kernel -- python tools/one_conv_instep.py > /dev/null 2>&1
 bash tools/prof_traffic.sh vox_scatter_64_2048_32 vox_scatter -- python tools/one_vox.py 64 2048 32 scatter > /dev/null 2>&1
-bash tools/prof_traffic.sh vox_64_2048_32 vox_fused -- python tools/one_vox.py 64 2048 32 > /dev/null 2>&1
-bash tools/prof_traffic.sh devox_affine_64_2048_32 devox_ring -- python tools/one_devox.py 64 2048 32 affine > /dev/null 2>&1
-bash tools/prof_traffic.sh global_prior skinny -- python tools/one_global_prior.py > /dev/null 2>&1
-for n in conv_instep vox_scatter_64_2048_32 vox_64_2048_32 devox_affine_64_2048_32 global_prior; do cp gpurun_out/traffic/$n.json $O/${TAG}_${n}_traffic.json; done
+[ $SHORT = 1 ] || bash tools/prof_traffic.sh vox_64_2048_32 vox_fused -- python tools/one_vox.py 64 2048 32 > /dev/null 2>&1
+bash tools/prof_traffic.sh devox_affine_64_2048_32 devox_ring -- python tools/one_devox.py 64 2048 32 planned > /dev/null 2>&1
+[ $SHORT = 1 ] || bash tools/prof_traffic.sh global_prior skinny -- python tools/one_global_prior.py > /dev/null 2>&1
+for n in conv_instep vox_scatter_64_2048_32 vox_64_2048_32 devox_affine_64_2048_32 global_prior; do [ -f gpurun_out/traffic/$n.json ] && cp gpurun_out/traffic/$n.json $O/${TAG}_${n}_traffic.json; done
 # MFMA-busy of the dominant conv on both kernels (own PMC passes, no tracing)
 ( cd /tmp; export TMPDIR=/tmp
-  for k in split fp32 instep; do
+  KS="split fp32 instep"; [ $SHORT = 1 ] && KS="split instep"
+  for k in $KS; do
     S=1; [ $k = fp32 ] && S=0
     DRV="$R/tools/one_conv.py 64 64 32"; [ $k = instep ] && DRV="$R/tools/one_conv_instep.py"
     LION_CONV_SPLIT=$S timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/pmc_$k -- python $DRV > /dev/null 2>&1
