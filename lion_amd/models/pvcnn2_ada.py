@@ -37,6 +37,7 @@ _POINT_STREAMS = {}
 # the entry, so its address cannot be handed to another tensor while the entry exists.
 _VOX_PLANS = None
 VOX_PLAN = os.environ.get("LION_VOX_PLAN", "1") != "0"   # A/B switch: 0 = every voxelisation recomputes its indices
+OCC_PLAN = os.environ.get("LION_OCC_PLAN", "1") != "0"       # A/B switch: 0 = every PVConv recomputes its tile occupancy
 DEVOX_PLAN = os.environ.get("LION_DEVOX_PLAN", "1") != "0"   # A/B switch: 0 = every r = 32 devoxelisation redoes its per-cloud setup
 
 
@@ -48,6 +49,23 @@ def voxel_plans():
         yield
     finally:
         _VOX_PLANS = prev
+
+
+def _occupancy(counts, r, cout, b):
+    """tile occupancy + work lists (fused_ops.conv3d_occupancy) of the count grid of a (cloud, r) pair: the same for every
+    PVConv that voxelises this pair (the sparse tile plan depends on r only), so while a forward's plans are alive it is
+    computed once and every use takes a COPY -- a convolution consumes the queue counter at the end of its buffer, the
+    pristine pair keeps it at zero."""
+    if _VOX_PLANS is None or not OCC_PLAN:
+        return fused_ops.conv3d_occupancy(counts, r, cout, b)
+    key = ("occ", counts.data_ptr(), tuple(counts.shape), int(r), int(b))
+    hit = _VOX_PLANS.get(key)
+    if hit is None:
+        o1, o2 = fused_ops.conv3d_occupancy(counts, r, cout, b)
+        hit = (counts, o1._base if o1._base is not None else torch.stack([o1, o2]))   # [2, n]; counts stays alive with the entry
+        _VOX_PLANS[key] = hit
+    both = hit[1].clone()
+    return both[0], both[1]
 
 
 def _devox_plan(voxel_coords, r):
@@ -366,7 +384,7 @@ class PVConv(nn.Module):
         r = self.resolution
         occ1 = occ2 = None
         if SPARSE_CONV1 and counts is not None and r >= 16:
-            occ1, occ2 = fused_ops.conv3d_occupancy(counts, r, conv1.out_channels, grid.shape[0])
+            occ1, occ2 = _occupancy(counts, r, conv1.out_channels, grid.shape[0])
         y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, occ1)  # skips all-zero tiles
         f1, g1 = gn1.affine(style)
         a1, b1, _ = fused_ops.groupnorm_fold(st1, gn1.norm, f1, g1, r ** 3)
