@@ -332,6 +332,10 @@ int lion_pwconv_split_forward(const float *x, const uint16_t *wp, const float *b
  * softmax over the N points of every k row, ctx = softmax(k) v^T (D x D), out = ctx^T q.  D = 32 (every
  * LinearAttention of the models); one workgroup per (batch, head), fp32 MFMA. */
 int lion_linear_attention_core(const float *qkv, int B, int H, int D, int N, float *out, lionStream_t stream);
+/* its gradient (training): gout f32[B, H*D, N] -> gqkv f32[B, 3*H*D, N] (softmax backward included; the row dot product
+ * sum_n p gp is the 32 x 32 contraction sum_e gctx[d][e] ctx[d][e]: no second sweep over the points). */
+int lion_linear_attention_core_backward(const float *qkv, const float *gout, int B, int H, int D, int N, float *gqkv,
+                                        lionStream_t stream);
 /* nn.Linear on [B,K] (time-embedding MLP, batched AdaGN style projections): y[b][o] = act(bias[o] + sum_k x[b][k] W[o][k]),
  * wp = lion_pwconv_pack_weights(W f32[O,K]); act 0 none / 1 relu / 2 leaky-relu(slope).  One launch, fixed summation
  * order (4 K-quarters combined in order). */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "lion_pwconv_split_stat_tiles": (_i, [_i, _i, _i]),
     "lion_pwconv_split_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lion_linear_attention_core": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_linear_attention_core_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_linear_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "lion_affine_swish": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "lion_affine_swish_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -133,6 +133,11 @@ class LinearAttention(nn.Module):
         x = x.unsqueeze(-1)  # [B, C, N, 1]
         b, c, h, w = x.shape
         qkv = self.to_qkv(x)
+        from .. import train_ops
+        if w == 1 and self.to_qkv.out_channels == 3 * self.heads * 32 and train_ops.attention_trainable(qkv.squeeze(-1), self.heads, 32):
+            # training: the core (softmax over N, ctx, out) and its gradient on csrc/attention.hip
+            out = train_ops.linear_attention_core(qkv.squeeze(-1), self.heads)
+            return self.to_out(out.unsqueeze(-1)).squeeze(-1)
         q, k, v = rearrange(qkv, 'b (qkv heads c) h w -> qkv b heads c (h w)', heads=self.heads, qkv=3)
         k = k.softmax(dim=-1)
         context = torch.einsum('bhdn,bhen->bhde', k, v)

@@ -160,3 +160,46 @@ def pwconv_trainable(conv, x) -> bool:
 
 def pwconv(conv, x):
     return _PwConv.apply(x, conv.weight, conv.bias)
+
+
+ATTENTION = os.environ.get("LION_TRAIN_ATTENTION", "1") != "0"   # LinearAttention core (forward + backward) on own kernels
+
+
+class _LinAttnCore(torch.autograd.Function):
+    """softmax_N(k), ctx = k v^T, out = ctx^T q of LinearAttention (reference models/pvcnn2_ada.py:62-68) between its two
+    1x1 convolutions: csrc/attention.hip forward and backward (one workgroup per (batch, head) each) instead of a
+    rearrange copy, a softmax, two einsums and their five autograd kernels."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        lib = _lib.load()
+        qkv = qkv.contiguous()
+        b, n = qkv.shape[0], qkv.shape[2]
+        out = torch.empty((b, heads * 32, n), device=qkv.device, dtype=torch.float32)
+        _lib.check(lib.lion_linear_attention_core(_lib.ptr(qkv), b, heads, 32, n, _lib.ptr(out),
+                                                  _lib.stream_ptr(qkv.device)), "linear_attention_core")
+        ctx.save_for_backward(qkv)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (qkv,) = ctx.saved_tensors
+        lib = _lib.load()
+        gout = gout.contiguous()
+        b, n = qkv.shape[0], qkv.shape[2]
+        gqkv = torch.empty_like(qkv)
+        _lib.check(lib.lion_linear_attention_core_backward(_lib.ptr(qkv), _lib.ptr(gout), b, ctx.heads, 32, n, _lib.ptr(gqkv),
+                                                           _lib.stream_ptr(qkv.device)), "linear_attention_core_backward")
+        return gqkv, None
+
+
+def linear_attention_core(qkv, heads):
+    """[B, 3*heads*32, N] -> [B, heads*32, N], differentiable in qkv"""
+    return _LinAttnCore.apply(qkv, heads)
+
+
+def attention_trainable(qkv, heads, dim_head) -> bool:
+    return (ENABLED and ATTENTION and dim_head == 32 and qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3
+            and torch.is_grad_enabled() and not torch.is_autocast_enabled())

@@ -178,3 +178,50 @@ def test_affine_act_rows_beyond_the_grid_y_limit():
     t = xx * A[:, None] + Bs[:, None]
     ref = t * torch.sigmoid(t)
     assert (y - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,N", [(3, 2, 1024), (2, 4, 100), (1, 1, 2048), (2, 2, 16)])
+def test_linear_attention_core_backward_matches_float64_autograd(B, H, N):
+    """training path of LinearAttention (reference models/pvcnn2_ada.py:62-68): forward and gradient of the core on
+    csrc/attention.hip against float64 autograd of the reference's expressions; and the module in grad mode against
+    its torch formulation (LION_TRAIN_ATTENTION=0)."""
+    import torch
+    from lion_amd import train_ops
+    torch.manual_seed(B * 100 + H * 10 + N)
+    qkv = (torch.randn(B, 3 * H * 32, N, device="cuda") * 1.5).requires_grad_(True)
+    gout = torch.randn(B, H * 32, N, device="cuda")
+    out = train_ops.linear_attention_core(qkv, H)
+    (gq,) = torch.autograd.grad(out, qkv, gout)
+    q64 = qkv.detach().double().requires_grad_(True)
+    q, k, v = q64.view(B, 3, H, 32, N).unbind(1)
+    ks = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", ks, v)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(B, H * 32, N)
+    (gref,) = torch.autograd.grad(ref, q64, gout.double())
+    assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+    assert (gq.double() - gref).abs().max().item() / gref.abs().max().item() < 2e-5
+    # per block of the gradient (q, k, v parts have different scales)
+    for part in range(3):
+        a, r = gq.view(B, 3, H * 32, N)[:, part].double(), gref.view(B, 3, H * 32, N)[:, part]
+        assert (a - r).abs().max().item() / r.abs().max().item() < 5e-5, part
+
+
+def test_linear_attention_module_training_path_matches_torch_formulation():
+    import torch
+    from lion_amd import train_ops
+    from lion_amd.models.pvcnn2_ada import LinearAttention
+    torch.manual_seed(7)
+    att = LinearAttention(64).cuda().train()
+    x = torch.randn(2, 64, 512, device="cuda")
+    outs = []
+    for flag in (True, False):
+        train_ops.ATTENTION = flag
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = att(xi)
+            gx, gw = torch.autograd.grad(y.square().sum(), [xi, att.to_qkv.weight])
+            outs.append((y.detach(), gx, gw))
+        finally:
+            train_ops.ATTENTION = True
+    for a, b in zip(outs[0], outs[1]):
+        assert (a - b).abs().max().item() / b.abs().max().item() < 1e-4
