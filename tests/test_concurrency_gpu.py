@@ -19,6 +19,19 @@ def test_fps_beside_the_dma_convolution_in_a_graph(C, R):
     assert all(r == (0, 0) for r in res), res
 
 
+@pytest.mark.parametrize("victim", ["bq", "nn", "group", "grouppts", "devox", "vox"])
+def test_operator_beside_the_split_convolution_in_a_graph(victim):
+    """every operator that can run on the geometry stream (or beside it) while conv3d_split_kernel's fp16 MFMA stream fills
+    the CUs -- ball query, 3-NN + interpolation, grouping, and the LDS-DMA ring of the r = 32 devoxelize / the voxelize
+    kernel -- replayed inside one hipGraph beside 6 convolutions: bit-identical to its stand-alone result in every replay, and
+    the convolutions' output unchanged (tools/victims_beside_conv.py; only FPS was ever observed wrong, DESIGN.md section 3 -- this keeps
+    the others honest when their kernels change)."""
+    import victims_beside_conv
+    rep = victims_beside_conv.run([victim], B=32, replays=10)[victim]
+    assert rep["replays_with_wrong_victim_output"] == 0 and rep["wrong_words"] == 0, rep
+    assert rep["replays_with_wrong_conv_output"] == 0, rep
+
+
 def test_local_prior_graph_replay_equals_eager():
     """the whole local denoiser (geometry prefetch + point branch on side streams) captured once and replayed 40 times:
     every replay == the eager forward, bit for bit"""
