@@ -107,6 +107,10 @@ def test_host_side_plan_functions():
     assert lib.lion_conv3d_wgrad_workspace_floats(32, 64, 64, 32) == 32 * 1 * 64 * 64 * 27 + 64   # one partial per workgroup (round 3) + the split kernel's maxima / scales (round 4)
     assert lib.lion_conv3d_wgrad_workspace_floats(32, 32, 32, 32) == 32 * 4 * 32 * 32 * 27 + 64  # 4 spatial splits
     assert lib.lion_conv3d_wgrad_workspace_floats(32, 3, 32, 32) == 0      # Cin % 4 != 0: library fallback
+    # devoxelize plans (r = 32, N <= 2048): per cloud a 16-byte header, 2304 piece ids, 8 corner offsets and a status per point
+    assert lib.lion_devoxelize_plan_bytes(32, 2048, 32) == 32 * (16 + 2304 * 2 + 2048 * 16 + 2048)
+    assert lib.lion_devoxelize_plan_bytes(3, 999, 32) == 3 * (16 + 2304 * 2 + 2048 * 16 + 2048)
+    assert lib.lion_devoxelize_plan_bytes(32, 2048, 16) == 0 and lib.lion_devoxelize_plan_bytes(32, 4096, 32) == 0
     # pointwise conv: column tiles of 4 waves x VB x 32 columns
     assert lib.lion_pwconv_stat_tiles(64, 35, 32768) == 32768 // 512
     assert lib.lion_pwconv_stat_tiles(128, 64, 8000) == -(-8000 // 256)
