@@ -111,6 +111,49 @@ def hbm_roofline(kernel, algorithmic_bytes, seconds):
             "us_per_call": seconds * 1e6, "algorithmic_bytes": algorithmic_bytes}
 
 
+# the voxelisations / devoxelisations of ONE denoiser forward at configs[1] (top): (C, N, r) per call,
+# in call order; the four (cloud, r) pairs they share are the N / r combinations
+VOX_TUPLES = [(4, 2048, 32), (32, 2048, 32), (128, 1024, 16), (192, 256, 8)] + 3 * [(128, 64, 8)] + 3 * [(128, 256, 8)] + \
+    2 * [(128, 1024, 16)] + 2 * [(64, 2048, 32)]
+DEVOX_TUPLES = 2 * [(32, 2048, 32)] + [(64, 1024, 16), (128, 256, 8)] + 3 * [(128, 64, 8)] + 3 * [(128, 256, 8)] + \
+    2 * [(128, 1024, 16)] + 2 * [(64, 2048, 32)]
+
+
+def vox_devox_totals(bk, fused_ops, B, dev):
+    """roofline_voxelize_forward_total / roofline_devoxelize_forward_total: ALL 14 + 14 calls of one denoiser forward, launched
+    the way the step launches them (one index plan per (cloud, r) pair + one scatter per feature tensor; one devoxelisation
+    plan per r = 32 cloud + the affine devoxelisation per grid), captured in ONE hipGraph each and timed by its replay:
+    sum of SURVEY.md 8d algorithmic bytes (1092.6 MB / 746.1 MB at B = 32) / the in-graph time of the whole set."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    clouds = {}
+    for _, N, r in VOX_TUPLES:
+        if (N, r) not in clouds:
+            clouds[(N, r)] = torch.randn(B, 3, N, device=dev, generator=g)
+    vfeat = [torch.randn(B, C, N, device=dev, generator=g) for C, N, r in VOX_TUPLES]
+    vbytes = sum(4.0 * B * (3 * N + C * N + C * r ** 3 + N + r ** 3) for C, N, r in VOX_TUPLES)
+
+    def vox_all():
+        plans = {k: bk.voxel_index(co, k[1], True, 0.0) for k, co in clouds.items()}
+        return [bk.voxel_scatter(f, plans[(N, r)]) for f, (C, N, r) in zip(vfeat, VOX_TUPLES)]
+    tv = ev_time_graph(vox_all, 3)
+    plans = {k: bk.voxel_index(co, k[1], True, 0.0) for k, co in clouds.items()}
+    dgrid = [torch.randn(B, C, r, r, r, device=dev, generator=g) for C, N, r in DEVOX_TUPLES]
+    dsc = [(torch.rand(B, C, device=dev, generator=g) + 0.5, torch.randn(B, C, device=dev, generator=g)) for C, N, r in DEVOX_TUPLES]
+    dbytes = sum(4.0 * B * (3 * N + C * min(r ** 3, 8 * N) + C * N) for C, N, r in DEVOX_TUPLES)
+
+    def devox_all():
+        dplans = {k: fused_ops.devoxelize_plan(plans[k]["norm"], k[1]) for k in clouds if k[1] == 32}
+        return [fused_ops.devoxelize_affine(gr, plans[(N, r)]["norm"], r, a_, b_, plan=dplans.get((N, r)))
+                for gr, (a_, b_), (C, N, r) in zip(dgrid, dsc, DEVOX_TUPLES)]
+    td = ev_time_graph(devox_all, 3)
+    rv = hbm_roofline("all 14 voxelisations of one denoiser forward (4 index plans + 14 vox_scatter launches, one graph)", vbytes, tv)
+    rd = hbm_roofline("all 14 devoxelisations of one denoiser forward (1 plan + 14 affine devoxelisations, one graph)", dbytes, td)
+    for r_ in (rv, rd):
+        r_["us_per_forward"] = r_.pop("us_per_call")
+        r_["note"] = "sum of SURVEY.md 8d algorithmic bytes over the calls / replay time of the graph that holds them all"
+    return rv, rd
+
+
 def build_models(cfg, device):
     from lion_amd.models.lion import LION
     torch.manual_seed(0)
@@ -193,6 +236,76 @@ def cpu_baseline(cfg, budget_s=25.0):
                     "trilinear_devoxelize (K4) C=64 N=2048 r=32": {"ms": t_devox * 1e3, "GB/s": dbytes / t_devox / 1e9}}}
     finally:
         bk._backend = saved
+
+
+def train_cpu_baseline(mode, cfg, budget_s=40.0):
+    """ONE forward + backward of the same training step on the host cores at B = 1 (PyTorch-CPU dense layers + autograd,
+    the C oracle's operators -- forward and backward -- through oracle.TorchBackend), the bounded sample BASELINE.md
+    section 3 allows for the training configs; samples/s = 1 / (fwd + bwd seconds), optimizer step excluded (it is
+    B-independent and would dominate a B = 1 sample)."""
+    import oracle
+    import lion_amd.functional.backend as bk
+    from lion_amd import _fallback, training
+    saved, was_strict = bk._backend, _fallback.strict()
+    bk._backend = oracle.TorchBackend()      # cpu_baseline leg only: the oracle is the thing TIMED here
+    _fallback.strict(False)
+    try:
+        torch.manual_seed(0)
+        x = torch.randn(1, 2048, 3)
+        if mode == "train_vae":
+            from lion_amd.models.vae_adain import Model as VAE
+            model = VAE(cfg).train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+            def fb():
+                return training.vae_forward_backward(model, opt, x, step=0)
+        else:
+            from lion_amd.models.lion import LION
+            lion = LION(cfg, device="cpu")
+            lion.vae.eval()
+            for p_ in lion.vae.parameters():
+                p_.requires_grad_(False)
+            model = lion.priors.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+            clip = torch.randn(1, 512) if mode == "train_prior_clip" else None
+
+            def fb():
+                return training.prior_forward_backward(lion.vae, model, lion.diffusion, opt, x, clip_feat=clip)
+        t0 = time.perf_counter()
+        fb()
+        first = time.perf_counter() - t0
+        sec, n = first, 1
+        if first < 0.4 * budget_s:          # a second pass with warm thread pools, if the budget allows
+            t0 = time.perf_counter()
+            fb()
+            sec, n = time.perf_counter() - t0, 2
+        return {"value": 1.0 / sec, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"forward + backward of ONE sample (B=1 x 2048 points) on the host, pass {n} of {n}: {sec:.2f} s "
+                          f"(first pass {first:.2f} s); dense layers PyTorch-CPU autograd ({torch.get_num_threads()} threads), "
+                          "point-voxel operators and their gradients oracle/liboracle.so; optimizer step excluded",
+                "seconds_fwd_bwd_B1": sec}
+    finally:
+        bk._backend = saved
+        _fallback.strict(was_strict)
+
+
+def run_side_lines(modes, steps, timeout_s):
+    """the OTHER configurations of BASELINE.json as short side runs of this script (own process each: own memory pool, a
+    failure or a timeout costs its own line only): returns {mode: parsed JSON line | {"error": ...}}."""
+    import subprocess
+    out = {}
+    for mode in modes:
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", mode, "--steps", str(steps), "--warmup", "3"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s,
+                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out[mode] = json.loads(line[-1]) if line else {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+        except Exception as e:
+            out[mode] = {"error": repr(e)}
+        out[mode]["side_run_seconds"] = time.perf_counter() - t0
+    return out
 
 
 def _spawn(args):
@@ -300,14 +413,18 @@ def train_bench(args, rank, world, dev, backend):
     # the PRODUCT's captured step (lion_amd/training.py::GraphedTrainStep): whole-step graph at world 1 and with RCCL
     # (bucket all-reduces captured as a side branch), [fwd + bwd] -> eager all-reduce -> [optimizer] graphs on backends
     # whose collectives cannot be captured (gloo); eager only with --no-graph or if capture fails (`launch` says so)
+    inputs = {"x": x}
     if vae_mode:
-        def fb(x):
-            return training.vae_forward_backward(model, opt, x, step=0, averager=averager)
+        # the (annealed) KL weight of a step lives in device memory: a captured step reads it there (set_scalar per step)
+        inputs["kl_weight"] = torch.full((), float(getattr(model, "kl_weight", 1.0)), device=dev)
+
+        def fb(x, kl_weight):
+            return training.vae_forward_backward(model, opt, x, step=0, averager=averager, kl_weight=kl_weight)
     else:
         def fb(x):
             return training.prior_forward_backward(lion.vae, model, lion.diffusion, opt, x, averager=averager,
                                                    clip_feat=clip_feat)
-    stepper = training.GraphedTrainStep(fb, {"x": x}, params, opt, averager, mode="off" if args.no_graph else None,
+    stepper = training.GraphedTrainStep(fb, inputs, params, opt, averager, mode="off" if args.no_graph else None,
                                         warmup=max(W, 3))
     launch = stepper.launch
     static_loss = [None]
@@ -343,21 +460,37 @@ def train_bench(args, rank, world, dev, backend):
             gy = torch.randn(32, 64, 32, 32, 32, device=dev)
             tw = ev_time(lambda: conv_ops.conv3d_k3_wgrad(xin, gy, (64, 64, 3, 3, 3)), 10, warm=3)
         flops = 2.0 * 27 * 64 * 64 * 32 ** 3 * 32
+        wg_split = bool(conv_ops.WGRAD_SPLIT)     # which weight-gradient kernel conv3d_k3_wgrad dispatched to (Cin = 64)
+        wg_peak = MFMA_F16_PEAK_TF / 3.0 if wg_split else MFMA_F32_PEAK_TF
+        wg_kernel = ("conv3d_wgrad_split_kernel: weight gradient of Conv3d 3x3x3 64->64 @32^3, B=32 -- fp32 operands cut into fp16 "
+                     "hi/lo pairs, 3 products per fp32 product on the 16-bit MFMA pipe, f32 accumulate (csrc/conv3d_wgrad.hip); "
+                     "peak = 2500 TF / 3" if wg_split else
+                     "conv3d_wgrad_kernel: weight gradient of Conv3d 3x3x3 64->64 @32^3, B=32 (exact-fp32 MFMA, csrc/conv3d_wgrad.hip)")
+        dt = "f32"
+        if conv_ops.SPLIT:
+            dt = ("f32 (voxel-conv forward / data-gradient" + (" / weight-gradient" if wg_split else "") + " operands cut into fp16 "
+                  "hi/lo pairs on the 16-bit MFMA pipe, f32 accumulate -- fp32-accurate, tests/test_conv_split_gpu.py" +
+                  ("" if wg_split else "; weight gradient exact-fp32 MFMA") + ")")
+        cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "unmeasured (--no-cpu-baseline)"}
+        if world > 1:
+            cpu["sample"] = "not timed at --gpus > 1; see the --gpus 1 line"
+        elif not args.no_cpu_baseline:
+            try:
+                cpu = train_cpu_baseline(args.mode, cfg)
+            except Exception as e:  # the baseline must never take the benchmark down
+                cpu["sample"] = f"unmeasured: {e!r}"
+        from lion_amd import _fallback
         out = {"metric": "samples/sec, one data-parallel training step (fwd + bwd + grad averaging + Adam)",
                "value": world * B / (ms / 1e3), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 (voxel-conv forward / data-gradient operands cut into fp16 pairs on the 16-bit MFMA pipe, f32 "
-                        "accumulate; weight gradient exact-fp32 MFMA)" if conv_ops.SPLIT else "f32",
-               "data": "synthetic",
+               "dtype": dt, "data": "synthetic",
                "config": {"workload": name, "samples_per_gpu": B, "points": 2048, "launch": launch,
                           "gradient_averaging": f"BucketedGradAverager, {len(averager.buckets)} buckets, world {world}",
-                          "final_loss": loss_v},
-               "roofline": {"kernel": "conv3d_wgrad_kernel: weight gradient of Conv3d 3x3x3 64->64 @32^3, B=32 "
-                                      "(fp32 MFMA, csrc/conv3d_wgrad.hip)", "bound": "mfma", "achieved": flops / tw / 1e12,
-                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / tw / 1e12 / MFMA_F32_PEAK_TF,
-                            "traffic": None, "us_per_launch": tw * 1e6},
-               "cpu_baseline": {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-                                "sample": "not timed for the training modes (the sampling line carries the host baseline)"}}
+                          "final_loss": loss_v, "vendor_library_fallbacks": _fallback.counts()},
+               "roofline": {"kernel": wg_kernel, "bound": "mfma", "achieved": flops / tw / 1e12,
+                            "peak": wg_peak, "unit": "TFLOP/s (fp32-equivalent conv FLOPs)" if wg_split else "TFLOP/s",
+                            "frac": flops / tw / 1e12 / wg_peak, "traffic": None, "us_per_launch": tw * 1e6},
+               "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
@@ -381,6 +514,13 @@ def main():
     ap.add_argument("--no-sparse", action="store_true",
                     help="run the voxel convolutions densely (no exact skip of all-zero input tiles)")
     ap.add_argument("--no-dense-check", action="store_true", help="skip the short dense (--no-sparse) side measurement")
+    ap.add_argument("--shapes-total", type=int, default=0,
+                    help="strong scaling: N shapes in total, split over the ranks (lion_amd.sampling.shard_batch); 0 (default) = "
+                         "weak scaling, --batch shapes per GPU")
+    ap.add_argument("--no-side-lines", action="store_true",
+                    help="skip the short side runs of the training configurations (configs[2..4]) that the 1-GPU sampling line "
+                         "carries as train_lines / config.train_*_samples_per_s")
+    ap.add_argument("--side-steps", type=int, default=5, help="timed steps of each training side run")
     ap.add_argument("--no-full-chain", action="store_true",
                     help="with --steps < 1000: skip the one real 1000-step chain that is run (untimed region) for config.full_chain_1000")
     args = ap.parse_args()
@@ -418,6 +558,12 @@ def main():
     lion = build_models(cfg, dev)
     d = lion.diffusion
     B, K, W = args.batch, args.steps, args.warmup
+    strong = args.shapes_total > 0
+    if strong:      # strong scaling: the job is --shapes-total shapes, every rank takes its contiguous share
+        from lion_amd.sampling import shard_batch
+        B = shard_batch(args.shapes_total, rank, world)
+        assert B >= 1, "--shapes-total must give every rank at least one shape"
+    total_shapes = args.shapes_total if strong else world * B
     assert 1 <= K <= 1000
     shapes = lion.vae.latent_shape()
     graph = not args.no_graph
@@ -462,11 +608,12 @@ def main():
         elapsed, decode_s, runs = float(tt[0]), float(tt[1]), [float(v) for v in tt[2:]]
     chain_s = max(elapsed - decode_s, 1e-9)
     ms_per_step = chain_s / K * 1e3
-    value = world * B / elapsed if K == 1000 else world * B / (1000.0 * ms_per_step / 1e3 + decode_s)
+    value = total_shapes / elapsed if K == 1000 else total_shapes / (1000.0 * ms_per_step / 1e3 + decode_s)
 
     out = None
     if rank == 0:
         from lion_amd.functional.backend import _backend as bk
+        from lion_amd import _fallback
         with torch.no_grad():
             # how much of the step the exact sparse evaluation saves on THIS trajectory (random-weight latents drift
             # into concentrated clouds): a short dense chain, same call
@@ -717,6 +864,7 @@ def main():
                            "K11+K12 three_nn_interpolate C=192 M=1024 N=2048": {"us": tnn * 1e6},
                            "note": "latency / VALU bound (SURVEY.md 8d): reported as times at B=32, graph replay"}
             del ea, eb, p2, cen, cf
+            roofv_total, roofd_total = vox_devox_totals(bk, fused_ops, B, dev)
             # HBM bytes per launch of the dominant kernels: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes cannot run inside
             # this process; tools/prof_traffic.sh writes them to profiles/ and the line quotes the file it read
             def traffic_of(name):
@@ -738,7 +886,12 @@ def main():
         out = {
             "metric": "shapes/sec @1000-step DDIM, Bx2048pts", "value": value, "unit": "shapes/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            # the real 1000-step chain: whole job / rank 0's wall time of one ddim_step = 1000 call (ranks are independent and
+            # equally loaded); with --steps 1000 it is `value` itself
+            "value_full_chain_1000": (value if K == 1000 else (None if full_chain is None else
+                                                               total_shapes / full_chain["seconds"])),
+            "ms_per_step_full_chain": (ms_per_step if K == 1000 else (full_chain or {}).get("ms_per_step")),
             "dtype": ("f32 (operands of the 3x3x3 voxel convolutions" +
                       (" and of the long 1x1 convolutions" if fused_ops.PW_SPLIT else "") +
                       " cut into fp16 hi/lo pairs on the 16-bit MFMA pipe with f32 accumulation -- fp32-accurate, "
@@ -748,7 +901,7 @@ def main():
             "config": {"workload": "configs[1]: unconditional airplane prior sampling, 1000-step DDIM chain "
                                    "(global PriorSEDrop + local PVCNN2Prior) + VAE decode, through the product "
                                    "sampler lion_amd.sampling.generate_samples_vada_2prior",
-                       "shapes_per_gpu": B, "points": 2048, "chain_steps": 1000,
+                       "shapes_per_gpu": B, "shapes_total": total_shapes, "points": 2048, "chain_steps": 1000,
                        "timed_steps_per_prior": K, "extrapolated": K != 1000, "decode_seconds": decode_s,
                        "timed_region_seconds": elapsed,
                        "timed_region_seconds_all_runs": runs,
@@ -759,6 +912,14 @@ def main():
                                    "note": "split graph: the FPS / ball-query chain of a step replays as its own graphs on a "
                                            "second stream beside the first PVConv (lion_amd/chain.py)"},
                        "voxel_index_plans": pvcnn2_ada.VOX_PLAN,
+                       # the metric's REAL chain, as scalars the driver's record keeps: one call of the product
+                       # sampler with ddim_step = 1000 on rank 0 (with --steps 1000 it IS the timed region)
+                       "full_chain_1000_shapes_per_s": (value if K == 1000 else (full_chain or {}).get("shapes_per_s")),
+                       "full_chain_1000_ms_per_step": (ms_per_step if K == 1000 else (full_chain or {}).get("ms_per_step")),
+                       "full_chain_1000_seconds": (elapsed if K == 1000 else (full_chain or {}).get("seconds")),
+                       "voxelize_forward_total_frac_of_hbm": roofv_total["frac"],
+                       "devoxelize_forward_total_frac_of_hbm": roofd_total["frac"],
+                       "vendor_library_fallbacks_in_step": sum(_fallback.counts().values()),
                        "full_chain_1000": full_chain,
                        "parallelism": f"{world} independent rank(s), no data-path collective",
                        "launch": "hipGraph replay of [step prologue, denoiser forward, update + Philox noise] (the local "
@@ -779,6 +940,7 @@ def main():
                                      {"frac": 1909.0 / ms_dense / (MFMA_F16_PEAK_TF / 3.0),
                                       "note": "1909 GFLOP of a B=32 step (SURVEY.md 8d) / ms_per_step_dense_convs / (2500/3 TF)"}),
             "roofline_fp32_kernel": roof32, "roofline_voxelize": roofv, "roofline_devoxelize": roofd,
+            "roofline_voxelize_forward_total": roofv_total, "roofline_devoxelize_forward_total": roofd_total,
             "roofline_backward_operators": roofb, "roofline_chamfer": roof_cd, "roofline_emd": roof_emd,
             "latency_bound_operators": latency_ops,
         }
@@ -791,6 +953,16 @@ def main():
             except Exception as e:  # the baseline must never take the benchmark down
                 out["cpu_baseline"] = {"value": None, "unit": "shapes/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
+        if world == 1 and not args.no_side_lines:
+            # configs[2..4] beside the metric's line: short side runs of --mode train_* (own process each), their values
+            # hoisted as scalars into config so that the driver's record of THIS line carries them
+            torch.cuda.empty_cache()
+            side = run_side_lines(["train_vae", "train_prior", "train_prior_clip"], args.side_steps, 240)
+            out["train_lines"] = side
+            for mode_, line_ in side.items():
+                out["config"][f"{mode_}_samples_per_s"] = line_.get("value")
+                out["config"][f"{mode_}_ms_per_step"] = line_.get("ms_per_step")
+                out["config"][f"{mode_}_wgrad_roofline_frac"] = (line_.get("roofline") or {}).get("frac")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()

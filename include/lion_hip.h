@@ -221,7 +221,11 @@ int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *b
  * empty produce exactly bias.  occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] (per-tile flags: 1 = some voxel of
  * the tile's halo holds a point; a work list, occupied tiles first; a queue counter) is derived from the
  * voxelisation's cnt i32[B,r^3]; passing it to ONE fused forward (only without pro_a/pro_b) skips the K loop of
- * empty tiles and balances the occupied ones over all CUs through the queue -- bit-identical output. */
+ * empty tiles and balances the occupied ones over all CUs through the queue -- bit-identical output.
+ * Round 5: the buffer also carries, per (sample, tile), the 256-bit map of the tile's ACTIVE voxels (a point within
+ * the margin): the split kernel packs only those into its 32-column MFMA blocks (voxel-level skipping inside an
+ * occupied tile; every other voxel of the tile is written as bias / constant response) -- outputs stay bit-identical,
+ * the GroupNorm tile sums agree to fp32 rounding (different summation order). */
 size_t lion_conv3d_occupancy_ints(int r, int Cout, int B);
 /* The second convolution sees swish(AdaGN(conv1)): a per-channel constant c = swish(A*bias1+Bs) wherever conv1 saw no
  * point, plus a sparse delta.  lion_conv3d_const_response turns c into tconst f32[B][27][Cout], the exact response of

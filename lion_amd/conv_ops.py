@@ -189,6 +189,8 @@ class _Conv3dK3(torch.autograd.Function):
         lib_mask = [ctx.needs_input_grad[0] and not own_dgrad, ctx.needs_input_grad[1] and not own_wgrad,
                     want_gb and not own_wgrad]
         if any(lib_mask):
+            from . import _fallback
+            _fallback.note("conv_ops._Conv3dK3.backward", f"convolution_backward mask {lib_mask} for {cin}->{cout} at r={r}")
             gx, gw, gb = torch.ops.aten.convolution_backward(
                 gy, x, weight, [weight.shape[0]] if ctx.has_bias else None,
                 [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, lib_mask)
@@ -220,6 +222,9 @@ def conv3d_module(conv: torch.nn.Conv3d, x):
           and supported(conv.in_channels, conv.out_channels, x.shape[2])
           and not torch.is_autocast_enabled())
     if not ok:
+        from . import _fallback
+        _fallback.note("conv_ops.conv3d_module", f"Conv3d {conv.in_channels}->{conv.out_channels} k={conv.kernel_size} on "
+                       f"{tuple(x.shape)} {x.dtype} {x.device.type}, autocast={torch.is_autocast_enabled()}")
         return conv(x)
     if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
         # always the module's own weight tensor: the packed / mirrored copies are cached per (storage, version),

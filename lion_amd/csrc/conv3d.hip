@@ -423,23 +423,29 @@ __global__ __launch_bounds__(256) void gn_fold_se_kernel(const float *__restrict
   }
 }
 
-// One workgroup per sample: (1) which (d, h) columns of the count grid hold a point (tiles span the whole w axis),
-// (2) per spatial tile: any point within `margin` voxels of the tile, for margin 1 (the conv that reads the voxelised
-// grid) and margin 2 (the delta of the second conv), (3) the sample's work list for each margin -- occupied tiles
-// first, empty ones after -- and the reset of the queue counter.  No atomics, no host memset, deterministic order.
-// occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter].
+// One workgroup per sample: (1) which voxels of each (d, h) row of the count grid hold a point (one bit per w: tiles span
+// the whole w axis and r <= 32), (2) per spatial tile: any point within `margin` voxels of the tile, for margin 1 (the conv
+// that reads the voxelised grid) and margin 2 (the delta of the second conv), (3) the sample's work list for each margin --
+// occupied tiles first, empty ones after -- and the reset of the queue counter, (4) round 5: per tile and margin the 256-bit
+// map of its ACTIVE voxels -- those with a point within `margin` (Chebyshev) -- bit t = voxel t of the tile in (d, h, w)
+// order, from which the split kernel packs the active voxels of a tile into 32-column MFMA blocks.  No global atomics,
+// no host memset, deterministic order.
+// occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter, 3 pad][B*tiles*8 voxel bit words].
 __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__restrict__ cnt, int r, int TD, int TH,
                                                              int32_t *__restrict__ occ1, int32_t *__restrict__ occ2) {
-  __shared__ int col[32 * 32];
+  __shared__ unsigned col[32 * 32];   // bit w of col[d * r + h]: voxel (d, h, w) holds a point
   __shared__ int flag[2][256];
   const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
   const int nth = r / TH, ntiles = (r / TD) * nth, total = B * ntiles;
-  for (int i = tid; i < r * r; i += 1024) col[i] = 0;
+  for (int i = tid; i < r * r; i += 1024) col[i] = 0u;
   __syncthreads();
   const int4 *c4 = reinterpret_cast<const int4 *>(cnt + (size_t)b * r * r * r);
   for (int i = tid; i < (r * r * r) >> 2; i += 1024) {
     const int4 v = c4[i];
-    if (v.x | v.y | v.z | v.w) col[(i << 2) / r] = 1; // benign race: everybody writes 1
+    if (v.x | v.y | v.z | v.w) { // r % 4 == 0: the four voxels lie in one row
+      const unsigned m4 = (v.x ? 1u : 0u) | (v.y ? 2u : 0u) | (v.z ? 4u : 0u) | (v.w ? 8u : 0u);
+      atomicOr(&col[(i << 2) / r], m4 << ((i << 2) % r)); // LDS integer atomic: the result does not depend on the order
+    }
   }
   __syncthreads();
   // per tile and margin: a 4-bit mask, bit w = wave w's 64-voxel block (64 / r rows of one d-plane) has a point within
@@ -451,12 +457,31 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
     int mask = 0;
     for (int w = 0; w < 4; ++w) {
       const int dl = dt + (w * RW) / TH, hl = ht + (w * RW) % TH;
-      int any = 0;
+      unsigned any = 0u;
       for (int d = max(dl - margin, 0); d <= min(dl + margin, r - 1); ++d)
         for (int h = max(hl - margin, 0); h <= min(hl + RW - 1 + margin, r - 1); ++h) any |= col[d * r + h];
       mask |= (any ? 1 : 0) << w;
     }
     flag[margin - 1][t] = mask;
+  }
+  // (4) the active-voxel bits: one (row, margin) per step -- the union of the (2 margin + 1)^2 neighbouring rows' point
+  // bits, spread by `margin` along w; a tile's 256 voxels are 256 / r rows of r bits = 8 words (r = 16: two rows per word)
+  const unsigned rmask = r == 32 ? 0xffffffffu : ((1u << r) - 1u);
+  for (int e = tid; e < 2 * r * r; e += 1024) {
+    const int row = e % (r * r), margin = 1 + e / (r * r);
+    int32_t *occ = margin == 1 ? occ1 : occ2;
+    if (!occ) continue;
+    const int d = row / r, h = row % r;
+    unsigned u = 0u;
+    for (int dd = max(d - margin, 0); dd <= min(d + margin, r - 1); ++dd)
+      for (int hh = max(h - margin, 0); hh <= min(h + margin, r - 1); ++hh) u |= col[dd * r + hh];
+    unsigned a = u | (u << 1) | (u >> 1);
+    if (margin == 2) a |= (u << 2) | (u >> 2);
+    a &= rmask;
+    const int tile = (d / TD) * nth + h / TH, lr = (d % TD) * TH + h % TH; // row lr of the tile's 256 / r rows
+    unsigned short *bits16 = reinterpret_cast<unsigned short *>(occ + 2 * total + 4 + ((size_t)b * ntiles + tile) * 8);
+    if (r == 32) reinterpret_cast<unsigned *>(bits16)[lr] = a;
+    else bits16[lr] = (unsigned short)a; // little endian: row 2 k in the low half of word k
   }
   __syncthreads();
   // the lists, occupied tiles first, both parts in ascending tile order: thread (margin, tile) finds its slot from the
@@ -645,7 +670,8 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
                                       nullptr, stream);
 }
 
-// occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] = [B*tiles flags][B*tiles work list][3 counters], tiles =
+// occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] = [B*tiles flags][B*tiles work list][queue counter, 3 pad][B*tiles*8
+// active-voxel bit words (bit t of a tile's 256 bits = voxel t in (d, h, w) order has a point within the margin)], tiles =
 // lion_conv3d_stat_tiles(r,Cout,B,sparse): flag 1 if any voxel of the tile's halo holds a point (cnt i32[B,r^3] from the
 // voxelisation).  Feed to ONE lion_conv3d_k3_fused_forward (the convolution that reads the voxelised grid): the call
 // consumes the work queue.
@@ -664,7 +690,8 @@ int lion_conv3d_const_response(const float *wsum, const float *bias2, const floa
 
 size_t lion_conv3d_occupancy_ints(int r, int Cout, int B) {
   if (r != 16 && r != 32) return 0;
-  return (size_t)2 * B * conv_plan(r, Cout, B, true).tiles + 1;
+  // [flags][list][queue counter + 3 pad words][8 active-voxel bit words per (sample, tile)]
+  return (size_t)10 * B * conv_plan(r, Cout, B, true).tiles + 4;
 }
 
 // occ_m1 / occ_m2 (either may be NULL): the occupancy + work list for margin 1 (conv on the voxelised grid) and

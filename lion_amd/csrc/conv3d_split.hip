@@ -50,6 +50,18 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
 // instrumented COPY of this file (0 item prologue, 1 waits at the chunk's two plane barriers, 2 load issue + wait + activate +
 // max, 3 max barrier, 4 cut + LDS write, 5 wait for the next weight group + group barrier, 6 taps, 7 epilogue); the product build carries no instrumentation and no switches.
 
+template <int N> struct IntC { static constexpr int value = N; }; // compile-time count for generic lambdas
+
+// Round 5 -- voxel compaction inside an occupied tile (sparse launches, occ != NULL).  In the chain the latent clouds sit
+// in a few hundred voxels: of the tiles that are NOT empty, 3-7 % (r = 32) / 10-22 % (r = 16) of the voxels have a point
+// within the margin (tools/tile_shape_estimate.py on the dumped x_t), yet the wave masks of round 3 skip a 64-voxel block
+// only when all of it is clear.  The occupancy buffer now carries the tile's 256-bit ACTIVE map; the workgroup packs the
+// active voxels (ascending order) into 32-voxel column blocks, block j -> wave j % 4, slot j / 4, and a wave runs the tap
+// loop for the blocks it got -- none, one (half the MFMAs) or two.  A lane's MFMA column may be any voxel of the tile (its
+// fragment address is its halo position); lanes beyond the active count repeat the last active voxel and store nothing.
+// Every voxel that is not active is written as bias / constant response by the thread that owns it (thread t <-> voxel t),
+// and enters the GroupNorm sums in closed form (counts per border configuration x table).  Outputs are bit-identical to the
+// dense evaluation (same K order per voxel, same tile scale); the tile sums differ in summation order only.
 template <int TD, int TH, int TW, int CB, int VB, bool PRO, bool STATS, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
                                                               const float *__restrict__ wtail,
@@ -80,6 +92,9 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   float *sT = reinterpret_cast<float *>(sx);  // [27][COT] constant response (delta mode), loaded after the K loop
   __shared__ int s_work;
   __shared__ unsigned s_max[2];               // bits of the chunk's max |activation| (double buffered over chunks)
+  __shared__ unsigned char s_list[256];       // sparse launches: the tile's active voxels, ascending
+  __shared__ int s_wcnt[4];                   // active voxels among each wave's 64
+  __shared__ int s_cls[27];                   // voxels that are NOT active, per border configuration
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 5, l32 = lane & 31;
   const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_wscale_kernel)
@@ -111,6 +126,26 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   const int ntw = r / TW, nth = r / TH;
   const int d0 = (tile / (ntw * nth)) * TD, h0 = ((tile / ntw) % nth) * TH, w0 = (tile % ntw) * TW;
   const int r3 = r * r * r;
+  // thread t owns voxel t of the tile ((d, h, w) order) for the bookkeeping of the sparse plan
+  int n_act = 4 * VB * 32;
+  if (queued) {
+    const unsigned *abits = reinterpret_cast<const unsigned *>(occ + 2 * B * ntiles + 4) + ((size_t)b * ntiles + tile) * 8;
+    const bool t_act = (abits[tid >> 5] >> (tid & 31)) & 1u;
+    const unsigned long long bal = __ballot(t_act);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    if (tid < 27) s_cls[tid] = 0;
+    __syncthreads();
+    int before = 0;
+    n_act = 0;
+#pragma unroll
+    for (int w_ = 0; w_ < 4; ++w_) { const int c = s_wcnt[w_]; before += w_ < wave ? c : 0; n_act += c; }
+    if (t_act) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)tid;
+    // (visible to the tap loop behind the first barrier of chunk(); an empty tile never reads it)
+  }
+  n_act = __builtin_amdgcn_readfirstlane(n_act);
+  // column blocks of 32 active voxels: block j -> wave j % 4, slot j / 4 (dense launches: wave w owns blocks VB w ..)
+  const int nblk = (n_act + 31) >> 5;
+  const int my_nvb = queued ? (wave < nblk ? 1 : 0) + (wave + 4 < nblk ? 1 : 0) : VB;
   const bool pro_on = PRO && pro_a != nullptr; // the PRO instantiation also serves launches without a prologue (see
   const bool delta = pro_on && tconst != nullptr; // launch_split_t: its register allocation is the better one)
   if (pro_on) {
@@ -141,9 +176,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[cb][vb][i] = cor[cb][vb][i] = 0.f;
 
-  const int wmask = queued ? occ[b * ntiles + tile] : 0xf;
-  const bool empty = wmask == 0;
-  const bool wave_on = (wmask >> wave) & 1;
+  const bool empty = n_act == 0;
   const int nchunks = empty ? 0 : Cin / KS;
   // this thread's u4 of a weight slice: element (pg, co) of the tile <- global [pg][Cout] at co0 + co
   const int we_g = (tid / COT) * Cout + co0 + (tid % COT);
@@ -178,13 +211,15 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   };
   if (nchunks) { weights_dma(0); weights_dma(1); } // nchunks >= 1 -> at least 9 groups
   // @phase 0
-  // One chunk of the K walk.  WORK = false is the copy run by a wave whose 64-voxel block sees no point (wave mask): it
-  // stages and takes part in every barrier and in the weight DMA, but owns no MFMA and no accumulator.  The two copies are
-  // separate LOOPS (the branch on wave_on sits outside them): with the branch inside the chunk -- per tap or around the
-  // 27 taps -- the register allocator split the accumulators' live ranges around the working path and parked five of
+  // One chunk of the K walk, for a wave that got NVB column blocks of the tile's active voxels.  NVB = 0 is the copy run by
+  // a wave without a block: it stages and takes part in every barrier and in the weight DMA, but owns no MFMA and no
+  // accumulator; NVB = 1 runs the taps on one column block (CB x 1 accumulator tiles, half the MFMAs).  The copies are
+  // separate LOOPS (the branch on the block count sits outside them): with the branch inside the chunk -- per tap or around
+  // the 27 taps -- the register allocator split the accumulators' live ranges around the working path and parked five of
   // the eight tuples in scratch across the staging of every chunk (684-792 bytes, 64->64 at 1070 us instead of 705).
-  auto chunk = [&](int q, auto work_c) {
-    constexpr bool WORK = decltype(work_c)::value;
+  auto chunk = [&](int q, auto nvb_c) {
+    constexpr int NVB = decltype(nvb_c)::value;
+    constexpr bool WORK = NVB > 0;
     __syncthreads(); // the previous chunk's planes are no longer read (and the prologue scalars are visible)
     // @phase 1
     {
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int vb = 0; vb < VB; ++vb)
+            for (int vb = 0; vb < NVB; ++vb)
 #pragma unroll
               for (int i = 0; i < 16; ++i) { acc[cb][vb][i] *= f; cor[cb][vb][i] *= f; }
         }
@@ -296,13 +331,17 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       typedef __attribute__((address_space(3))) const u4 lds_u4;
       // opaque per-chunk base addresses: every fragment read = base + 16-bit immediate.  Left to itself the compiler
       // hoists 27 tap offsets x (VB + CB) addresses out of the chunk loop and spills them.
-      uint32_t xq[VB], wq2[2];
+      uint32_t xq[NVB > 0 ? NVB : 1], wq2[2];
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const int g_ = ln >> 5, l32_ = ln & 31;
 #pragma unroll
-      for (int vb = 0; vb < VB; ++vb) { // halo position of this lane's voxel in the wave's column block vb
-        const int v = (wave * VB + vb) * 32 + l32_;
+      for (int vb = 0; vb < NVB; ++vb) { // halo position of this lane's voxel in the wave's column block vb
+        int v = (wave * VB + vb) * 32 + l32_;
+        if (queued) { // the (wave + 4 vb)-th block of the tile's active voxels; lanes past the end repeat the last one
+          const int i = (wave + 4 * vb) * 32 + l32_;
+          v = s_list[i < n_act ? i : n_act - 1];
+        }
         const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
         xq[vb] = sx_lds + (uint32_t)((g_ * HP + (d * HH + h) * HW + w) * 16);
         asm volatile("" : "+v"(xq[vb]));
@@ -311,18 +350,19 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       wq2[1] = sw_lds0 + (uint32_t)(((par ^ 1) * TG * WPL + g_ * COT + l32_) * 16);
       asm volatile("" : "+v"(wq2[0]));
       asm volatile("" : "+v"(wq2[1]));
-      u4 wf[2][CB][2], xf[2][VB][2];
-      constexpr int NR = 2 * VB + 2 * CB; // fragment reads per tap
-      // read r_ of a tap, in the order the tap's MFMAs need them: X_h (VB), W_h (CB) -- the main sweep --, then X_l (VB),
-      // then W_l (CB); LDS returns in order, so the counted wait in front of the first MFMA covers only the first VB + CB
+      constexpr int NX = NVB > 0 ? NVB : 1;
+      u4 wf[2][CB][2], xf[2][NX][2];
+      constexpr int NR = 2 * NVB + 2 * CB; // fragment reads per tap
+      // read r_ of a tap, in the order the tap's MFMAs need them: X_h (NVB), W_h (CB) -- the main sweep --, then X_l (NVB),
+      // then W_l (CB); LDS returns in order, so the counted wait in front of the first MFMA covers only the first NVB + CB
       auto frag = [&](int tap, int s_, int r_) {
-        const int pc = r_ >= VB + CB, rr = pc ? r_ - (VB + CB) : r_;
-        if (rr < VB) {
+        const int pc = r_ >= NVB + CB, rr = pc ? r_ - (NVB + CB) : r_;
+        if (rr < NVB) {
           const int vb = rr;
           const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
           xf[s_][vb][pc] = *(lds_u4 *)(uintptr_t)(xq[vb] + (uint32_t)((pc * 2 * HP + toff) * 16));
         } else {
-          const int cb = rr - VB, k = tap / TG, t = tap % TG;
+          const int cb = rr - NVB, k = tap / TG, t = tap % TG;
           wf[s_][cb][pc] = *(lds_u4 *)(uintptr_t)(wq2[k & 1] + (uint32_t)((t * WPL + pc * 2 * COT + cb * 32) * 16));
         }
       };
@@ -353,12 +393,12 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
           // MFMA m of the tap: the CB VB main products, then the X_lo products, then the W_lo products (two MFMAs into one
           // accumulator are CB VB issues apart)
           auto mfma = [&](int m) {
-            const int kind = m / (CB * VB), cb = (m / VB) % CB, vb = m % VB;
+            const int kind = m / (CB * NX), cb = (m / NX) % CB, vb = m % NX;
             if (kind == 0) acc[cb][vb] = mma(wf[cur][cb][0], xf[cur][vb][0], acc[cb][vb]);
             else if (kind == 1) cor[cb][vb] = mma(wf[cur][cb][0], xf[cur][vb][1], cor[cb][vb]);
             else cor[cb][vb] = mma(wf[cur][cb][1], xf[cur][vb][0], cor[cb][vb]);
           };
-          constexpr int NM = 3 * CB * VB;
+          constexpr int NM = 3 * CB * NX;
 #pragma unroll
           for (int m = 0; m < NM; ++m) {
             // the reads of tap + 1: PER per MFMA slot from slot 1 on (1 at CB = 2: slots 1 .. 8 of 11; 2 at CB = 1), so that
@@ -380,8 +420,9 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       // @phase 6
     }
   };
-  if (wave_on) { for (int q = 0; q < nchunks; ++q) chunk(q, BoolC<true>{}); }
-  else { for (int q = 0; q < nchunks; ++q) chunk(q, BoolC<false>{}); }
+  if (my_nvb == VB) { for (int q = 0; q < nchunks; ++q) chunk(q, IntC<VB>{}); }
+  else if (VB > 1 && my_nvb == 1) { for (int q = 0; q < nchunks; ++q) chunk(q, IntC<1>{}); }
+  else { for (int q = 0; q < nchunks; ++q) chunk(q, IntC<0>{}); }
 
   if (delta) {
     __syncthreads(); // the last tap's LDS reads are done: the operand planes become the response table
@@ -399,9 +440,16 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   // waits for the stores issued before it: 18-23 store / wait / store sequences per epilogue (tools/store_wait_scan.py),
   // each a round trip to memory.
   int gvv[VB];
+  bool valid[VB];
 #pragma unroll
   for (int vb = 0; vb < VB; ++vb) {
-    const int v = (wave * VB + vb) * 32 + l32;
+    int v = (wave * VB + vb) * 32 + l32;
+    valid[vb] = true;
+    if (queued) { // as in the tap loop: the (wave + 4 vb)-th block of the active voxels
+      const int i = (wave + 4 * vb) * 32 + l32;
+      valid[vb] = i < n_act;
+      v = valid[vb] ? s_list[i] : 0;
+    }
     const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
     const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
     gvv[vb] = (gd * r + gh) * r + gw;
@@ -418,22 +466,48 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   }
 #pragma unroll
   for (int vb = 0; vb < VB; ++vb)
+    if (valid[vb]) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+      for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
-        const float o = acc[cb][vb][i];
-        yb[(size_t)co * r3 + gvv[vb]] = o;
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+          const float o = acc[cb][vb][i];
+          yb[(size_t)co * r3 + gvv[vb]] = o;
+        }
+    }
+  bool t_act = true; // (read again rather than kept alive across the K loop: the kernel sits at the 256-register limit)
+  if (queued) {
+    int tt = tid;
+    asm volatile("" : "+v"(tt));
+    const unsigned *abits = reinterpret_cast<const unsigned *>(occ + 2 * B * ntiles + 4) + ((size_t)b * ntiles + tile) * 8;
+    t_act = (abits[tt >> 5] >> (tt & 31)) & 1u;
+  }
+  if (queued && !t_act) {
+    // the voxels no lane computed: thread t writes voxel t of the tile = bias / the constant response of its border
+    // configuration, exactly what the dense evaluation leaves there (its accumulators are exact zeros)
+    const int d = tid / (TH * TW), h = (tid / TW) % TH, w = tid % TW;
+    const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
+    const int cfg = (((gd == 0 ? 0 : gd == r - 1 ? 2 : 1) * 3 + (gh == 0 ? 0 : gh == r - 1 ? 2 : 1)) * 3 +
+                     (gw == 0 ? 0 : gw == r - 1 ? 2 : 1));
+    const float *addv = delta ? sT + cfg * COT : sbias;
+    float *yv = yb + (gd * r + gh) * r + gw;
+#pragma unroll 8
+    for (int co = 0; co < COT; ++co) yv[(size_t)co * r3] = addv[co];
+    if (STATS) atomicAdd(&s_cls[delta ? cfg : 0], 1); // LDS integer atomic: order free, result exact
+  }
   if (STATS) { // per-tile channel sums, as csrc/conv3d.hip
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float s1 = acc[cb][0][i], s2 = acc[cb][0][i] * acc[cb][0][i];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int vb = 1; vb < VB; ++vb) { s1 += acc[cb][vb][i]; s2 += acc[cb][vb][i] * acc[cb][vb][i]; }
+        for (int vb = 0; vb < VB; ++vb) {
+          const float o = valid[vb] ? acc[cb][vb][i] : 0.f;
+          s1 += o;
+          s2 += o * o;
+        }
         s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
         s1 = row_pair_sum_odd_rows(s1); s2 = row_pair_sum_odd_rows(s2);
         if (l32 == 16) { // the row pair's sum lives in the odd rows
@@ -447,6 +521,19 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
+      if (queued && n_act < 4 * VB * 32) { // the voxels written as constants, in closed form: count x value per configuration
+        if (delta) {
+          for (int c = 0; c < 27; ++c) {
+            const float n = (float)s_cls[c], tv = sT[c * COT + tid];
+            s1 += n * tv;
+            s2 += n * (tv * tv);
+          }
+        } else {
+          const float n = (float)s_cls[0], tv = sbias[tid];
+          s1 += n * tv;
+          s2 += n * (tv * tv);
+        }
+      }
       float *o = stats + (((size_t)b * Cout + co0 + tid) * ntiles + tile) * 2;
       o[0] = s1;
       o[1] = s2;

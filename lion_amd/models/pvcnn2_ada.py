@@ -216,12 +216,15 @@ def conv1x1(conv, x):
     from .. import train_ops
     if train_ops.pwconv_trainable(conv, x):  # training: forward, data / weight / bias gradients on own kernels
         return train_ops.pwconv(conv, x)
+    from .. import _fallback
     if (x.is_cuda and torch.is_grad_enabled() and all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
             and all(p == 0 for p in conv.padding) and conv.groups == 1):
+        _fallback.note("pvcnn2_ada.conv1x1 (training matmul)", f"{tuple(conv.weight.shape)} on {tuple(x.shape)}")
         y = torch.matmul(conv.weight.flatten(1), x.flatten(2))
         if conv.bias is not None:
             y = y + conv.bias[:, None]
         return y.reshape(x.shape[0], conv.out_channels, *x.shape[2:])
+    _fallback.note("pvcnn2_ada.conv1x1 (library conv)", f"{tuple(conv.weight.shape)} on {tuple(x.shape)} {x.dtype} {x.device.type}")
     return type(conv).forward(conv, x)  # the class's own forward (conv.forward may be routed here)
 
 

@@ -137,6 +137,12 @@ class Model(nn.Module):
         if kl_weight is not None:
             pass
         elif a.trainer.anneal_kl and self.num_total_iter > 0:
+            if x.is_cuda and torch.cuda.is_current_stream_capturing():
+                # a captured step would replay the weight of THIS iteration for ever: the schedule has to
+                # live in device memory -- pass kl_weight as a 0-d tensor and refresh it per step (GraphedTrainStep.set_scalar)
+                raise RuntimeError("get_loss under graph capture with trainer.anneal_kl: the annealed KL weight is derived "
+                                   "from `it` on the host and would be frozen into the graph; pass kl_weight= as a 0-d "
+                                   "device tensor instead")
             kl_weight = kl_coeff(step=it, total_step=a.sde.kl_anneal_portion_vada * self.num_total_iter,
                                  constant_step=a.sde.kl_const_portion_vada * self.num_total_iter,
                                  min_kl_coeff=a.sde.kl_const_coeff_vada, max_kl_coeff=a.sde.kl_max_coeff_vada)

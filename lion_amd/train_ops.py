@@ -26,13 +26,23 @@ def _rows(t):
     return t.reshape(-1).contiguous()
 
 
+def _bc_view(t, B, C):
+    """the [B, C] a factor / bias stands for, by broadcasting RULES (not by element count: at B == C a [B, 1] and a
+    [1, C] factor have the same number of elements): [B, C], [1, C], [B, 1], [C], scalars, and the same with trailing
+    singleton dimensions ([B, C, 1, 1], [B, 1, 1] ...)"""
+    while t.dim() > 2 and t.shape[-1] == 1:
+        t = t.squeeze(-1)
+    if t.dim() > 2:
+        raise ValueError(f"AdaGN factor / bias of shape {tuple(t.shape)} does not broadcast to [B, C] = [{B}, {C}]")
+    return t.expand(B, C)
+
+
 def _rowview(t, B, C):
     """(pointer holder, row stride) of a [B, C] float32 view whose channel stride is 1 (a chunk of the [B, 2C] AdaGN
     projection is such a view) -- anything else is made contiguous"""
-    if t.numel() != B * C:            # a broadcastable [1, C] / [B, 1] factor: materialise the [B, C] it stands for
-        t = t.expand(B, C) if t.dim() == 2 else t.reshape(-1, C).expand(B, C)
-    t = t.reshape(B, C)
-    if t.dtype != torch.float32 or t.stride(1) != 1:
+    if tuple(t.shape) != (B, C):      # a broadcastable factor: materialise the [B, C] it stands for
+        t = _bc_view(t, B, C)
+    if t.dtype != torch.float32 or t.stride(1) != 1 or (B > 1 and t.stride(0) == 0):
         t = t.float().contiguous()
     return t, int(t.stride(0))
 
@@ -91,13 +101,12 @@ class _AdaGNAct(torch.autograd.Function):
         dpw = pw.sum(0)                                                       # [C, 2]: d norm.weight, d norm.bias
         dgw = dpw[:, 0].contiguous() if ctx.needs_input_grad[1] else None
         dgb = dpw[:, 1].contiguous() if ctx.needs_input_grad[2] else None
-        def back(g, shape):   # the gradient of a broadcast [1, C] / [B, 1] factor is the sum over what it was spread over
-            n = 1
-            for d in shape:
-                n *= int(d)
-            if n == B * C:
-                return g.reshape(shape)
-            return (g.sum(0) if n == C else g.sum(1)).reshape(shape)
+        def back(g, shape):   # the gradient of a broadcast factor: summed over exactly the dimensions it was spread over
+            shape = tuple(int(d) for d in shape)
+            core = shape
+            while len(core) > 2 and core[-1] == 1:
+                core = core[:-1]
+            return g.sum_to_size(core if core else (1,)).reshape(shape)
         dfac = back(dfac, f_shape) if has_f and ctx.needs_input_grad[3] else None
         dbias = back(dbias, b_shape) if has_b and ctx.needs_input_grad[4] else None
         return dx, dgw, dgb, dfac, dbias, None, None, None

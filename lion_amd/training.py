@@ -117,11 +117,18 @@ class GraphedTrainStep:
           but no per-kernel launch cost either.
       mode 'eager' (LION_TRAIN_GRAPH=off, or capture failed: `self.launch` says why): the plain step.
     The optimizer must be capturable (torch.optim.Adam(..., capturable=True)); scalars that change from step to step
-    (annealed KL weight) are 0-d device tensors in `inputs`, refreshed with `set_scalar`.  The gradient layout is frozen
+    (annealed KL weight) are 0-d device tensors in `inputs`, refreshed with `set_scalar`.
+    Construction runs `warmup` eager steps and one or two more for the capture on whatever `inputs` holds -- real
+    updates, Adam moments and step counters included.  With `restore=True` (default) the parameters and the optimizer
+    state are snapshotted first and written back IN PLACE afterwards (the captured graph keeps pointing at the same
+    state tensors), so the caller's first step starts from the weights, moments and step count it handed in, exactly as
+    the eager / reference trainer would (hvae_trainer.py:90-154); `restore=False` keeps the consumed steps.
+    The gradient layout is frozen
     at capture: parameters that received no gradient in the captured step are skipped by every replay (their
     ``grad`` stays None, as the reference's averaging leaves them)."""
 
-    def __init__(self, forward_backward, inputs: dict, params, optimizer, averager=None, mode=None, warmup=3):
+    def __init__(self, forward_backward, inputs: dict, params, optimizer, averager=None, mode=None, warmup=3,
+                 restore=True):
         import os
         import torch.distributed as dist
         self.fb, self.inputs, self.params = forward_backward, dict(inputs), list(params)
@@ -136,6 +143,58 @@ class GraphedTrainStep:
         self.loss = self.aux = None
         self._graphs = []
         dev = next(t.device for t in self.inputs.values() if torch.is_tensor(t))
+        snapshot = self._snapshot() if restore else None
+        try:
+            self._build(mode, dev, world, backend, warmup)
+        finally:
+            if snapshot is not None:
+                self._restore(snapshot)
+                torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+
+    def _opt_params(self):
+        seen, out = set(), []
+        for group in self.opt.param_groups:
+            for p in group['params']:
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        for p in self.params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def _snapshot(self):
+        """parameters and optimizer state as they are handed in (clones; `None` marks state the optimizer had not created yet)"""
+        snap = []
+        for p in self._opt_params():
+            st = self.opt.state.get(p, None)
+            snap.append((p, p.detach().clone(),
+                         None if not st else {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}))
+        return snap
+
+    def _restore(self, snap):
+        """write the snapshot back THROUGH the live tensors: the captured graphs hold their addresses.  State that did not
+        exist before construction (lazily created by the warm-up steps) goes back to its initial value, zero."""
+        with torch.no_grad():
+            for p, value, st in snap:
+                p.copy_(value)
+                live = self.opt.state.get(p, None)
+                if not live:
+                    continue
+                for k, v in live.items():
+                    if torch.is_tensor(v):
+                        if st is not None and torch.is_tensor(st.get(k)):
+                            v.copy_(st[k])
+                        else:
+                            v.zero_()
+                    elif st is not None and k in st:
+                        live[k] = st[k]
+                    elif isinstance(v, (int, float)):
+                        live[k] = type(v)(0)
+        _wcache.invalidate_all()   # packed-weight caches key on parameter versions: the copies above bumped them
+
+    def _build(self, mode, dev, world, backend, warmup):
         for _ in range(max(warmup, 1)):          # eager steps: optimizer state, packed-weight caches, kernel attributes
             self._eager()
         torch.cuda.synchronize(dev)

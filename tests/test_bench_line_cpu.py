@@ -52,3 +52,55 @@ def test_bench_line_numbers_are_consistent():
         # the power-limited rate of a bare MFMA stream cannot exceed the constant-operand rate, nor the nominal peak
         rnd, cst = d["mfma_ceiling"]["random_fp16_operands"], d["mfma_ceiling"]["constant_operands"]
         assert 0 < rnd["TFLOP/s fp16"] <= cst["TFLOP/s fp16"] * 1.02 <= 2600
+
+
+def _roofline_objects(obj, path=""):
+    """every dict below `obj` that looks like a roofline object (has achieved / peak / frac)"""
+    if isinstance(obj, dict):
+        if {"achieved", "peak", "frac"} <= set(obj):
+            yield path, obj
+        for k, v in obj.items():
+            yield from _roofline_objects(v, f"{path}.{k}" if path else k)
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            yield from _roofline_objects(v, f"{path}[{i}]")
+
+
+def _latest_round_lines():
+    """the bench lines (sampling, demo, training modes) of the LATEST round that has them under profiles/"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*.json")))
+    assert files
+    latest = os.path.basename(files[-1]).split("_")[0]
+    out = []
+    for f in files:
+        if os.path.basename(f).split("_")[0] != latest:
+            continue
+        for ln in open(f).read().strip().splitlines():
+            if ln.startswith("{"):
+                out.append((f, json.loads(ln)))
+    return out
+
+
+def test_every_roofline_fraction_is_a_fraction():
+    """round-4 verdict: the committed training lines carried frac = 1.21 (a kernel on the 16-bit pipe divided by the fp32
+    peak).  A fraction of a peak lies in (0, 1]; achieved / peak must reproduce it."""
+    seen = 0
+    for f, d in _latest_round_lines():
+        for path, r in _roofline_objects(d):
+            if r["achieved"] is None:
+                continue
+            seen += 1
+            assert 0.0 < r["frac"] <= 1.0, (f, path, r["frac"])
+            assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 * max(1.0, r["frac"]), (f, path)
+    assert seen >= 3
+
+
+def test_training_lines_name_the_kernel_they_time():
+    for f, d in _latest_round_lines():
+        if "training step" not in d.get("metric", ""):
+            continue
+        r = d["roofline"]
+        split = "split" in r["kernel"]
+        assert abs(r["peak"] - (2500.0 / 3.0 if split else 157.3)) < 1e-6, (f, r["kernel"], r["peak"])
+        c = d["cpu_baseline"]
+        assert c["value"] is not None or c["sample"].startswith(("unmeasured", "not timed")), (f, c)

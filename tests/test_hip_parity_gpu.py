@@ -770,6 +770,83 @@ def test_conv3d_constant_plus_delta_matches_dense(c, r, n, flat, conv_kernel):
     assert torch.allclose(tot_s, tot_d, rtol=1e-3, atol=1e-4 * tot_d.abs().max().item())
 
 
+def _cloud(kind, B, n, gen):
+    """clouds that drive the voxel compaction of the sparse split convolution through its cases: `clumped` = what the
+    latents of the chain look like after ~20 steps (95 % of the points in a tenth of the extent: a few active voxels per
+    occupied tile, most waves without a block); `one-point` (a centre voxel + two corners); `two-corners` (active voxels on the grid's faces / edges /
+    corners only); `full` = every voxel occupied (every tile has its 8 blocks); `gauss`"""
+    if kind == "one-point":   # one point in the middle of the grid (+ the two corner points that pin the normalisation)
+        c = torch.zeros(B, 3, 3, device="cuda")
+        c[:, :, 1], c[:, :, 2] = 1.0, -1.0
+        return c
+    if kind == "two-corners":
+        c = torch.ones(B, 3, 2, device="cuda")
+        c[:, :, 1] = -1.0
+        return c
+    c = torch.randn(B, 3, n, device="cuda", generator=gen)
+    if kind == "clumped":
+        c[:, :, : int(0.95 * n)] *= 0.1
+    if kind == "full":
+        c = torch.rand(B, 3, n, device="cuda", generator=gen) * 2 - 1
+        c[:, :, :8] = torch.tensor([[x, y, z] for x in (-1., 1.) for y in (-1., 1.) for z in (-1., 1.)], device="cuda").t()
+    return c
+
+
+@pytest.mark.parametrize("kind,c,r,n", [("clumped", 64, 32, 2048), ("clumped", 128, 16, 1024), ("one-point", 32, 32, 1),
+                                        ("two-corners", 64, 16, 2), ("full", 32, 16, 60000), ("gauss", 64, 32, 2048),
+                                        ("gauss", 128, 16, 1024), ("clumped", 32, 32, 2048)])
+def test_conv3d_voxel_compaction_matches_dense(kind, c, r, n):
+    """Round 5: the sparse split convolution packs the ACTIVE voxels of a tile (a point within the margin) into its MFMA
+    column blocks and writes every other voxel as bias / constant response.  conv1 (margin 1): outputs bit-identical to
+    the dense launch of the same kernel; conv2 (constant + delta, margin 2): within 1e-5 of float64, borders included;
+    GroupNorm tile sums equal to fp32 summation order in both."""
+    from lion_amd import conv_ops, fused_ops as fo
+    if not conv_ops.SPLIT:
+        pytest.skip("the split kernel is switched off")
+    gen = torch.Generator(device="cuda").manual_seed(r * 7 + c + n)
+    B = 3
+    coords = _cloud(kind, B, n, gen)
+    n = coords.shape[2]
+    feat = torch.randn(B, c, n, device="cuda", generator=gen)
+    # `full`: coordinates in [-1, 1] taken as they are (normalize = False maps them onto the whole grid); otherwise the
+    # reference's normalisation by the cloud's own extent
+    out, _, _, cnt = bk_().voxelize_points_forward(feat, coords, r, kind != "full", 0.0)
+    grid = out.view(B, c, r, r, r)
+    conv1 = torch.nn.Conv3d(c, c, 3, padding=1).cuda()
+    conv2 = torch.nn.Conv3d(c, c, 3, padding=1).cuda()
+    A = torch.rand(B, c, device="cuda", generator=gen) + 0.5
+    Bs = torch.randn(B, c, device="cuda", generator=gen) * 0.5
+    with torch.no_grad():
+        occ1, occ2 = fo.conv3d_occupancy(cnt, r, c, B)
+        nt = (occ1.numel() - 4) // 10 // B
+        words = occ1[2 * B * nt + 4:].view(B, nt, 8).cpu().numpy().astype("uint32")
+        active = int(((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).sum())
+        if kind == "full":
+            assert active == B * r ** 3
+        elif kind in ("one-point", "two-corners"):
+            assert 0 < active <= B * 3 * 27
+        y_d, s_d = fo.conv3d_fused(grid, conv1, None, True, None)
+        y_s, s_s = fo.conv3d_fused(grid, conv1, None, True, occ1)
+        assert torch.equal(y_d, y_s)
+        t_d, t_s = s_d.sum(2), s_s.sum(2)
+        assert torch.allclose(t_d, t_s, rtol=1e-4, atol=1e-5 * t_d.abs().max().item())
+        dense, sd = fo.conv3d_fused(y_s, conv2, (A, Bs), True, None)
+        sparse, ss = fo.conv3d_fused(y_s, conv2, (A, Bs), True, occ2, prev_conv=conv1)
+        ref = torch.nn.functional.conv3d(
+            torch.nn.functional.silu(y_s.double() * A.double().view(B, c, 1, 1, 1) + Bs.double().view(B, c, 1, 1, 1)),
+            conv2.weight.double(), conv2.bias.double(), padding=1)
+    scale = ref.abs().max().item()
+    assert (sparse.double() - ref).abs().max().item() / scale < 1e-5
+    assert (dense.double() - ref).abs().max().item() / scale < 1e-5
+    tot_s, tot_d = ss.sum(2), sd.sum(2)
+    assert torch.allclose(tot_s, tot_d, rtol=1e-3, atol=1e-4 * tot_d.abs().max().item())
+    # run twice: the packing, the fill and the closed-form sums are deterministic
+    with torch.no_grad():
+        occ1b, _ = fo.conv3d_occupancy(cnt, r, c, B)
+        y_s2, s_s2 = fo.conv3d_fused(grid, conv1, None, True, occ1b)
+    assert torch.equal(y_s, y_s2) and torch.equal(s_s, s_s2)
+
+
 @pytest.mark.parametrize("r,cout,n", [(32, 64, 2048), (32, 32, 300), (16, 128, 1024)])
 def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
     """lion_conv3d_tile_occupancy flags (margin 1 and 2) == max-pool dilation of the count grid reduced over
@@ -796,6 +873,12 @@ def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
             k = int(ref[b].sum())
             assert ref[b][lst[b][:k].long()].all() and not ref[b][lst[b][k:].long()].any()
         assert int(occ[2 * B * nt]) == 0
+        # round 5: the 256-bit map of each tile's ACTIVE voxels (a point within the margin), bit t = voxel t of the tile in
+        # (d, h, w) order: the dilation itself, cut into tiles
+        words = occ[2 * B * nt + 4:2 * B * nt + 4 + 8 * B * nt].view(B, nt, 8).cpu().numpy().astype("uint32")
+        bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, nt, 256)
+        want = d.view(B, r // td, td, r // th, th, r).permute(0, 1, 3, 2, 4, 5).reshape(B, nt, 256).cpu().numpy()
+        assert np.array_equal(bits, want.astype(bits.dtype)), m
 
 
 @pytest.mark.parametrize("B,N,M", [(3, 512, 512), (2, 300, 1024), (4, 2048, 2048)])

@@ -225,3 +225,38 @@ def test_linear_attention_module_training_path_matches_torch_formulation():
             train_ops.ATTENTION = True
     for a, b in zip(outs[0], outs[1]):
         assert (a - b).abs().max().item() / b.abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("fshape, bshape", [((16, 1), (1, 16)), ((1, 16), (16, 1)), ((16, 1, 1), (16,)), ((16, 16, 1), (1, 1))])
+def test_adagn_act_broadcast_factors_when_batch_equals_channels(fshape, bshape):
+    """B == C (round-4 advisor finding): a [B, 1] and a [1, C] factor have the same number of elements, so neither the
+    forward's expansion nor the backward's reduction may go by element count.  Against float64 autograd on the
+    broadcast the caller wrote; the gradients come back in the shapes handed in."""
+    from lion_amd import train_ops
+    torch.manual_seed(11)
+    B = C = 16
+    norm = torch.nn.GroupNorm(8, C).cuda()
+    x = torch.randn(B, C, 33, device="cuda").requires_grad_(True)
+    factor = (torch.rand(fshape, device="cuda") + 0.5).requires_grad_(True)
+    bias = (torch.randn(bshape, device="cuda") * 0.3).requires_grad_(True)
+    y = train_ops.adagn_act(x, norm, factor, bias, act=True)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+
+    def full(t):   # the [B, C] the caller's shape stands for under broadcasting
+        t = t.detach()
+        while t.dim() > 2 and t.shape[-1] == 1:
+            t = t.squeeze(-1)
+        return t.expand(B, C).contiguous()
+    yr, leaves = _ref(x, norm, full(factor), full(bias), True)
+    yr.backward(gy.double())
+    tol = lambda ref: 1e-4 * max(ref.abs().max().item(), 1e-3)
+    assert (y.double() - yr).abs().max().item() <= tol(yr)
+    assert (x.grad.double() - leaves[0].grad).abs().max().item() <= tol(leaves[0].grad)
+    for t, leaf in ((factor, leaves[3]), (bias, leaves[4])):
+        assert tuple(t.grad.shape) == tuple(t.shape)
+        core = tuple(t.shape)
+        while len(core) > 2 and core[-1] == 1:
+            core = core[:-1]
+        want = leaf.grad.sum_to_size(core).reshape(t.shape)
+        assert (t.grad.double() - want).abs().max().item() <= 3 * tol(want)

@@ -222,8 +222,25 @@ def test_graphed_train_step_whole_split_and_eager_agree():
             loss = ((net(x) - y) ** 2).mean() * w
             loss.backward()
             return loss.detach(), None
+        if mode == "reference":     # the plain trainer loop from the same initial state: no warm-up, no capture
+            losses = []
+            for i in range(3, 8):
+                loss, _ = fb(xs[i], ys[i], torch.full((), 1.0 + 0.1 * i, device="cuda"))
+                avg.finish()
+                opt.step()
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            return None, [p.detach().clone() for p in net.parameters()], losses
+        init = [p.detach().clone() for p in params]
         st = GraphedTrainStep(fb, {"x": xs[0].clone(), "y": ys[0].clone(), "w": torch.ones((), device="cuda")}, params, opt,
                               avg, mode=mode, warmup=4 if mode == "off" else 3)
+        # construction consumed warm-up / capture steps on the first batch and put everything back: the
+        # parameters, Adam's moments and its step counters are those handed in
+        for p_, i_ in zip(params, init):
+            assert torch.equal(p_.detach(), i_)
+        for p_ in net.parameters():
+            st_ = opt.state[p_]
+            assert float(st_["step"]) == 0.0 and not bool(st_["exp_avg"].any()) and not bool(st_["exp_avg_sq"].any())
         losses = []
         for i in range(3, 8):
             st.set_scalar("w", 1.0 + 0.1 * i)
@@ -234,10 +251,11 @@ def test_graphed_train_step_whole_split_and_eager_agree():
 
     st_w, p_w, l_w = run("whole")
     st_s, p_s, l_s = run("split")
-    st_e, p_e, l_e = run("off")     # (run() gives the eager form the extra warm-up step the captures spend on their side-stream pass)
+    st_e, p_e, l_e = run("off")
+    _, p_r, l_r = run("reference")
     assert st_w.mode == "whole" and len(st_w._graphs) == 1, st_w.launch
     assert st_s.mode == "split" and len(st_s._graphs) == 2, st_s.launch
     assert st_e.mode == "eager"
-    assert l_w == l_s == l_e
-    for a, b, c in zip(p_w, p_s, p_e):
-        assert torch.equal(a, b) and torch.equal(a, c)
+    assert l_w == l_s == l_e == l_r
+    for a, b, c, d_ in zip(p_w, p_s, p_e, p_r):
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d_)
