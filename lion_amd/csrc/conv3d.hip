@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256) void gn_fold_se_kernel(const float *__restrict
 // map of its ACTIVE voxels -- those with a point within `margin` (Chebyshev) -- bit t = voxel t of the tile in (d, h, w)
 // order, from which the split kernel packs the active voxels of a tile into 32-column MFMA blocks.  No global atomics,
 // no host memset, deterministic order.
-// occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter, 3 pad][B*tiles*8 voxel bit words].
+// occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter, 3 pad][B*tiles*8 voxel bit words]
+//         [B occupied-tile counts].
 __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__restrict__ cnt, int r, int TD, int TH,
                                                              int32_t *__restrict__ occ1, int32_t *__restrict__ occ2) {
   __shared__ unsigned col[32 * 32];   // bit w of col[d * r + h]: voxel (d, h, w) holds a point
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
       fl[t] = f;
       list[f ? before : occupied + (t - before)] = t;
       if (b == 0 && t == 0) occ[2 * total] = 0; // the queue of the convolution that consumes this list
+      if (t == 0) occ[10 * total + 4 + b] = occupied; // the sample's occupied tiles (the split kernel queues only those)
     }
   }
 }
@@ -671,7 +673,8 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
 }
 
 // occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] = [B*tiles flags][B*tiles work list][queue counter, 3 pad][B*tiles*8
-// active-voxel bit words (bit t of a tile's 256 bits = voxel t in (d, h, w) order has a point within the margin)], tiles =
+// active-voxel bit words (bit t of a tile's 256 bits = voxel t in (d, h, w) order has a point within the margin)][B counts of
+// occupied tiles], tiles =
 // lion_conv3d_stat_tiles(r,Cout,B,sparse): flag 1 if any voxel of the tile's halo holds a point (cnt i32[B,r^3] from the
 // voxelisation).  Feed to ONE lion_conv3d_k3_fused_forward (the convolution that reads the voxelised grid): the call
 // consumes the work queue.
@@ -690,8 +693,8 @@ int lion_conv3d_const_response(const float *wsum, const float *bias2, const floa
 
 size_t lion_conv3d_occupancy_ints(int r, int Cout, int B) {
   if (r != 16 && r != 32) return 0;
-  // [flags][list][queue counter + 3 pad words][8 active-voxel bit words per (sample, tile)]
-  return (size_t)10 * B * conv_plan(r, Cout, B, true).tiles + 4;
+  // [flags][list][queue counter + 3 pad words][8 active-voxel bit words per (sample, tile)][occupied tiles per sample]
+  return (size_t)10 * B * conv_plan(r, Cout, B, true).tiles + 4 + B;
 }
 
 // occ_m1 / occ_m2 (either may be NULL): the occupancy + work list for margin 1 (conv on the voxelised grid) and

@@ -819,7 +819,7 @@ def test_conv3d_voxel_compaction_matches_dense(kind, c, r, n):
     with torch.no_grad():
         occ1, occ2 = fo.conv3d_occupancy(cnt, r, c, B)
         nt = (occ1.numel() - 4) // 10 // B
-        words = occ1[2 * B * nt + 4:].view(B, nt, 8).cpu().numpy().astype("uint32")
+        words = occ1[2 * B * nt + 4:2 * B * nt + 4 + 8 * B * nt].view(B, nt, 8).cpu().numpy().astype("uint32")
         active = int(((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).sum())
         if kind == "full":
             assert active == B * r ** 3
@@ -879,6 +879,9 @@ def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
         bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, nt, 256)
         want = d.view(B, r // td, td, r // th, th, r).permute(0, 1, 3, 2, 4, 5).reshape(B, nt, 256).cpu().numpy()
         assert np.array_equal(bits, want.astype(bits.dtype)), m
+        # ... and the number of occupied tiles per sample (the split kernel queues only those; the rest is written by its
+        # plane-fill items)
+        assert torch.equal(occ[10 * B * nt + 4:10 * B * nt + 4 + B], ref.sum(1).int()), m
 
 
 @pytest.mark.parametrize("B,N,M", [(3, 512, 512), (2, 300, 1024), (4, 2048, 2048)])
