@@ -678,7 +678,7 @@ def main():
             roof_plain = roof
             if conv_ops.SPLIT:
                 # the same launch on an all-zero input: identical instruction stream and MFMA count, no operand toggling.  The
-                # ratio is what the chip's power management takes from this kernel on random data (the in-kernel
+                # ratio is what the chip's power management takes from this kernel on random data (profiles/HISTORY.md 4g: the in-kernel
                 # clock, s_memtime against the 100 MHz wall clock, falls to 1.45-1.9 GHz under the dense random-data launch
                 # and stays at 2.1-2.4 GHz on sparse / zero data; a bare MFMA stream sustains 2.4 GHz).
                 xz = torch.zeros_like(xin)
@@ -696,7 +696,7 @@ def main():
             # in graphs and subtracted.
             # what the matrix pipe itself sustains on this board: the bare tap stream of the split convolution (MFMAs + their
             # fragment reads, pipe 100 % busy at 32.5 cycles per MFMA) on random fp16 operands runs into the 1400-W cap at
-            # ~1.56 GHz; on constant operands it holds 2.4 GHz (tools/exp/mfma_issue_probe.hip)
+            # ~1.56 GHz; on constant operands it holds 2.4 GHz (tools/exp/mfma_issue_probe.hip, profiles/HISTORY.md 4g)
             mfma_ceiling = None
             try:
                 import ctypes

@@ -220,8 +220,10 @@ int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *b
 /* The first convolution of a PVConv reads the voxelised grid (>= 94 % zeros); spatial tiles whose whole halo is
  * empty produce exactly bias.  occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] (per-tile flags: 1 = some voxel of
  * the tile's halo holds a point; a work list, occupied tiles first; a queue counter) is derived from the
- * voxelisation's cnt i32[B,r^3]; passing it to ONE fused forward (only without pro_a/pro_b) skips the K loop of
- * empty tiles and balances the occupied ones over all CUs through the queue -- bit-identical output.
+ * voxelisation's cnt i32[B,r^3]; passing it to a fused forward (only without pro_a/pro_b) skips the K loop of
+ * empty tiles and balances the occupied ones over all CUs through the queue -- bit-identical output.  The queue
+ * re-arms itself when the launch's last workgroup leaves (round 5): one buffer serves any number of launches in
+ * stream order (never two concurrently).
  * Round 5: the buffer also carries, per (sample, tile), the 256-bit map of the tile's ACTIVE voxels (a point within
  * the margin): the split kernel packs only those into its 32-column MFMA blocks (voxel-level skipping inside an
  * occupied tile; every other voxel of the tile is written as bias / constant response) -- outputs stay bit-identical,

@@ -206,6 +206,24 @@ class GraphedChain:
         """x_init: the chain's start; table [S, 8] float32 rows {t_model, a0..a5, 0}.  Returns the final latent
         (a fresh tensor).  `trajectory`: list that receives a copy of x after every step (before the last
         step's update if `trajectory_before_last`, as run_denoising_diffusion reports it)."""
+        S = self.prepare(x_init, table, seed, condition_input, clip_feat)
+        if RECORD is not None and self.z is not None and noise_trajectory is None:
+            noise_trajectory = []
+            RECORD.append((x_init.detach().clone(), noise_trajectory))
+        for i in range(S):
+            if trajectory is not None and trajectory_before_last and i == S - 1:
+                trajectory.append(self.x.clone())
+            self.replay()
+            if noise_trajectory is not None and self.z is not None:
+                noise_trajectory.append(self.z.clone())
+            if trajectory is not None and not (trajectory_before_last and i == S - 1):
+                trajectory.append(self.x.clone())
+        return self.x.clone()
+
+    @torch.no_grad()
+    def prepare(self, x_init, table: np.ndarray, seed: int, condition_input=None, clip_feat=None) -> int:
+        """everything a chain needs in device memory before its first replay (on the current stream): the start latent, the
+        conditioning, the schedule table, the time-embedding rows, the step counter and the Philox key.  Returns S."""
         S = int(table.shape[0])
         assert 1 <= S <= self.capacity and table.shape[1] == 8
         self.x.copy_(x_init)
@@ -222,18 +240,7 @@ class GraphedChain:
         self.counter.zero_()
         words = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32).view(np.int32)
         self.seed.copy_(torch.from_numpy(words))
-        if RECORD is not None and self.z is not None and noise_trajectory is None:
-            noise_trajectory = []
-            RECORD.append((x_init.detach().clone(), noise_trajectory))
-        for i in range(S):
-            if trajectory is not None and trajectory_before_last and i == S - 1:
-                trajectory.append(self.x.clone())
-            self.replay()
-            if noise_trajectory is not None and self.z is not None:
-                noise_trajectory.append(self.z.clone())
-            if trajectory is not None and not (trajectory_before_last and i == S - 1):
-                trajectory.append(self.x.clone())
-        return self.x.clone()
+        return S
 
 
 class ChainCache:

@@ -304,6 +304,13 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
     }
   }
   } // work loop
+  // Round 5: the queue re-arms itself -- the last workgroup to leave (every other one has popped its final, out-of-range
+  // index) zeroes the queue and the exit counter, so ONE occupancy buffer serves every convolution that shares its
+  // (cloud, resolution) pair without the per-use clone (7 copy launches per denoiser step).
+  if (queued && tid == 0) {
+    int32_t *q = occ + 2 * B * ntiles;
+    if (atomicAdd(q + 1, 1) == (int)gridDim.x - 1) { q[0] = 0; q[1] = 0; }
+  }
 }
 
 // GroupNorm(G groups) + adaptive affine folded into per-(batch, channel) scalars:
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
       int32_t *fl = occ + (size_t)b * ntiles, *list = occ + total + (size_t)b * ntiles;
       fl[t] = f;
       list[f ? before : occupied + (t - before)] = t;
-      if (b == 0 && t == 0) occ[2 * total] = 0; // the queue of the convolution that consumes this list
+      if (b == 0 && t == 0) { occ[2 * total] = 0; occ[2 * total + 1] = 0; } // queue + exit counter of the convolutions that consume this list
       if (t == 0) occ[10 * total + 4 + b] = occupied; // the sample's occupied tiles (the split kernel queues only those)
     }
   }
@@ -676,8 +683,8 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
 // active-voxel bit words (bit t of a tile's 256 bits = voxel t in (d, h, w) order has a point within the margin)][B counts of
 // occupied tiles], tiles =
 // lion_conv3d_stat_tiles(r,Cout,B,sparse): flag 1 if any voxel of the tile's halo holds a point (cnt i32[B,r^3] from the
-// voxelisation).  Feed to ONE lion_conv3d_k3_fused_forward (the convolution that reads the voxelised grid): the call
-// consumes the work queue.
+// voxelisation).  Feed to lion_conv3d_k3_fused_forward (the convolution that reads the voxelised grid): the call pops the
+// work queue and re-arms it on exit.
 // wsum f32[27][Cin][Cout]: weights summed over the taps that stay inside the grid for each border configuration
 // cfg = (cd*3 + ch)*3 + cw (0 low face, 1 interior, 2 high face per axis); bias2 f32[Cout] or NULL (this conv),
 // bias1 f32[Cin] or NULL (the conv that produced the input), pro_a/pro_b f32[B,Cin] -> tconst f32[B][27][Cout].
@@ -698,7 +705,7 @@ size_t lion_conv3d_occupancy_ints(int r, int Cout, int B) {
 }
 
 // occ_m1 / occ_m2 (either may be NULL): the occupancy + work list for margin 1 (conv on the voxelised grid) and
-// margin 2 (delta mode of the following conv), each consumed by ONE fused forward.
+// margin 2 (delta mode of the following conv); a fused forward re-arms the queue it popped (any number of launches in stream order).
 int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
                                lionStream_t stream) {
   if (!cnt || (!occ_m1 && !occ_m2) || B <= 0 || Cout <= 0) return LION_EINVAL;

@@ -658,6 +658,11 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   }
   // @phase 7
   } // work loop
+  // the queue re-arms itself (see csrc/conv3d.hip): the last workgroup to leave zeroes the queue and the exit counter
+  if (queued && tid == 0) {
+    int32_t *q = occ + 2 * B * ntiles;
+    if (atomicAdd(q + 1, 1) == (int)gridDim.x - 1) { q[0] = 0; q[1] = 0; }
+  }
   // @phase-flush
 }
 

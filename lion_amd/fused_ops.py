@@ -27,8 +27,10 @@ def border_weight_sums(weight):
 
 
 def conv3d_occupancy(counts, r, cout, b):
-    """(occ for the conv on the voxelised grid, occ for the delta mode of the following conv), one launch; each is
-    consumed by ONE conv3d_fused call.  counts: int32 [B, r^3] from the voxelisation."""
+    """(occ for the conv on the voxelised grid, occ for the delta mode of the following conv), one launch.  A sparse
+    conv3d_fused call pops its work from the buffer's queue and re-arms it when its last workgroup leaves, so the same
+    buffer serves any number of convolutions one after the other on a stream (never two at once).
+    counts: int32 [B, r^3] from the voxelisation."""
     lib = _lib.load()
     n = lib.lion_conv3d_occupancy_ints(r, cout, b)
     buf = torch.empty((2, n), device=counts.device, dtype=torch.int32)

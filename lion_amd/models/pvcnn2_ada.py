@@ -54,18 +54,17 @@ def voxel_plans():
 def _occupancy(counts, r, cout, b):
     """tile occupancy + work lists (fused_ops.conv3d_occupancy) of the count grid of a (cloud, r) pair: the same for every
     PVConv that voxelises this pair (the sparse tile plan depends on r only), so while a forward's plans are alive it is
-    computed once and every use takes a COPY -- a convolution consumes the queue counter at the end of its buffer, the
-    pristine pair keeps it at zero."""
+    computed once and every convolution of the pair works from the SAME buffers: a sparse convolution re-arms its work
+    queue when its last workgroup leaves (round 5; until then every use took a copy -- 7 copy launches per step)."""
     if _VOX_PLANS is None or not OCC_PLAN:
         return fused_ops.conv3d_occupancy(counts, r, cout, b)
     key = ("occ", counts.data_ptr(), tuple(counts.shape), int(r), int(b))
     hit = _VOX_PLANS.get(key)
     if hit is None:
         o1, o2 = fused_ops.conv3d_occupancy(counts, r, cout, b)
-        hit = (counts, o1._base if o1._base is not None else torch.stack([o1, o2]))   # [2, n]; counts stays alive with the entry
+        hit = (counts, (o1, o2))   # counts stays alive with the entry
         _VOX_PLANS[key] = hit
-    both = hit[1].clone()
-    return both[0], both[1]
+    return hit[1]
 
 
 def _devox_plan(voxel_coords, r):

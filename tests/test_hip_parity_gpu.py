@@ -925,3 +925,39 @@ def test_conv3d_wgrad_matches_fp64_reference(cin, cout, r):
     if cin % 32 == 0:  # the data gradient is a forward conv with Cin output channels
         gx = conv3d_k3(gy, dgrad_weight(w), None)
         assert (gx.double() - xd.grad).abs().max().item() / xd.grad.abs().max().item() < 1e-5
+
+
+def test_conv3d_work_queue_rearms_itself(conv_kernel):
+    """Round 5: a sparse convolution re-arms the queue of its occupancy buffer when its last workgroup leaves, so ONE buffer
+    serves every convolution that shares its (cloud, resolution) pair (a PVCNN2 forward used to clone it 7 times).  Three
+    launches from the same buffer == three launches from fresh buffers, bit for bit; queue and exit counter are zero
+    after each."""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(9)
+    B, c, r, n = 3, 32, 32, 2048
+    coords = torch.randn(B, 3, n, device="cuda") * torch.tensor([1.0, 0.2, 0.6], device="cuda").view(1, 3, 1)
+    feat = torch.randn(B, c, n, device="cuda")
+    out, _, _, cnt = bk_().voxelize_points_forward(feat, coords, r, True, 0.0)
+    grid = out.view(B, c, r, r, r)
+    conv1 = torch.nn.Conv3d(c, c, 3, padding=1).cuda()
+    conv2 = torch.nn.Conv3d(c, c, 3, padding=1).cuda()
+    A = torch.rand(B, c, device="cuda") + 0.5
+    Bs = torch.randn(B, c, device="cuda") * 0.5
+    with torch.no_grad():
+        occ1, occ2 = fo.conv3d_occupancy(cnt, r, c, B)
+        nt = int(_lib_().lion_conv3d_stat_tiles(r, c, B, 1))
+        fresh = lambda: fo.conv3d_occupancy(cnt, r, c, B)
+        for _ in range(3):
+            y_a, s_a = fo.conv3d_fused(grid, conv1, None, True, occ1)
+            y_b, s_b = fo.conv3d_fused(grid, conv1, None, True, fresh()[0])
+            assert torch.equal(y_a, y_b) and torch.equal(s_a, s_b)
+            assert occ1[2 * B * nt:2 * B * nt + 2].tolist() == [0, 0]
+            z_a, t_a = fo.conv3d_fused(y_a, conv2, (A, Bs), True, occ2, prev_conv=conv1)
+            z_b, t_b = fo.conv3d_fused(y_a, conv2, (A, Bs), True, fresh()[1], prev_conv=conv1)
+            assert torch.equal(z_a, z_b) and torch.equal(t_a, t_b)
+            assert occ2[2 * B * nt:2 * B * nt + 2].tolist() == [0, 0]
+
+
+def _lib_():
+    from lion_amd import _lib
+    return _lib.load()

@@ -1,5 +1,5 @@
 // mfma_issue_probe.hip -- how fast does ONE wave issue v_mfma_f32_32x32x16_f16, alone on its SIMD and beside a partner,
-// with and without the fragment reads of the split convolution's tap loop?  (DESIGN.md 4c claims 64-65 cycles per MFMA
+// with and without the fragment reads of the split convolution's tap loop?  (profiles/HISTORY.md 4c claims 64-65 cycles per MFMA
 // and wave "with or without a second wave"; the microarchitecture guide says 32 for a lone wave.  The answer decides
 // whether a one-wave-per-SIMD tap loop can feed the matrix pipe.)
 //
