@@ -16,14 +16,36 @@
 namespace {
 
 constexpr int NN_TILE = 2048;
+constexpr int NN_SPLIT = 4; // lanes per point
 
+// insert candidate (d, i) into the running three: strictly smaller distance, or -- LEX only -- equal distance and lower index
+template <bool LEX>
+__device__ __forceinline__ void nn_insert(float d, int i, float &b0, float &b1, float &b2, int &i0, int &i1, int &i2) {
+  const bool lt2 = d < b2 || (LEX && d == b2 && i < i2);
+  if (lt2) {
+    const bool lt1 = d < b1 || (LEX && d == b1 && i < i1);
+    const bool lt0 = d < b0 || (LEX && d == b0 && i < i0);
+    // selects, not nested branches: the three lists shift by at most one place
+    b2 = lt1 ? b1 : d;  i2 = lt1 ? i1 : i;
+    b1 = lt0 ? b0 : (lt1 ? d : b1);  i1 = lt0 ? i0 : (lt1 ? i : i1);
+    b0 = lt0 ? d : b0;  i0 = lt0 ? i : i0;
+  }
+}
+
+// Round 5: FOUR lanes per point, lane q scans the centres q, q + 4, q + 8, ... of the LDS tile (a quad reads four
+// consecutive words: conflict free, the 16 quads of a wave read the same four), four distances are formed before the
+// running three are touched, and the quad's lists are merged by (distance, index) -- which is the order the reference's
+// one-thread scan with strict '<' produces: its result is the three smallest centres by (distance, index), whatever the
+// order they are met in.  The round-1 kernel (one lane per point, 256 workgroups for (2048, 1024) at B = 32: one wave per
+// SIMD walking 1024 dependent compare chains) took ~100 us of the step's 153 us of 3-NN; bit-exact as before.
 __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ points,
                                                        const float *__restrict__ centers, int N,
                                                        int M, int32_t *__restrict__ idx,
                                                        float *__restrict__ wgt) {
   __shared__ float sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
   const int tid = threadIdx.x, b = blockIdx.y;
-  const int j = blockIdx.x * 256 + tid;
+  const int q = tid & (NN_SPLIT - 1);
+  const int j = blockIdx.x * (256 / NN_SPLIT) + (tid >> 2);
   const float *pc = points + (size_t)b * 3 * N;
   const float *cc = centers + (size_t)b * 3 * M;
   float ux = 0.f, uy = 0.f, uz = 0.f;
@@ -37,18 +59,33 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__
       sx[k] = cc[t0 + k]; sy[k] = cc[t0 + k + M]; sz[k] = cc[t0 + k + 2 * M];
     }
     __syncthreads();
-    for (int k = 0; k < tn; ++k) {
-      const float d = sqdist3(ux, uy, uz, sx[k], sy[k], sz[k]); // :44
-      if (d < best2) {                                           // :45-59
-        best2 = d; i2 = t0 + k;
-        if (d < best1) {
-          best2 = best1; i2 = i1; best1 = d; i1 = t0 + k;
-          if (d < best0) { best1 = best0; i1 = i0; best0 = d; i0 = t0 + k; }
-        }
-      }
+    int k = q;
+    for (; k + 3 * NN_SPLIT < tn; k += 4 * NN_SPLIT) { // this lane's next four centres: distances first, then the inserts
+      float d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = sqdist3(ux, uy, uz, sx[k + u * NN_SPLIT], sy[k + u * NN_SPLIT], sz[k + u * NN_SPLIT]); // :44
+#pragma unroll
+      for (int u = 0; u < 4; ++u) nn_insert<false>(d[u], t0 + k + u * NN_SPLIT, best0, best1, best2, i0, i1, i2); // :45-59
+    }
+    for (; k < tn; k += NN_SPLIT)
+      nn_insert<false>(sqdist3(ux, uy, uz, sx[k], sy[k], sz[k]), t0 + k, best0, best1, best2, i0, i1, i2);
+  }
+  // merge the quad's four lists into lane 0's: candidates of lanes 1, 2, 3 by (distance, index)
+  {
+    const float c0 = best0, c1 = best1, c2 = best2;
+    const int k0 = i0, k1 = i1, k2 = i2;
+    const int base = (tid & 63) & ~(NN_SPLIT - 1);
+#pragma unroll
+    for (int o = 1; o < NN_SPLIT; ++o) {
+      const float e0 = __shfl(c0, base + o, 64), e1 = __shfl(c1, base + o, 64), e2 = __shfl(c2, base + o, 64);
+      const int m0 = __shfl(k0, base + o, 64), m1 = __shfl(k1, base + o, 64), m2 = __shfl(k2, base + o, 64);
+      // a list that never filled a place still carries (+inf, 0): +inf is never smaller than anything, it stays out
+      if (e0 < INFINITY) nn_insert<true>(e0, m0, best0, best1, best2, i0, i1, i2);
+      if (e1 < INFINITY) nn_insert<true>(e1, m1, best0, best1, best2, i0, i1, i2);
+      if (e2 < INFINITY) nn_insert<true>(e2, m2, best0, best1, best2, i0, i1, i2);
     }
   }
-  if (j >= N) return;
+  if (j >= N || q != 0) return;
   best0 = fmaxf(fminf(1e10f, best0), 1e-10f); // :61-63
   best1 = fmaxf(fminf(1e10f, best1), 1e-10f);
   best2 = fmaxf(fminf(1e10f, best2), 1e-10f);
@@ -134,7 +171,7 @@ int lion_three_nn_interpolate_forward(const float *points, const float *centers,
   if (!points || !centers || !idx || !wgt || B <= 0 || N <= 0 || M <= 0) return LION_EINVAL;
   if (cfeat && (!out || C <= 0)) return LION_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  three_nn_kernel<<<dim3(lion_cdiv(N, 256), B), 256, 0, st>>>(points, centers, N, M, idx, wgt);
+  three_nn_kernel<<<dim3(lion_cdiv(N, 256 / NN_SPLIT), B), 256, 0, st>>>(points, centers, N, M, idx, wgt);
   LION_LAUNCH_CHECK();
   if (!cfeat) return 0;
   const int pt = lion_cdiv(N, 256);

@@ -38,6 +38,7 @@ _POINT_STREAMS = {}
 _VOX_PLANS = None
 VOX_PLAN = os.environ.get("LION_VOX_PLAN", "1") != "0"   # A/B switch: 0 = every voxelisation recomputes its indices
 OCC_PLAN = os.environ.get("LION_OCC_PLAN", "1") != "0"       # A/B switch: 0 = every PVConv recomputes its tile occupancy
+OCC_CLONE = os.environ.get("LION_OCC_CLONE", "0") != "0"     # A/B switch: 1 = a copy of the occupancy buffers per convolution (libraries before round 5)
 DEVOX_PLAN = os.environ.get("LION_DEVOX_PLAN", "1") != "0"   # A/B switch: 0 = every r = 32 devoxelisation redoes its per-cloud setup
 
 
@@ -64,6 +65,8 @@ def _occupancy(counts, r, cout, b):
         o1, o2 = fused_ops.conv3d_occupancy(counts, r, cout, b)
         hit = (counts, (o1, o2))   # counts stays alive with the entry
         _VOX_PLANS[key] = hit
+    if OCC_CLONE:   # A/B against a library from before round 5, whose convolutions leave the queue counter consumed
+        return hit[1][0].clone(), hit[1][1].clone()
     return hit[1]
 
 

@@ -19,6 +19,23 @@ pytestmark = pytest.mark.gpu
 B = 32
 
 
+@pytest.fixture(autouse=True)
+def strict_kernels(request):
+    """LION_STRICT for this module (round-4 verdict, hygiene): the benchmarked B = 32 configuration must run on the library's
+    own kernels only -- any layer that leaves them for MIOpen / rocBLAS / an ATen walk raises instead of being timed.
+    (Not for the test whose second leg IS the host evaluation: PyTorch-CPU dense layers + the oracle's operators.)"""
+    from lion_amd import _fallback
+    if "oracle_backend" in request.node.name:
+        yield
+        return
+    was = _fallback.strict()
+    _fallback.reset()
+    _fallback.strict(True)
+    yield
+    _fallback.strict(was)
+    assert _fallback.counts() == {}, _fallback.counts()
+
+
 @pytest.fixture(scope="module")
 def lion32():
     from lion_amd.config import released_prior_cfg

@@ -44,6 +44,32 @@ def test_sample_line_contract_single_rank():
     for k in ("roofline_chamfer", "roofline_emd", "latency_bound_operators", "roofline_voxelize", "roofline_devoxelize"):
         assert k in d, k
     assert d["cpu_baseline"]["ms_per_step_B32"] > 0 and len(d["cpu_baseline"]["per_kernel_B32"]) == 3
+    # round 5: the real chain as top-level / config scalars (the driver's record keeps scalars), the aggregate voxelize /
+    # devoxelize rooflines over the 14 + 14 calls of a forward, no vendor-library fallback inside the step, and the three
+    # training configurations as side lines with the weight-gradient roofline of the kernel that runs (frac <= 1)
+    assert abs(d["value_full_chain_1000"] - 2 / fc["seconds"]) < 1e-9 and d["ms_per_step_full_chain"] == fc["ms_per_step"]
+    assert d["config"]["full_chain_1000_shapes_per_s"] == d["value_full_chain_1000"]
+    for k in ("roofline_voxelize_forward_total", "roofline_devoxelize_forward_total"):
+        assert d[k]["bound"] == "hbm" and 0 < d[k]["frac"] <= 1 and d[k]["us_per_forward"] > 0
+    assert d["config"]["vendor_library_fallbacks_in_step"] == 0
+    for mode in ("train_vae", "train_prior", "train_prior_clip"):
+        ln = d["train_lines"][mode]
+        assert "error" not in ln, ln
+        assert ln["value"] > 0 and 0 < ln["roofline"]["frac"] <= 1 and "split" in ln["roofline"]["kernel"]
+        assert abs(ln["roofline"]["peak"] - 2500.0 / 3.0) < 1e-6
+        assert ln["cpu_baseline"]["value"] > 0 and ln["cpu_baseline"]["kind"] == "port"
+        assert d["config"][f"{mode}_samples_per_s"] == ln["value"]
+
+
+def test_sample_strong_scaling_two_ranks_over_gloo():
+    """--shapes-total: a fixed job split over the ranks (SURVEY.md 8e read as 32 shapes in total): 5 shapes over 2 ranks =
+    3 + 2, `value` = the whole job's 5 shapes over the slower rank's time, scaling = strong."""
+    d = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--shapes-total", "5", "--repeats", "1", "--no-dense-check",
+               "--no-full-chain", env={"LION_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shapes_total"] == 5
+    assert d["config"]["shapes_per_gpu"] == 3      # rank 0's share (remainder to the low ranks)
+    per_step_s = d["ms_per_step"] / 1e3
+    assert abs(d["value"] - 5 / (1000.0 * per_step_s + d["config"]["decode_seconds"])) < 1e-6 * d["value"] + 1e-9
 
 
 def test_sample_two_ranks_share_the_device_over_gloo():

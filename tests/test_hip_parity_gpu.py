@@ -358,6 +358,25 @@ def test_gather_forward_backward(bk, orc):
                                orc.gather_features_backward(gy, idx, N), rtol=TOL, atol=TOL)
 
 
+@pytest.mark.parametrize("N,M", [(1000, 343), (257, 27), (64, 8), (33, 5)])
+def test_three_nn_exact_ties_follow_the_scan_order(bk, orc, N, M):
+    """Round 5: four lanes share a point's scan and their lists are merged by (distance, index).  Points and centres on an
+    integer lattice (duplicated centres included) make most of the three nearest distances exact ties: indices and
+    weights must still be the reference's -- the lowest index wins (neighbor_interpolate.cu:45-59, strict '<')."""
+    rng = np.random.default_rng(N + M)
+    B = 3
+    side = max(2, int(round(M ** (1 / 3))))
+    ctr = rng.integers(0, side, (B, 3, M)).astype(np.float32)           # many coincident centres
+    pts = rng.integers(-1, side + 1, (B, 3, N)).astype(np.float32)
+    pts[:, :, ::3] += 0.5                                                # a third of the points sit between lattice sites
+    cf = rng.standard_normal((B, 5, M)).astype(np.float32)
+    o_out, o_idx, o_w = orc.three_nn_interpolate_forward(pts, ctr, cf)
+    out, idx, w = bk.three_nearest_neighbors_interpolate_forward(dev(pts), dev(ctr), dev(cf))
+    assert np.array_equal(host(idx), o_idx)
+    assert np.array_equal(host(w), o_w)
+    assert np.array_equal(host(out), o_out)
+
+
 @pytest.mark.parametrize("C,N,M", [(192, 2048, 1024), (192, 1024, 256), (128, 256, 64),
                                    (128, 64, 16), (4, 50, 2), (4, 50, 1), (9, 3000, 2500)])
 def test_three_nn_interpolate(bk, orc, C, N, M):

@@ -6,16 +6,16 @@
 # stored as <tag>_bench_steps20_TRACED_line.json and only serves the per-kernel tables.
 # SHORT=1 (second argument "short"): only what a change of the sampling path's kernels moves -- the two bench lines, the traced step,
 # operator / conv benches, traffic and MFMA-busy passes (training lines, probes and the 1x1 / wgrad benches keep their last set).
-TAG=${1:-r04}
+TAG=${1:-r05}
 SHORT=0; [ "${2:-}" = short ] && SHORT=1
 R=$PWD; O=$R/gpurun_out/profiles; mkdir -p $O
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
-python bench.py > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
+python bench.py --no-side-lines > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
 [ $SHORT = 1 ] || python bench.py --mode demo > $O/${TAG}_bench_demo.json 2>> $O/${TAG}_bench_default.err
 [ $SHORT = 1 ] || python bench.py --mode train_vae > $O/${TAG}_bench_train_vae.json 2>> $O/${TAG}_bench_default.err
 [ $SHORT = 1 ] || python bench.py --mode train_prior > $O/${TAG}_bench_train_prior.json 2>> $O/${TAG}_bench_default.err
 [ $SHORT = 1 ] || python bench.py --mode train_prior_clip > $O/${TAG}_bench_train_prior_clip.json 2>> $O/${TAG}_bench_default.err
-( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-dense-check > $O/${TAG}_bench_steps20_TRACED_line.json 2> /dev/null )
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-dense-check --no-side-lines --no-full-chain > $O/${TAG}_bench_steps20_TRACED_line.json 2> /dev/null )
 python tools/kstats.py $O/step_trace 70 > $O/${TAG}_bench_steps20_kernel_stats.txt 2>&1
 python tools/trace_gaps.py $O/step_trace begin_step_kernel --top 45 --last 9 > $O/${TAG}_bench_steps20_timeline.txt 2>&1
 python tools/conv_split_bench.py > $O/${TAG}_conv_split_bench.txt 2>/dev/null
