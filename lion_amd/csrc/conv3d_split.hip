@@ -57,9 +57,9 @@ template <int N> struct IntC { static constexpr int value = N; }; // compile-tim
 //   LION_SPLIT_COMPACT 1: voxel compaction inside occupied tiles (below).  Sparse launches on the chain's clouds 8-11 %
 //                         faster (r = 32: 195 -> 179 us, r = 16: 160 -> 142 us), dense launches 5-6 % slower (the third copy
 //                         of the K walk costs the register allocation 40 bytes of scratch around the staging); step 6.84 ->
-//                         6.93 ms.  What a sparse item costs is not its MFMAs: 46 % of a sparse launch's wave cycles are the
-//                         epilogue's stores and 16 % the wait for them at the next queue pop
-//                         (profiles/r05a_conv_phase_times_sparse_compaction_v1.txt).
+//                         6.93 ms.  What a sparse item costs is not its MFMAs: on the chain's clouds 40 % of a sparse launch's wave
+//                         cycles are the epilogue (80 % of its items are empty tiles), 15 % the queue pop, 45 % the K loop
+//                         (profiles/r05b_conv_epilogue_phases.txt).
 //                      0: the round-3 wave masks (a wave skips its 64-voxel block when no point is within the margin).
 //   LION_SPLIT_FILL    1: empty tiles written by split_fill_kernel in front of the convolution (16-byte stores in plane
 //                         order).  As a kernel of its own it serialises 30-40 us per convolution that the empty work items
