@@ -238,6 +238,14 @@ int lion_conv3d_const_response(const float *wsum, const float *bias2, const floa
                                const float *pro_b, int B, int Cin, int Cout, float *tconst, lionStream_t stream);
 int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
                                lionStream_t stream); /* margin 1 / margin 2 lists; either may be NULL; r in {16, 32} */
+/* Round 5: the same with consumer_aware != 0 for the pair of a PVConv (pvcnn2_ada.py:206-233: conv on the voxelised grid
+ * -> delta conv -> trilinear devoxelisation).  Nobody reads the first conv's output outside the tiles the second one
+ * stages (a point within 2 voxels, and their neighbours), nor the second one's outside the tiles around the points: a
+ * split-kernel launch that pops such a buffer writes NO output for an empty tile without a reader (its GroupNorm sums
+ * are still produced, in closed form).  The rest of y is left as allocated.  With consumer_aware == 0 (and through
+ * lion_conv3d_tile_occupancy) every voxel of y is written, as before. */
+int lion_conv3d_tile_occupancy_aware(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
+                                     int consumer_aware, lionStream_t stream);
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
                         const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
                         float *A, float *Bs, float *chmean, lionStream_t stream);

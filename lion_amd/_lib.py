@@ -55,6 +55,7 @@ SIGNATURES = {
     "lion_conv3d_const_response": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_conv3d_occupancy_ints": (_sz, [_i, _i, _i]),
     "lion_conv3d_tile_occupancy": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "lion_conv3d_tile_occupancy_aware": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "lion_conv3d_split_packed_halfs": (_sz, [_i, _i]),
     "lion_conv3d_split_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_conv3d_split_stat_tiles": (_i, [_i, _i]),

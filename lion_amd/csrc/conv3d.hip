@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, LION_CONV_WAVES) void conv3d_k3_kernel(const f
   // occ (optional): 0 = every input voxel of this tile's halo is zero in ALL channels (conv1 of a PVConv reads the
   // voxelised grid, >= 94 % zeros, and whole tiles far from the cloud are empty).  The K loop is skipped and the
   // epilogue writes bias -- bit-identical to accumulating the zeros.
-  const int wmask = queued ? occ[b * ntiles + tile] : 0xf; // bit w: wave w's 64 voxels see a point (sparse launches)
+  const int wmask = queued ? (occ[b * ntiles + tile] & 0xf) : 0xf; // bit w: wave w's 64 voxels see a point (sparse launches)
   const bool empty = wmask == 0;
   const bool wave_on = (wmask >> wave) & 1;
   const int nchunks = empty ? 0 : Cin / KC;
@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256) void gn_fold_se_kernel(const float *__restrict
 // occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter, 3 pad][B*tiles*8 voxel bit words]
 //         [B occupied-tile counts].
 __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__restrict__ cnt, int r, int TD, int TH,
-                                                             int32_t *__restrict__ occ1, int32_t *__restrict__ occ2) {
+                                                             int32_t *__restrict__ occ1, int32_t *__restrict__ occ2,
+                                                             int aware) {
   __shared__ unsigned col[32 * 32];   // bit w of col[d * r + h]: voxel (d, h, w) holds a point
   __shared__ int flag[2][256];
   const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
@@ -512,9 +513,21 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
         occupied += c;
       }
       int32_t *fl = occ + (size_t)b * ntiles, *list = occ + total + (size_t)b * ntiles;
-      fl[t] = f;
+      // (5) round 5 -- who READS a tile's output?  The convolution on the voxelised grid feeds the delta convolution, which
+      // stages the halo of every tile with a point within 2 voxels: its output is read in those tiles and their 8
+      // neighbours in the (d, h) tile grid (tiles span w), nowhere else.  The delta convolution feeds the devoxelisation,
+      // which reads the 8 voxels around each point: inside the tiles with a point within 2 voxels (within 1, even), nowhere
+      // else.  Bit 8 of a tile's flag = its output has a reader; a consumer-aware launch (word [2 total + 2] != 0) stores
+      // nothing for an EMPTY tile without that bit -- it still contributes its GroupNorm sums.
+      int need = flag[1][t] != 0;
+      if (m == 0) {
+        const int td = t / nth, th = t % nth;
+        for (int dd = max(td - 1, 0); dd <= min(td + 1, r / TD - 1); ++dd)
+          for (int hh = max(th - 1, 0); hh <= min(th + 1, nth - 1); ++hh) need |= flag[1][dd * nth + hh] != 0;
+      }
+      fl[t] = f | (need << 8);
       list[f ? before : occupied + (t - before)] = t;
-      if (b == 0 && t == 0) { occ[2 * total] = 0; occ[2 * total + 1] = 0; } // queue + exit counter of the convolutions that consume this list
+      if (b == 0 && t == 0) { occ[2 * total] = 0; occ[2 * total + 1] = 0; occ[2 * total + 2] = aware; } // queue, exit counter, mode
       if (t == 0) occ[10 * total + 4 + b] = occupied; // the sample's occupied tiles (the split kernel queues only those)
     }
   }
@@ -708,13 +721,21 @@ size_t lion_conv3d_occupancy_ints(int r, int Cout, int B) {
 // margin 2 (delta mode of the following conv); a fused forward re-arms the queue it popped (any number of launches in stream order).
 int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
                                lionStream_t stream) {
+  return lion_conv3d_tile_occupancy_aware(cnt, B, r, Cout, occ_m1, occ_m2, 0, stream);
+}
+
+// consumer_aware != 0: the convolutions that pop these buffers leave the output of EMPTY tiles that nobody reads unwritten
+// (see conv_tile_occ_kernel (5)): only for the pair (conv on the voxelised grid -> delta conv -> devoxelisation) of a PVConv.
+int lion_conv3d_tile_occupancy_aware(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
+                                     int consumer_aware, lionStream_t stream) {
   if (!cnt || (!occ_m1 && !occ_m2) || B <= 0 || Cout <= 0) return LION_EINVAL;
   if (r != 16 && r != 32) return LION_EUNSUPPORTED;
   const ConvPlan p = conv_plan(r, Cout, B, true);
   if (!p.vb || p.tiles > 256 || (((uintptr_t)cnt) & 15) != 0) return LION_EUNSUPPORTED;
   int td, th, tw;
   conv_tile_dims(r, p.vb, &td, &th, &tw);
-  conv_tile_occ_kernel<<<B, 1024, 0, static_cast<hipStream_t>(stream)>>>(cnt, r, td, th, occ_m1, occ_m2);
+  // the reader map of the first buffer is derived from the second margin's flags: both are computed in any case
+  conv_tile_occ_kernel<<<B, 1024, 0, static_cast<hipStream_t>(stream)>>>(cnt, r, td, th, occ_m1, occ_m2, consumer_aware ? 1 : 0);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -196,6 +196,8 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     kmax = __builtin_amdgcn_readfirstlane(v);
   }
   const int n_tile_items = kmax * B * ncz;
+  // consumer-aware buffers (lion_conv3d_tile_occupancy_aware): empty tiles whose output nobody reads store nothing
+  const bool aware = queued && occ[2 * B * ntiles + 2] != 0;
   // @phase-init
   for (int iter = 0;; ++iter) {
   int b, tile, co0;
@@ -238,9 +240,40 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     for (int w_ = 0; w_ < 4; ++w_) { const int c = s_wcnt[w_]; before += w_ < wave ? c : 0; n_act += c; }
     if (t_act) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)tid;
     // (visible to the tap loop behind the first barrier of chunk(); an empty tile never reads it)
-  } else if (queued) { // round-3 plan: bit w of the tile's flag = wave w's 64-voxel block sees a point
-    wmask = occ[b * ntiles + tile];
+  } else if (queued) { // round-3 plan: bit w of the tile's flag = wave w's 64-voxel block sees a point; bit 8 = has a reader
+    const int fw = occ[b * ntiles + tile];
+    wmask = fw & 0xf;
     n_act = wmask ? 4 * VB * 32 : 0;
+    if (aware && fw == 0) {
+      // An empty tile WITHOUT A READER (conv_tile_occ_kernel (5)): no output is stored -- nobody stages or interpolates
+      // from it -- only its GroupNorm sums are owed, in closed form: voxels per border configuration x the constant the
+      // dense evaluation leaves there (bias, or the delta mode's constant response).  In the chain 73-80 % of the tiles of
+      // an r = 32 launch are empty and most of them have no reader: 268 MB of constants per launch were written for nobody.
+      if (STATS && tid < COT) {
+        const bool dl = PRO && pro_a != nullptr && tconst != nullptr;
+        const int nd[3] = {d0 == 0 ? 1 : 0, TD - (d0 == 0 ? 1 : 0) - (d0 + TD == r ? 1 : 0), d0 + TD == r ? 1 : 0};
+        const int nh[3] = {h0 == 0 ? 1 : 0, TH - (h0 == 0 ? 1 : 0) - (h0 + TH == r ? 1 : 0), h0 + TH == r ? 1 : 0};
+        const int nw[3] = {w0 == 0 ? 1 : 0, TW - (w0 == 0 ? 1 : 0) - (w0 + TW == r ? 1 : 0), w0 + TW == r ? 1 : 0};
+        float s1 = 0.f, s2 = 0.f;
+        if (dl) {
+#pragma unroll
+          for (int cfg = 0; cfg < 27; ++cfg) { // unrolled: constant indices keep the count arrays in registers
+            const float n = (float)(nd[cfg / 9] * nh[(cfg / 3) % 3] * nw[cfg % 3]);
+            const float tv = tconst[((size_t)b * 27 + cfg) * Cout + co0 + tid];
+            s1 += n * tv;
+            s2 += n * (tv * tv);
+          }
+        } else {
+          const float tv = bias ? bias[co0 + tid] : 0.f;
+          s1 = (float)(TD * TH * TW) * tv;
+          s2 = (float)(TD * TH * TW) * (tv * tv);
+        }
+        float *o = stats + (((size_t)b * Cout + co0 + tid) * ntiles + tile) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+      continue;
+    }
   }
   n_act = __builtin_amdgcn_readfirstlane(n_act);
   if (LION_SPLIT_FILL && queued && n_act == 0) continue; // (fewer occupied tiles than kmax: split_fill_kernel wrote this one)

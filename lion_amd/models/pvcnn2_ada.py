@@ -38,6 +38,9 @@ _POINT_STREAMS = {}
 _VOX_PLANS = None
 VOX_PLAN = os.environ.get("LION_VOX_PLAN", "1") != "0"   # A/B switch: 0 = every voxelisation recomputes its indices
 OCC_PLAN = os.environ.get("LION_OCC_PLAN", "1") != "0"       # A/B switch: 0 = every PVConv recomputes its tile occupancy
+# the fused voxel branch is the ONLY reader of its two convolutions' outputs (conv1 -> conv2's halos, conv2 -> the 8 voxels
+# around each point): empty tiles without a reader are not written (round 5; 0 = every voxel of both outputs is written)
+SKIP_UNREAD = os.environ.get("LION_CONV_SKIP_UNREAD", "1") != "0"
 OCC_CLONE = os.environ.get("LION_OCC_CLONE", "0") != "0"     # A/B switch: 1 = a copy of the occupancy buffers per convolution (libraries before round 5)
 DEVOX_PLAN = os.environ.get("LION_DEVOX_PLAN", "1") != "0"   # A/B switch: 0 = every r = 32 devoxelisation redoes its per-cloud setup
 
@@ -58,11 +61,11 @@ def _occupancy(counts, r, cout, b):
     computed once and every convolution of the pair works from the SAME buffers: a sparse convolution re-arms its work
     queue when its last workgroup leaves (round 5; until then every use took a copy -- 7 copy launches per step)."""
     if _VOX_PLANS is None or not OCC_PLAN:
-        return fused_ops.conv3d_occupancy(counts, r, cout, b)
+        return fused_ops.conv3d_occupancy(counts, r, cout, b, consumer_aware=SKIP_UNREAD)
     key = ("occ", counts.data_ptr(), tuple(counts.shape), int(r), int(b))
     hit = _VOX_PLANS.get(key)
     if hit is None:
-        o1, o2 = fused_ops.conv3d_occupancy(counts, r, cout, b)
+        o1, o2 = fused_ops.conv3d_occupancy(counts, r, cout, b, consumer_aware=SKIP_UNREAD)
         hit = (counts, (o1, o2))   # counts stays alive with the entry
         _VOX_PLANS[key] = hit
     if OCC_CLONE:   # A/B against a library from before round 5, whose convolutions leave the queue counter consumed

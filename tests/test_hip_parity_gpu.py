@@ -744,7 +744,7 @@ def test_conv3d_empty_tile_skip_is_bit_identical(cin, cout, r, n, conv_kernel):
         occ1, _ = fo.conv3d_occupancy(cnt, r, cout, B)
         y1, s1 = fo.conv3d_fused(grid, conv, None, True, occ1)
         nt = occ1.numel() // 2 // B
-        assert (occ1[:B * nt] != 0).float().mean().item() < 0.9  # the flat cloud leaves tiles empty
+        assert ((occ1[:B * nt] & 0xf) != 0).float().mean().item() < 0.9  # the flat cloud leaves tiles empty
     assert torch.equal(y0, y1)  # same K order per voxel whatever the tiling
     t0, t1 = s0.sum(2), s1.sum(2)  # the sparse launch tiles differently: compare the totals
     assert torch.allclose(t0, t1, rtol=1e-4, atol=1e-5 * t0.abs().max().item())
@@ -883,9 +883,17 @@ def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
     for occ, m in ((occ1, 1), (occ2, 2)):
         d = torch.nn.functional.max_pool3d(g, 2 * m + 1, 1, m)[:, 0]
         ref = d.view(B, r // td, td, r // th, th, r).amax(dim=(2, 4, 5)).reshape(B, nt).int()
-        flags = occ[:B * nt].view(B, nt)  # 4-bit masks: bit w = wave w's 64-voxel block sees a point; 0 = empty tile
+        word = occ[:B * nt].view(B, nt)
+        flags = word & 0xf                # 4-bit masks: bit w = wave w's 64-voxel block sees a point; 0 = empty tile
         assert torch.equal((flags != 0).int(), ref), m
-        assert int(flags.max()) <= 15
+        assert int((word >> 9).max()) == 0
+        # round 5, bit 8 = the tile's output has a reader: margin 2 -- the tiles around the points themselves (the
+        # devoxelisation); margin 1 -- the margin-2 tiles and their neighbours in the (d, h) tile grid (the delta conv's halos)
+        d2 = torch.nn.functional.max_pool3d(g, 5, 1, 2)[:, 0]
+        occ2_ref = d2.view(B, r // td, td, r // th, th, r).amax(dim=(2, 4, 5))           # [B, r/td, r/th]
+        need_ref = occ2_ref if m == 2 else torch.nn.functional.max_pool2d(occ2_ref[:, None], 3, 1, 1)[:, 0]
+        assert torch.equal((word >> 8) & 1, need_ref.reshape(B, nt).int()), m
+        assert int(occ[2 * B * nt + 2]) == 0      # the plain entry point: every voxel is written
         lst = occ[B * nt:2 * B * nt].view(B, nt)
         for b in range(B):
             assert sorted(lst[b].tolist()) == list(range(nt))

@@ -160,6 +160,53 @@ def test_fused_pvconv_matches_layer_by_layer(cin, cout, r, n, flat):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("kind", ["gauss", "flat", "clumped"])
+@pytest.mark.parametrize("cin,cout,r,n", [(64, 64, 32, 2048), (32, 32, 32, 2048), (128, 128, 16, 1024), (4, 32, 32, 2048)])
+def test_pvconv_unread_tiles_are_not_written_and_nothing_changes(cin, cout, r, n, kind):
+    """Round 5 (pvcnn2_ada.SKIP_UNREAD, lion_conv3d_tile_occupancy_aware): inside the fused voxel branch the first convolution's
+    output is read only where the second one stages halos, the second one's only around the points; empty tiles without a
+    reader are not stored.  (i) Nobody reads what was not written: the voxel grids' memory is pre-poisoned through the caching
+    allocator with 0, NaN and 1e30 in turn and the PVConv's output is bit-identical under all three; (ii) against the
+    evaluation that writes every voxel the output agrees to fp32 rounding -- the GroupNorm sums of a skipped tile are
+    count x value instead of a tree of 256 equal terms, nothing else differs."""
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models import pvcnn2_ada as m
+    cfg = released_prior_cfg()
+    torch.manual_seed(r + cin)
+    pv = m.PVConv(cin, cout, 3, r, with_se=True, attention=False, dropout=0.1, cfg=cfg)
+    fill_(pv)
+    pv.cuda().eval()
+    B = 3
+    feat = torch.randn(B, cin, n, device="cuda")
+    coords = torch.randn(B, 3, n, device="cuda")
+    if kind == "flat":
+        coords = coords * torch.tensor([1.0, 0.15, 0.6], device="cuda").view(1, 3, 1)
+    elif kind == "clumped":
+        coords[:, :, : int(0.95 * n)] *= 0.1
+    sty = torch.randn(B, 128, device="cuda")
+
+    def poison(val):   # blocks of the sizes the branch is about to allocate, filled and handed back to the allocator
+        blocks = [torch.full((B, cout, r, r, r), val, device="cuda") for _ in range(3)]
+        del blocks
+
+    saved = m.SKIP_UNREAD
+    try:
+        with torch.no_grad():
+            m.SKIP_UNREAD = False
+            poison(float("nan"))
+            ref = pv((feat, coords, None, sty))[0].clone()
+            m.SKIP_UNREAD = True
+            outs = []
+            for val in (0.0, float("nan"), 1e30):
+                poison(val)
+                outs.append(pv((feat, coords, None, sty))[0].clone())
+    finally:
+        m.SKIP_UNREAD = saved
+    assert torch.isfinite(ref).all() and all(bool(torch.isfinite(o).all()) for o in outs)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert (outs[1] - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
 def test_fused_shared_mlp_and_sa_module_match_layer_by_layer():
     """inference fusion of the 1-D / 2-D SharedMLP (row sums -> fold -> swish(AdaGN) [-> max over U])
     == the torch layer sequence."""

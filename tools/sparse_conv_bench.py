@@ -48,7 +48,7 @@ for c, r, n in ((64, 32, 2048), (32, 32, 2048), (128, 16, 1024)):
         grid = out.view(B, c, r, r, r)
         nt = lib.lion_conv3d_stat_tiles(r, c, B, 1)
         o1, o2 = fo.conv3d_occupancy(cnt, r, c, B)
-        fr = [1 - (o.view(-1)[:B * nt] != 0).float().mean().item() for o in (o1, o2)]
+        fr = [1 - ((o.view(-1)[:B * nt] & 0xf) != 0).float().mean().item() for o in (o1, o2)]
         act, blk = [], []
         for o in (o1, o2):
             w = o.view(-1)[2 * B * nt + 4:2 * B * nt + 4 + 8 * B * nt].view(B * nt, 8).cpu().numpy().astype("uint32")
