@@ -70,6 +70,13 @@ int lion_voxel_index(const float *coords, int B, int N, int r, int normalize, fl
                      lionStream_t stream);
 int lion_voxel_scatter(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N,
                        int r, float *out, lionStream_t stream);
+/* Round 5: the same scatter for a grid whose ONLY reader is the sparse convolution that pops occ_m1
+ * (lion_conv3d_tile_occupancy[_aware], margin 1; r in {16, 32}) -- conv1 of a PVConv in the fused inference path
+ * (pvcnn2_ada.py:206-222).  That convolution stages the halo of the tiles with a point within one voxel and nothing
+ * else: z-rows of the grid outside every such halo are NOT written (left as allocated; their content is all zeros in the
+ * full scatter and has no reader). */
+int lion_voxel_scatter_read(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int r,
+                            const int32_t *occ_m1, float *out, lionStream_t stream);
 
 /* ---- K3: avg_voxelize_backward, vox.cpp:54-79 (vox.cu:86-110) --------------------------
  * gy f32[B,C,r3], ind i32[B,N], cnt i32[B,r3] -> gx f32[B,C,N]. */

@@ -25,6 +25,7 @@ SIGNATURES = {
     "lion_voxel_plan_bytes": (_sz, [_i, _i, _i]),
     "lion_voxel_index": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lion_voxel_scatter": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp, _vp]),
+    "lion_voxel_scatter_read": (_i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp, _vp, _vp]),
     "lion_avg_voxelize_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_trilinear_devoxelize_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lion_trilinear_devoxelize_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

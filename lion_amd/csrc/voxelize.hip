@@ -136,7 +136,8 @@ __device__ __forceinline__ void vox_means_and_store(
       o.y = sl.y >= 0 ? y : 0.f;
       o.z = sl.z >= 0 ? z : 0.f;
       o.w = sl.w >= 0 ? w : 0.f;
-      *reinterpret_cast<float4 *>(obase + (size_t)cl * r3 + 4 * g) = o;
+      // slot -2 (lion_voxel_scatter_read): a z-row no convolution tile stages -- its zeros have no reader, nothing is stored
+      if (sl.x != -2) *reinterpret_cast<float4 *>(obase + (size_t)cl * r3 + 4 * g) = o;
       cl += step_c; g += step_g;
       if (g >= q4) { g -= q4; ++cl; }
     }
@@ -401,7 +402,8 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
 template <int NP>
 __global__ __launch_bounds__(VT) void vox_scatter_kernel(
     const float *__restrict__ feat, const void *__restrict__ plan, int B, int C, int N, int r3, int S, int CS, int SV,
-    int n_words, int arena_words, int ch_cap, float *__restrict__ out) {
+    int n_words, int arena_words, int ch_cap, float *__restrict__ out, const int32_t *__restrict__ occ_flags, int r, int TD,
+    int TH) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *slot = reinterpret_cast<int32_t *>(smem);
   int32_t *ust = slot + SV;
@@ -425,7 +427,26 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
     posv[p] = mine ? (w & 0xffff) : -1;
     invp[p] = mine ? iv : 0.f;
   }
-  for (int v = tid; v < SV; v += VT) slot[v] = -1;
+  if (occ_flags) {
+    // Round 5: the grid's only reader is the sparse convolution that pops occ_flags (lion_conv3d_tile_occupancy, margin 1):
+    // it stages the halo -- one voxel in d and h, all of w -- of the tiles with a point within one voxel, nothing else.  A
+    // z-row (d, h) outside every such halo is never read: its voxels (all empty -- a point's own row lies inside an occupied
+    // tile) get slot -2 and phase C stores nothing there.  The chain's clouds leave ~70 % of an r = 32 grid unread.
+    __shared__ unsigned char rowneed[1024];   // rows of this slab (SV / r <= 1024)
+    const int nth = r / TH, ntiles = (r / TD) * nth, row0 = (slab * SV) / r, nrows = SV / r;
+    const int32_t *fl = occ_flags + (size_t)b * ntiles;
+    for (int q = tid; q < nrows; q += VT) {
+      const int d = (row0 + q) / r, h = (row0 + q) % r;
+      int need = 0;
+      for (int dd = max(d - 1, 0); dd <= min(d + 1, r - 1); ++dd)
+        for (int hh = max(h - 1, 0); hh <= min(h + 1, r - 1); ++hh) need |= fl[(dd / TD) * nth + hh / TH] & 0xf;
+      rowneed[q] = need != 0;
+    }
+    __syncthreads();
+    for (int v = tid; v < SV; v += VT) slot[v] = rowneed[v / r] ? -1 : -2;
+  } else {
+    for (int v = tid; v < SV; v += VT) slot[v] = -1;
+  }
   __syncthreads();
   const int32_t *ust_g = pl.ust + ((size_t)b * S + slab) * n_words;
   const int32_t *uvl_g = pl.uvl + ((size_t)b * S + slab) * n_words;
@@ -552,7 +573,8 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
   // (70 -> 74 us), so r = 32 keeps one workgroup per CU.
   const bool two_per_cu = N <= VT;
   const long wgs = two_per_cu ? 512 : 256;
-  const size_t lds_limit = two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT;
+  // (the kernel's static LDS -- the 1-KiB row map of the reader-aware form -- comes out of the same budget)
+  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - 1024 - 64;
   // slabs per cloud: enough workgroups to touch every CU, slabs of >= 512 voxels (int4 groups)
   int S = 1;
   while (S < 16 && (long)B * S < wgs && r3 / (S * 2) >= 512 && (r3 % (S * 2 * 4)) == 0) S *= 2;
@@ -693,8 +715,25 @@ int lion_voxel_index(const float *coords, int B, int N, int r, int normalize, fl
                        static_cast<hipStream_t>(stream), plan);
 }
 
+static int voxel_scatter_impl(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int r, float *out,
+                              const int32_t *occ_flags, lionStream_t stream);
+
 int lion_voxel_scatter(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int r, float *out,
                        lionStream_t stream) {
+  return voxel_scatter_impl(feat, plan, plan_bytes, B, C, N, r, out, nullptr, stream);
+}
+
+// The same scatter for a grid whose ONLY reader is the sparse convolution popping occ_m1 (lion_conv3d_tile_occupancy[_aware],
+// margin 1; r in {16, 32}): z-rows outside the halo of every occupied tile are not written (left as allocated).
+int lion_voxel_scatter_read(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int r,
+                            const int32_t *occ_m1, float *out, lionStream_t stream) {
+  if (!occ_m1) return LION_EINVAL;
+  if (r != 16 && r != 32) return LION_EUNSUPPORTED;
+  return voxel_scatter_impl(feat, plan, plan_bytes, B, C, N, r, out, occ_m1, stream);
+}
+
+static int voxel_scatter_impl(const float *feat, const void *plan, size_t plan_bytes, int B, int C, int N, int r, float *out,
+                              const int32_t *occ_flags, lionStream_t stream) {
   if (!feat || !plan || !out || B <= 0 || C <= 0 || N <= 0 || r <= 0) return LION_EINVAL;
   const size_t need = lion_voxel_plan_bytes(B, N, r);
   if (need == 0 || (((uintptr_t)out) & 15) != 0) return LION_EUNSUPPORTED;
@@ -714,7 +753,8 @@ int lion_voxel_scatter(const float *feat, const void *plan, size_t plan_bytes, i
     while ((long)B * p.S * CS < 512 && C / (CS * 2) >= 8) CS *= 2;
     p.CS = CS;
   }
-  const size_t lds_limit = two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT;
+  // (the kernel's static LDS -- the 1-KiB row map of the reader-aware form -- comes out of the same budget)
+  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - 1024 - 64;
   const size_t fixed = ((size_t)p.SV + (size_t)p.n_words) * 4;
   const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
   const size_t want = ((size_t)N + nocc) * C * 4;
@@ -730,7 +770,7 @@ int lion_voxel_scatter(const float *feat, const void *plan, size_t plan_bytes, i
     static LionLdsLimit cfg = {};                                                                      \
     if (int e = lion_dynamic_lds(&vox_scatter_kernel<NPV>, lds, cfg)) return e;                        \
     vox_scatter_kernel<NPV><<<grid, VT, lds, st>>>(feat, plan, B, C, N, r3, p.S, p.CS, p.SV, p.n_words, \
-                                                   (int)(arena / 4), 64, out);                         \
+                                                   (int)(arena / 4), 64, out, occ_flags, r, r == 32 ? 2 : 4, 4); \
   }
   switch (p.NP) {
   case 1: LION_VOXS_LAUNCH(1) break;

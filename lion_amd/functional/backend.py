@@ -262,9 +262,11 @@ class _HipBackend:
                    "voxel_index")
         return {"norm": norm, "ind": ind, "cnt": cnt, "ws": ws, "shape": (b, n, r)}
 
-    def voxel_scatter(self, features, plan):
+    def voxel_scatter(self, features, plan, occ_m1=None):
         """features f32[B,C,N] -> f32[B,C,r^3] mean-pooled with plan's voxel assignment (bit-identical to
-        voxelize_points_forward on the plan's coordinates)."""
+        voxelize_points_forward on the plan's coordinates).  occ_m1 (the margin-1 buffer of fused_ops.conv3d_occupancy):
+        the grid's only reader is the sparse convolution popping it -- z-rows outside every occupied tile's halo are
+        left unwritten (lion_voxel_scatter_read)."""
         _lib.require_cuda(features); _f32(features, "features")
         b, n, r = plan["shape"]
         if features.shape[0] != b or features.shape[2] != n:
@@ -272,6 +274,11 @@ class _HipBackend:
         c = features.shape[1]
         out = torch.empty((b, c, r * r * r), device=features.device, dtype=torch.float32)
         ws = plan["ws"]
+        if occ_m1 is not None:
+            _lib.check(self.lib.lion_voxel_scatter_read(_lib.ptr(features), _lib.ptr(ws), ws.numel(), b, c, n, r,
+                                                        _lib.ptr(occ_m1), _lib.ptr(out), _lib.stream_ptr(features.device)),
+                       "voxel_scatter_read")
+            return out
         _lib.check(self.lib.lion_voxel_scatter(_lib.ptr(features), _lib.ptr(ws), ws.numel(), b, c, n, r, _lib.ptr(out),
                                                _lib.stream_ptr(features.device)), "voxel_scatter")
         return out

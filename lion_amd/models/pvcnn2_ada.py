@@ -323,9 +323,11 @@ class Voxelization(nn.Module):
         self.normalize = normalize
         self.eps = eps
 
-    def forward(self, features, coords, return_counts=False):
+    def forward(self, features, coords, return_counts=False, sparse_reader=False):
         """return_counts (inference only): also the per-voxel point counts int32 [B, r^3], from which
-        the first convolution derives its empty tiles."""
+        the first convolution derives its empty tiles.  sparse_reader (PVConv's fused branch): the grid will be read by the
+        sparse convolution only -- the tile occupancy of the (cloud, r) pair is computed first and the scatter leaves the
+        z-rows outside every occupied tile's halo unwritten (round 5)."""
         coords = coords.detach()
         if return_counts:
             from ..functional.backend import _backend
@@ -342,7 +344,10 @@ class Voxelization(nn.Module):
                 else:
                     plan = hit[1]
             if plan is not None:   # phases B + C only: the voxel ids of this cloud at this resolution exist already
-                out = _backend.voxel_scatter(features.float().contiguous(), plan)
+                occ_m1 = None
+                if sparse_reader and SKIP_UNREAD and SPARSE_CONV1 and self.r in (16, 32) and hasattr(_backend, "voxel_scatter"):
+                    occ_m1 = _occupancy(plan["cnt"], self.r, 64, b)[0]
+                out = _backend.voxel_scatter(features.float().contiguous(), plan, occ_m1)
                 return out.view(b, c, self.r, self.r, self.r), plan["norm"], plan["cnt"]
             out, norm_coords, _, counts = _backend.voxelize_points_forward(
                 features.float().contiguous(), co, self.r, self.normalize, self.eps)
@@ -422,7 +427,9 @@ class PVConv(nn.Module):
         counts = None
         if (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled() and features.is_cuda
                 and not torch.is_autocast_enabled()):
-            grid, voxel_coords, counts = self.voxelization(features, coords, return_counts=True)
+            # the fused voxel branch below is the grid's only reader, and its first convolution runs sparse
+            will_fuse = fused_ops.fusable(self.voxel_layers[0], self.voxel_layers[4], self.resolution, features.float())
+            grid, voxel_coords, counts = self.voxelization(features, coords, return_counts=True, sparse_reader=will_fuse)
         else:
             grid, voxel_coords = self.voxelization(features, coords)
         if (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled()

@@ -988,3 +988,34 @@ def test_conv3d_work_queue_rearms_itself(conv_kernel):
 def _lib_():
     from lion_amd import _lib
     return _lib.load()
+
+
+@pytest.mark.parametrize("C,N,r,kind", [(64, 2048, 32, "flat"), (32, 2048, 32, "gauss"), (128, 1024, 16, "flat"), (4, 2048, 32, "clumped")])
+def test_voxel_scatter_for_the_sparse_reader(C, N, r, kind):
+    """Round 5, lion_voxel_scatter_read: a grid whose only reader is the sparse convolution is written where that convolution
+    stages -- the z-rows within one voxel (in d and h) of a tile with a point within one voxel -- bit-identical to the full
+    scatter there, and NOT written elsewhere (the buffer handed in keeps its sentinel; the full scatter holds zeros there)."""
+    from lion_amd import _lib, fused_ops as fo
+    gen = torch.Generator(device="cuda").manual_seed(C + N + r)
+    B = 3
+    co = _cloud(kind, B, N, gen)
+    if kind == "flat":
+        co = torch.randn(B, 3, N, device="cuda", generator=gen) * torch.tensor([1.0, 0.15, 0.6], device="cuda").view(1, 3, 1)
+    feat = torch.randn(B, C, N, device="cuda", generator=gen)
+    plan = bk_().voxel_index(co, r, True, 0.0)
+    full = bk_().voxel_scatter(feat, plan)
+    occ1, _ = fo.conv3d_occupancy(plan["cnt"], r, 64, B)
+    lib = _lib.load()
+    out = torch.full((B, C, r ** 3), -7.5, device="cuda")
+    ws = plan["ws"]
+    _lib.check(lib.lion_voxel_scatter_read(_lib.ptr(feat), _lib.ptr(ws), ws.numel(), B, C, N, r, _lib.ptr(occ1), _lib.ptr(out),
+                                           _lib.stream_ptr(feat.device)), "voxel_scatter_read")
+    td, th = (2, 4) if r == 32 else (4, 4)
+    nt = (r // td) * (r // th)
+    occ_t = ((occ1[:B * nt] & 0xf) != 0).view(B, 1, r // td, r // th).float()
+    rows = occ_t.repeat_interleave(td, 2).repeat_interleave(th, 3)                      # [B, 1, r, r]: rows of occupied tiles
+    need = torch.nn.functional.max_pool2d(rows, 3, 1, 1)[:, 0].bool()                   # + one row around them
+    need_v = need.view(B, 1, r, r, 1).expand(B, C, r, r, r).reshape(B, C, r ** 3)
+    assert torch.equal(out[need_v], full[need_v])
+    assert bool((out[~need_v] == -7.5).all()) and bool((full[~need_v] == 0).all())
+    assert 0.0 < need.float().mean().item() < (0.95 if kind != "gauss" else 1.01)
