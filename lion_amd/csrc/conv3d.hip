@@ -521,11 +521,19 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
       // nothing for an EMPTY tile without that bit -- it still contributes its GroupNorm sums.
       int need = flag[1][t] != 0;
       if (m == 0) {
-        const int td = t / nth, th = t % nth;
-        for (int dd = max(td - 1, 0); dd <= min(td + 1, r / TD - 1); ++dd)
-          for (int hh = max(th - 1, 0); hh <= min(th + 1, nth - 1); ++hh) need |= flag[1][dd * nth + hh] != 0;
+        if (aware == 2) {
+          // level 2: the delta convolution does not read the first one's output inside its EMPTY tiles either -- there it is
+          // bias1 exactly, the activated input minus its constant exactly zero, and the split kernel stages zeros for such
+          // rows without loading them (bit 9 of the margin-2 words below tells it): only occupied tiles are ever stored
+          need = 0;
+        } else {
+          const int td = t / nth, th = t % nth;
+          for (int dd = max(td - 1, 0); dd <= min(td + 1, r / TD - 1); ++dd)
+            for (int hh = max(th - 1, 0); hh <= min(th + 1, nth - 1); ++hh) need |= flag[1][dd * nth + hh] != 0;
+        }
       }
-      fl[t] = f | (need << 8);
+      // margin-2 words also carry bit 9 = the tile is occupied at margin 1 (see above)
+      fl[t] = f | (need << 8) | ((m == 1 && flag[0][t] != 0) ? (1 << 9) : 0);
       list[f ? before : occupied + (t - before)] = t;
       if (b == 0 && t == 0) { occ[2 * total] = 0; occ[2 * total + 1] = 0; occ[2 * total + 2] = aware; } // queue, exit counter, mode
       if (t == 0) occ[10 * total + 4 + b] = occupied; // the sample's occupied tiles (the split kernel queues only those)
@@ -726,6 +734,8 @@ int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32
 
 // consumer_aware != 0: the convolutions that pop these buffers leave the output of EMPTY tiles that nobody reads unwritten
 // (see conv_tile_occ_kernel (5)): only for the pair (conv on the voxelised grid -> delta conv -> devoxelisation) of a PVConv.
+// consumer_aware == 2: additionally the delta convolution is the SPLIT kernel, which does not load the first convolution's
+// output inside that convolution's empty tiles -- the first convolution then stores occupied tiles only.
 int lion_conv3d_tile_occupancy_aware(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
                                      int consumer_aware, lionStream_t stream) {
   if (!cnt || (!occ_m1 && !occ_m2) || B <= 0 || Cout <= 0) return LION_EINVAL;
@@ -735,7 +745,8 @@ int lion_conv3d_tile_occupancy_aware(const int32_t *cnt, int B, int r, int Cout,
   int td, th, tw;
   conv_tile_dims(r, p.vb, &td, &th, &tw);
   // the reader map of the first buffer is derived from the second margin's flags: both are computed in any case
-  conv_tile_occ_kernel<<<B, 1024, 0, static_cast<hipStream_t>(stream)>>>(cnt, r, td, th, occ_m1, occ_m2, consumer_aware ? 1 : 0);
+  conv_tile_occ_kernel<<<B, 1024, 0, static_cast<hipStream_t>(stream)>>>(cnt, r, td, th, occ_m1, occ_m2,
+                                                                         consumer_aware == 2 ? 2 : consumer_aware ? 1 : 0);
   LION_LAUNCH_CHECK();
   return 0;
 }

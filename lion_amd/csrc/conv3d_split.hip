@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   __shared__ unsigned char s_list[256];       // sparse launches: the tile's active voxels, ascending
   __shared__ int s_wcnt[4];                   // active voxels among each wave's 64
   __shared__ int s_cls[27];                   // voxels that are NOT active, per border configuration
+  __shared__ unsigned char s_rowok[256];      // aware level 2, delta launches: this staging thread's halo row has been written
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 5, l32 = lane & 31;
   const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_wscale_kernel)
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   }
   const int n_tile_items = kmax * B * ncz;
   // consumer-aware buffers (lion_conv3d_tile_occupancy_aware): empty tiles whose output nobody reads store nothing
-  const bool aware = queued && occ[2 * B * ntiles + 2] != 0;
+  const int aware_level = queued ? occ[2 * B * ntiles + 2] : 0;
+  const bool aware = aware_level != 0;
   // @phase-init
   for (int iter = 0;; ++iter) {
   int b, tile, co0;
@@ -293,6 +295,19 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   }
   for (int c = tid; c < COT; c += TM) sbias[c] = bias ? bias[co0 + c] : 0.f;
   if (tid < 2) s_max[tid] = 0u;
+  // Aware level 2 (lion_conv3d_tile_occupancy_aware): the producer of x stored its occupied (margin-1) tiles only.  Inside
+  // its empty tiles x is bias1 exactly, so this launch's staged value -- the activation minus its constant -- is exactly
+  // zero there: such halo rows are not loaded (their quads take the out-of-range offset, for which buffer loads return 0,
+  // and the prologue writes 0 for them).  Bit 9 of this buffer's flag words = the tile is occupied at margin 1.
+  const bool rows_masked = delta && aware_level == 2;
+  if (rows_masked) {
+    constexpr int QR_ = (TW + 8) / 4, HH_ = TH + 2, HD_ = TD + 2;
+    const int row = tid / QR_, hd = row / HH_, hh = row - hd * HH_;
+    const int gd = d0 - 1 + hd, gh = h0 - 1 + hh;
+    bool ok = tid < HD_ * HH_ * QR_ && gd >= 0 && gd < r && gh >= 0 && gh < r;
+    if (ok) ok = (occ[b * ntiles + (gd / TD) * (r / TH) + gh / TH] >> 9) & 1;
+    s_rowok[tid] = ok;
+  }
   int E = 127; // exponent of the tile's activation scale 2^E; 127 = none yet (everything staged so far was zero)
 
   // Everything derived from the thread index (the staging offsets, the fragment bases of the tap loop) is RECOMPUTED per
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     const int row = rt / QR, qd = rt - row * QR;
     const int hd = row / HH, hh = row - hd * HH;
     const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw0 = w0 - 4 + 4 * qd;
-    const bool gok = rt < IPH && gd >= 0 && gd < r && gh >= 0 && gh < r && gw0 >= 0 && gw0 < r;
+    const bool gok = rt < IPH && gd >= 0 && gd < r && gh >= 0 && gh < r && gw0 >= 0 && gw0 < r && (!rows_masked || s_rowok[rt]);
     const int goff = gok ? ((gd * r + gh) * r + gw0) * 4 : 0x7fffff00;
     const int p0 = row * HW + 4 * qd - 3; // halo position of the quad's first column (column k is used iff 0 <= hw0 + k < HW)
     const int hw0 = 4 * qd - 3;

@@ -31,15 +31,17 @@ def conv3d_occupancy(counts, r, cout, b, consumer_aware=False):
     conv3d_fused call pops its work from the buffer's queue and re-arms it when its last workgroup leaves, so the same
     buffer serves any number of convolutions one after the other on a stream (never two at once).
     counts: int32 [B, r^3] from the voxelisation.
-    consumer_aware=True (only for the conv -> delta conv -> devoxelize chain of a PVConv, models/pvcnn2_ada.py): the
+    consumer_aware = 1 (only for the conv -> delta conv -> devoxelize chain of a PVConv, models/pvcnn2_ada.py): the
     convolutions leave the output of empty tiles WITHOUT A READER unwritten (the first conv's output is read where the
-    second one stages its halos, the second one's around the points); their GroupNorm sums stay complete."""
+    second one stages its halos, the second one's around the points); their GroupNorm sums stay complete.
+    consumer_aware = 2: the delta convolution is the split kernel, which stages zeros for the rows of the first
+    convolution's empty tiles without loading them -- the first convolution stores its occupied tiles only."""
     lib = _lib.load()
     n = lib.lion_conv3d_occupancy_ints(r, cout, b)
     buf = torch.empty((2, n), device=counts.device, dtype=torch.int32)
     cnt_c = counts.contiguous()
     _lib.check(lib.lion_conv3d_tile_occupancy_aware(_lib.ptr(cnt_c), b, r, cout, _lib.ptr(buf[0]), _lib.ptr(buf[1]),
-                                                    1 if consumer_aware else 0, _lib.stream_ptr(counts.device)),
+                                                    int(consumer_aware), _lib.stream_ptr(counts.device)),
                "conv3d_tile_occupancy_aware")
     return buf[0], buf[1]
 

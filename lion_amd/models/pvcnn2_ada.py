@@ -41,6 +41,7 @@ OCC_PLAN = os.environ.get("LION_OCC_PLAN", "1") != "0"       # A/B switch: 0 = e
 # the fused voxel branch is the ONLY reader of its two convolutions' outputs (conv1 -> conv2's halos, conv2 -> the 8 voxels
 # around each point): empty tiles without a reader are not written (round 5; 0 = every voxel of both outputs is written)
 SKIP_UNREAD = os.environ.get("LION_CONV_SKIP_UNREAD", "1") != "0"
+SKIP_UNREAD_LEVEL2 = os.environ.get("LION_CONV_SKIP_UNREAD_LEVEL2", "1") != "0"   # A/B: 0 = conv1 still stores the empty tiles conv2's halos touch
 OCC_CLONE = os.environ.get("LION_OCC_CLONE", "0") != "0"     # A/B switch: 1 = a copy of the occupancy buffers per convolution (libraries before round 5)
 DEVOX_PLAN = os.environ.get("LION_DEVOX_PLAN", "1") != "0"   # A/B switch: 0 = every r = 32 devoxelisation redoes its per-cloud setup
 
@@ -55,17 +56,21 @@ def voxel_plans():
         _VOX_PLANS = prev
 
 
-def _occupancy(counts, r, cout, b):
+def _occupancy(counts, r, cout, b, level=None):
     """tile occupancy + work lists (fused_ops.conv3d_occupancy) of the count grid of a (cloud, r) pair: the same for every
     PVConv that voxelises this pair (the sparse tile plan depends on r only), so while a forward's plans are alive it is
     computed once and every convolution of the pair works from the SAME buffers: a sparse convolution re-arms its work
-    queue when its last workgroup leaves (round 5; until then every use took a copy -- 7 copy launches per step)."""
+    queue when its last workgroup leaves (round 5; until then every use took a copy -- 7 copy launches per step).
+    level: the consumer-aware level of the buffers (0 every voxel written, 1 unread empty tiles skipped, 2 the delta
+    convolution is the split kernel: conv1 stores occupied tiles only); None = 1 if SKIP_UNREAD else 0."""
+    if level is None:
+        level = 1 if SKIP_UNREAD else 0
     if _VOX_PLANS is None or not OCC_PLAN:
-        return fused_ops.conv3d_occupancy(counts, r, cout, b, consumer_aware=SKIP_UNREAD)
-    key = ("occ", counts.data_ptr(), tuple(counts.shape), int(r), int(b))
+        return fused_ops.conv3d_occupancy(counts, r, cout, b, consumer_aware=level)
+    key = ("occ", counts.data_ptr(), tuple(counts.shape), int(r), int(b), int(level))
     hit = _VOX_PLANS.get(key)
     if hit is None:
-        o1, o2 = fused_ops.conv3d_occupancy(counts, r, cout, b, consumer_aware=SKIP_UNREAD)
+        o1, o2 = fused_ops.conv3d_occupancy(counts, r, cout, b, consumer_aware=level)
         hit = (counts, (o1, o2))   # counts stays alive with the entry
         _VOX_PLANS[key] = hit
     if OCC_CLONE:   # A/B against a library from before round 5, whose convolutions leave the queue counter consumed
@@ -346,7 +351,7 @@ class Voxelization(nn.Module):
             if plan is not None:   # phases B + C only: the voxel ids of this cloud at this resolution exist already
                 occ_m1 = None
                 if sparse_reader and SKIP_UNREAD and SPARSE_CONV1 and self.r in (16, 32) and hasattr(_backend, "voxel_scatter"):
-                    occ_m1 = _occupancy(plan["cnt"], self.r, 64, b)[0]
+                    occ_m1 = _occupancy(plan["cnt"], self.r, 64, b, int(sparse_reader))[0]
                 out = _backend.voxel_scatter(features.float().contiguous(), plan, occ_m1)
                 return out.view(b, c, self.r, self.r, self.r), plan["norm"], plan["cnt"]
             out, norm_coords, _, counts = _backend.voxelize_points_forward(
@@ -392,6 +397,16 @@ class PVConv(nn.Module):
             self.point_features = SharedMLP(in_channels, out_channels, cfg=cfg)
         self.add_point_feat = add_point_feat
 
+    def _aware_level(self):
+        """consumer-aware level of this PVConv's occupancy buffers (fused_ops.conv3d_occupancy): 2 when the delta convolution
+        runs on the split kernel (it then stages zeros for the rows of conv1's empty tiles without loading them, and conv1
+        stores occupied tiles only), else 1; 0 with LION_CONV_SKIP_UNREAD=0."""
+        if not SKIP_UNREAD:
+            return 0
+        from .. import conv_ops
+        conv2 = self.voxel_layers[4]
+        return 2 if (SKIP_UNREAD_LEVEL2 and conv_ops.use_split(None, conv2.in_channels, conv2.out_channels, self.resolution)) else 1
+
     def _fused_voxel_branch(self, grid, voxel_coords, style, counts=None):
         """eval-mode voxel branch with every pointwise stage folded into the convolutions / the
         devoxelisation (lion_amd/fused_ops.py): conv1 (+GN sums) -> fold -> conv2 with the
@@ -402,7 +417,7 @@ class PVConv(nn.Module):
         r = self.resolution
         occ1 = occ2 = None
         if SPARSE_CONV1 and counts is not None and r >= 16:
-            occ1, occ2 = _occupancy(counts, r, conv1.out_channels, grid.shape[0])
+            occ1, occ2 = _occupancy(counts, r, conv1.out_channels, grid.shape[0], self._aware_level())
         y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, occ1)  # skips all-zero tiles
         f1, g1 = gn1.affine(style)
         a1, b1, _ = fused_ops.groupnorm_fold(st1, gn1.norm, f1, g1, r ** 3)
@@ -429,7 +444,8 @@ class PVConv(nn.Module):
                 and not torch.is_autocast_enabled()):
             # the fused voxel branch below is the grid's only reader, and its first convolution runs sparse
             will_fuse = fused_ops.fusable(self.voxel_layers[0], self.voxel_layers[4], self.resolution, features.float())
-            grid, voxel_coords, counts = self.voxelization(features, coords, return_counts=True, sparse_reader=will_fuse)
+            grid, voxel_coords, counts = self.voxelization(features, coords, return_counts=True,
+                                                           sparse_reader=self._aware_level() if will_fuse else 0)
         else:
             grid, voxel_coords = self.voxelization(features, coords)
         if (FUSE_INFERENCE and not self.training and not torch.is_grad_enabled()

@@ -886,7 +886,12 @@ def test_conv3d_tile_occupancy_matches_dilation_reference(r, cout, n):
         word = occ[:B * nt].view(B, nt)
         flags = word & 0xf                # 4-bit masks: bit w = wave w's 64-voxel block sees a point; 0 = empty tile
         assert torch.equal((flags != 0).int(), ref), m
-        assert int((word >> 9).max()) == 0
+        assert int((word >> 10).max()) == 0
+        # bit 9 (margin-2 words only): the tile is occupied at margin 1 -- the split delta convolution loads the first
+        # convolution's output only inside such tiles (aware level 2)
+        d1 = torch.nn.functional.max_pool3d(g, 3, 1, 1)[:, 0]
+        occ1_ref = d1.view(B, r // td, td, r // th, th, r).amax(dim=(2, 4, 5)).reshape(B, nt).int()
+        assert torch.equal((word >> 9) & 1, occ1_ref if m == 2 else torch.zeros_like(occ1_ref)), m
         # round 5, bit 8 = the tile's output has a reader: margin 2 -- the tiles around the points themselves (the
         # devoxelisation); margin 1 -- the margin-2 tiles and their neighbours in the (d, h) tile grid (the delta conv's halos)
         d2 = torch.nn.functional.max_pool3d(g, 5, 1, 2)[:, 0]
