@@ -788,6 +788,12 @@ def main():
             sbytes = 4.0 * B * (C * N + C * r ** 3 + 4 * N)
             roofv = hbm_roofline("voxel_scatter (K2 from the index plan) C=64 N=2048 r=32: vox_scatter_kernel", sbytes, ts)
             roofv["index_kernel_us (once per (cloud, r) pair, 4 per forward)"] = ti * 1e6
+            # the form a PVConv's fused branch launches since round 5: the grid's only reader is the sparse convolution, z-rows
+            # outside every occupied tile's halo are not written (lion_voxel_scatter_read; fewer bytes: not a roofline figure)
+            occ_r = fused_ops.conv3d_occupancy(plan["cnt"], r, 64, B, consumer_aware=2)[0]
+            tsr = ev_time_graph(lambda: bk.voxel_scatter(ft, plan, occ_r), 20)
+            roofv["sparse_reader_form_us (lion_voxel_scatter_read, same cloud: rows nobody reads are not written)"] = tsr * 1e6
+            del occ_r
             roofv["fused_single_call"] = hbm_roofline("voxelize_points (P1+K1+K2 in one launch, the C-ABI drop-in entry): "
                                                       "vox_fused_kernel", vbytes, tv)
             nc = plan["norm"]

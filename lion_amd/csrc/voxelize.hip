@@ -68,7 +68,7 @@ __device__ __forceinline__ int lds_slot_add_aggregated(int32_t *arr, int idx, bo
 // Phases B + C of one (cloud, slab, channel range) workgroup, shared by the fused kernel and the plan-driven scatter
 // kernel.  In LDS: slot[SV] dense (voxel -> rank among the slab's occupied voxels, -1 = empty), ust[my_occ]
 // ((start << 16) | count per occupied voxel); per thread: the sorted position (or -1) and 1 / count of its NP points.
-template <int NP>
+template <int NP, bool READ = false>
 __device__ __forceinline__ void vox_means_and_store(
     const float *__restrict__ feat, float *__restrict__ out, int b, int C, int N, int r3, int lo, int SV, int cs, int CS,
     int my_pts, int my_occ, const int (&posv)[NP], const float (&invp)[NP], const int32_t *slot, const int32_t *ust,
@@ -137,7 +137,7 @@ __device__ __forceinline__ void vox_means_and_store(
       o.z = sl.z >= 0 ? z : 0.f;
       o.w = sl.w >= 0 ? w : 0.f;
       // slot -2 (lion_voxel_scatter_read): a z-row no convolution tile stages -- its zeros have no reader, nothing is stored
-      if (sl.x != -2) *reinterpret_cast<float4 *>(obase + (size_t)cl * r3 + 4 * g) = o;
+      if (!READ || sl.x != -2) *reinterpret_cast<float4 *>(obase + (size_t)cl * r3 + 4 * g) = o;
       cl += step_c; g += step_g;
       if (g >= q4) { g -= q4; ++cl; }
     }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(VT) void vox_fused_kernel(
 }
 
 // vox_scatter_kernel: phases B + C from a stored plan.  LDS (dynamic): slot[SV] | ust[n_words] | arena.
-template <int NP>
+template <int NP, bool READ>
 __global__ __launch_bounds__(VT) void vox_scatter_kernel(
     const float *__restrict__ feat, const void *__restrict__ plan, int B, int C, int N, int r3, int S, int CS, int SV,
     int n_words, int arena_words, int ch_cap, float *__restrict__ out, const int32_t *__restrict__ occ_flags, int r, int TD,
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
     posv[p] = mine ? (w & 0xffff) : -1;
     invp[p] = mine ? iv : 0.f;
   }
-  if (occ_flags) {
+  if constexpr (READ) {
     // Round 5: the grid's only reader is the sparse convolution that pops occ_flags (lion_conv3d_tile_occupancy, margin 1):
     // it stages the halo -- one voxel in d and h, all of w -- of the tiles with a point within one voxel, nothing else.  A
     // z-row (d, h) outside every such halo is never read: its voxels (all empty -- a point's own row lies inside an occupied
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
     ust[u] = ust_g[u];
     slot[uvl_g[u]] = u;
   }
-  vox_means_and_store<NP>(feat, out, b, C, N, r3, slab * SV, SV, cs, CS, my_pts, my_occ, posv, invp, slot, ust, arena,
-                          arena_words, ch_cap);
+  vox_means_and_store<NP, READ>(feat, out, b, C, N, r3, slab * SV, SV, cs, CS, my_pts, my_occ, posv, invp, slot, ust, arena,
+                                arena_words, ch_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -573,8 +573,7 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
   // (70 -> 74 us), so r = 32 keeps one workgroup per CU.
   const bool two_per_cu = N <= VT;
   const long wgs = two_per_cu ? 512 : 256;
-  // (the kernel's static LDS -- the 1-KiB row map of the reader-aware form -- comes out of the same budget)
-  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - 1024 - 64;
+  const size_t lds_limit = two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT;
   // slabs per cloud: enough workgroups to touch every CU, slabs of >= 512 voxels (int4 groups)
   int S = 1;
   while (S < 16 && (long)B * S < wgs && r3 / (S * 2) >= 512 && (r3 % (S * 2 * 4)) == 0) S *= 2;
@@ -753,8 +752,8 @@ static int voxel_scatter_impl(const float *feat, const void *plan, size_t plan_b
     while ((long)B * p.S * CS < 512 && C / (CS * 2) >= 8) CS *= 2;
     p.CS = CS;
   }
-  // (the kernel's static LDS -- the 1-KiB row map of the reader-aware form -- comes out of the same budget)
-  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - 1024 - 64;
+  // (the static LDS of the reader-aware instantiation -- its 1-KiB row map -- comes out of the same budget)
+  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - (occ_flags ? 1024 + 64 : 0);
   const size_t fixed = ((size_t)p.SV + (size_t)p.n_words) * 4;
   const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
   const size_t want = ((size_t)N + nocc) * C * 4;
@@ -766,11 +765,16 @@ static int voxel_scatter_impl(const float *feat, const void *plan, size_t plan_b
   const int r3 = r * r * r;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define LION_VOXS_LAUNCH(NPV)                                                                          \
-  {                                                                                                    \
+  if (occ_flags) {                                                                                     \
     static LionLdsLimit cfg = {};                                                                      \
-    if (int e = lion_dynamic_lds(&vox_scatter_kernel<NPV>, lds, cfg)) return e;                        \
-    vox_scatter_kernel<NPV><<<grid, VT, lds, st>>>(feat, plan, B, C, N, r3, p.S, p.CS, p.SV, p.n_words, \
-                                                   (int)(arena / 4), 64, out, occ_flags, r, r == 32 ? 2 : 4, 4); \
+    if (int e = lion_dynamic_lds(&vox_scatter_kernel<NPV, true>, lds, cfg)) return e;                  \
+    vox_scatter_kernel<NPV, true><<<grid, VT, lds, st>>>(feat, plan, B, C, N, r3, p.S, p.CS, p.SV, p.n_words, \
+                                                         (int)(arena / 4), 64, out, occ_flags, r, r == 32 ? 2 : 4, 4); \
+  } else {                                                                                             \
+    static LionLdsLimit cfg = {};                                                                      \
+    if (int e = lion_dynamic_lds(&vox_scatter_kernel<NPV, false>, lds, cfg)) return e;                 \
+    vox_scatter_kernel<NPV, false><<<grid, VT, lds, st>>>(feat, plan, B, C, N, r3, p.S, p.CS, p.SV, p.n_words, \
+                                                          (int)(arena / 4), 64, out, nullptr, r, 0, 0); \
   }
   switch (p.NP) {
   case 1: LION_VOXS_LAUNCH(1) break;
