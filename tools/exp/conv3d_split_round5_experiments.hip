@@ -50,19 +50,102 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
 // instrumented COPY of this file (0 item prologue, 1 waits at the chunk's two plane barriers, 2 load issue + wait + activate +
 // max, 3 max barrier, 4 cut + LDS write, 5 wait for the next weight group + group barrier, 6 taps, 7 epilogue); the product build carries no instrumentation and no switches.
 
-// Round-5 experiments on the sparse plan that were built, bit-exact, measured on one box inside the sampling step and NOT
-// adopted live in tools/exp/conv3d_split_round5_experiments.hip (this file with the switches LION_SPLIT_COMPACT /
-// LION_SPLIT_FILL; build with tools/build_variant.sh NAME conv3d_split=tools/exp/conv3d_split_round5_experiments.hip:-D...):
-//   * voxel compaction inside occupied tiles (active voxels packed into 32-column MFMA blocks, a one-block wave path):
-//     sparse launches 8-11 % faster, dense ones 5-6 % slower (a third copy of the K walk costs the register allocation 40
-//     bytes of scratch around the staging), step 6.84 -> 6.93 ms;
-//   * a plane-fill kernel for empty tiles in front of the convolution: serialises 30-40 us per convolution, step 6.84 -> 7.05 ms
-//     (as queue items inside this kernel it cost the dense layer 37 %).
-// Evidence: profiles/r05a_conv_ab_variants_one_box.txt, r05a_conv_ab_r04_vs_fill_items_in_kernel.txt,
-// r05b_conv_epilogue_phases.txt (where a launch's cycles go).  What was adopted instead is below: empty tiles nobody reads are
-// not stored at all (aware levels), and the work queue re-arms itself.
 template <int N> struct IntC { static constexpr int value = N; }; // compile-time count for generic lambdas
 
+// Compile-time switches of the round-5 sparse-plan experiments.  BOTH ARE OFF in the product: built, bit-exact, measured on
+// one box against the round-4 kernel inside the sampling step (profiles/r05a_conv_ab_variants_one_box.txt) and not adopted:
+//   LION_SPLIT_COMPACT 1: voxel compaction inside occupied tiles (below).  Sparse launches on the chain's clouds 8-11 %
+//                         faster (r = 32: 195 -> 179 us, r = 16: 160 -> 142 us), dense launches 5-6 % slower (the third copy
+//                         of the K walk costs the register allocation 40 bytes of scratch around the staging); step 6.84 ->
+//                         6.93 ms.  What a sparse item costs is not its MFMAs: on the chain's clouds 40 % of a sparse launch's wave
+//                         cycles are the epilogue (80 % of its items are empty tiles), 15 % the queue pop, 45 % the K loop
+//                         (profiles/r05b_conv_epilogue_phases.txt).
+//                      0: the round-3 wave masks (a wave skips its 64-voxel block when no point is within the margin).
+//   LION_SPLIT_FILL    1: empty tiles written by split_fill_kernel in front of the convolution (16-byte stores in plane
+//                         order).  As a kernel of its own it serialises 30-40 us per convolution that the empty work items
+//                         overlap with the occupied tiles' MFMAs: step 6.84 -> 7.05 ms.  As queue items inside the convolution
+//                         kernel (even as a non-inlined function) it cost the dense layer 37 %
+//                         (profiles/r05a_conv_ab_r04_vs_fill_items_in_kernel.txt).
+//                      0: every empty tile is a work item of the convolution (its epilogue writes bias / constant response).
+// tools/build_variant.sh NAME 'conv3d_split:-DLION_SPLIT_COMPACT=1 -DLION_SPLIT_FILL=1' builds the others; the GPU tests
+// run on every variant (tests/test_hip_parity_gpu.py::test_conv3d_voxel_compaction_matches_dense checks outputs, not which
+// path produced them).
+#ifndef LION_SPLIT_COMPACT
+#define LION_SPLIT_COMPACT 0
+#endif
+#ifndef LION_SPLIT_FILL
+#define LION_SPLIT_FILL 0
+#endif
+
+// The EMPTY tiles of a sparse launch: workgroup (sample fb, FCO channel planes) writes bias / the constant response per
+// border configuration with 16-byte stores in plane order, leaving out the rows of occupied tiles (those write all of their
+// voxels themselves), and the GroupNorm sums of the sample's empty tiles in closed form (voxels per border configuration x
+// value).  Round 5 measured why this is not left to the convolution's work items: with every empty tile an item of its own
+// (64 stores of 4 bytes per lane into 2 x 512-byte runs per channel) the sparse launches spent 46 % of their cycles in the
+// epilogue and 16 % waiting for its stores at the next queue pop (profiles/r05a_conv_phase_times_sparse_*.txt) -- 268 MB of
+// constants leaving at ~1.6 TB/s.  Inside the convolution kernel (as queue items, even as a non-inlined function) the
+// extra code cost the register allocation of the tap loop 37 % of the dense layer's time
+// (profiles/r05a_conv_ab_r04_vs_fill_items_in_kernel.txt); as a kernel of its own it runs at the stores' rate in front of it.
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void split_fill_kernel(int FCO, bool fdelta, float *__restrict__ y,
+                                                         const float *__restrict__ bias, const float *__restrict__ tconst,
+                                                         float *__restrict__ stats, const int32_t *__restrict__ occ, int B,
+                                                         int Cout, int r, int ntiles) {
+  constexpr int TM = 256;
+  __shared__ unsigned char s_fl[256];
+  __shared__ float s_ft[27 * 8];
+  const int tid = threadIdx.x, r3_ = r * r * r;
+  const int f = blockIdx.x, fb = f % B, fc0 = (f / B) * FCO;
+  for (int t = tid; t < ntiles; t += TM) s_fl[t] = occ[fb * ntiles + t] != 0;
+  for (int e = tid; e < 27 * FCO; e += TM) {
+    const int cfg = e / FCO, c = fc0 + e % FCO;
+    s_ft[e] = fdelta ? tconst[((size_t)fb * 27 + cfg) * Cout + c] : (bias ? bias[c] : 0.f);
+  }
+  __syncthreads();
+  const int nth_ = r / TH, rr = r * r, q_per = r3_ >> 2;
+  float *yf = y + ((size_t)fb * Cout + fc0) * r3_;
+  for (int q = tid; q < FCO * q_per; q += TM) {
+    const int cl = q / q_per, v0 = (q - cl * q_per) << 2;
+    const int d = v0 / rr, h = (v0 - d * rr) / r, w0_ = v0 - d * rr - h * r;
+    if (s_fl[(d / TD) * nth_ + h / TH]) continue; // an occupied tile writes all of its voxels itself
+    const int cdh = ((d == 0 ? 0 : d == r - 1 ? 2 : 1) * 3 + (h == 0 ? 0 : h == r - 1 ? 2 : 1)) * 3;
+    const float mid = s_ft[(cdh + 1) * FCO + cl];
+    typedef float f4s __attribute__((ext_vector_type(4)));
+    f4s o = {w0_ == 0 ? s_ft[cdh * FCO + cl] : mid, mid, mid, w0_ + 4 == r ? s_ft[(cdh + 2) * FCO + cl] : mid};
+    *reinterpret_cast<f4s *>(yf + (size_t)cl * r3_ + v0) = o;
+  }
+  if (stats) {
+    for (int e = tid; e < FCO * ntiles; e += TM) {
+      const int cl = e / ntiles, t = e - cl * ntiles;
+      if (s_fl[t]) continue;
+      const int dt = (t / nth_) * TD, ht = (t % nth_) * TH;
+      const int nd[3] = {dt == 0 ? 1 : 0, TD - (dt == 0 ? 1 : 0) - (dt + TD == r ? 1 : 0), dt + TD == r ? 1 : 0};
+      const int nh[3] = {ht == 0 ? 1 : 0, TH - (ht == 0 ? 1 : 0) - (ht + TH == r ? 1 : 0), ht + TH == r ? 1 : 0};
+      const int nw[3] = {1, TW - 2, 1}; // tiles span the w axis (TW == r)
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int cfg = 0; cfg < 27; ++cfg) {
+        const float n = (float)(nd[cfg / 9] * nh[(cfg / 3) % 3] * nw[cfg % 3]), tv = s_ft[cfg * FCO + cl];
+        s1 += n * tv;
+        s2 += n * (tv * tv);
+      }
+      float *o = stats + (((size_t)fb * Cout + fc0 + cl) * ntiles + t) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+}
+
+// Round 5 -- voxel compaction inside an occupied tile (sparse launches, occ != NULL; LION_SPLIT_COMPACT).  In the chain the latent clouds sit
+// in a few hundred voxels: of the tiles that are NOT empty, 3-7 % (r = 32) / 10-22 % (r = 16) of the voxels have a point
+// within the margin (tools/tile_shape_estimate.py on the dumped x_t), yet the wave masks of round 3 skip a 64-voxel block
+// only when all of it is clear.  The occupancy buffer now carries the tile's 256-bit ACTIVE map; the workgroup packs the
+// active voxels (ascending order) into 32-voxel column blocks, block j -> wave j % 4, slot j / 4, and a wave runs the tap
+// loop for the blocks it got -- none, one (half the MFMAs) or two.  A lane's MFMA column may be any voxel of the tile (its
+// fragment address is its halo position); lanes beyond the active count repeat the last active voxel and store nothing.
+// Every voxel that is not active is written as bias / constant response by the thread that owns it (thread t <-> voxel t),
+// and enters the GroupNorm sums in closed form (counts per border configuration x table).  Outputs are bit-identical to the
+// dense evaluation (same K order per voxel, same tile scale); the tile sums differ in summation order only.
 template <int TD, int TH, int TW, int CB, int VB, bool PRO, bool STATS, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__restrict__ x, const u4 *__restrict__ wp,
                                                               const float *__restrict__ wtail,
@@ -93,13 +176,27 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   float *sT = reinterpret_cast<float *>(sx);  // [27][COT] constant response (delta mode), loaded after the K loop
   __shared__ int s_work;
   __shared__ unsigned s_max[2];               // bits of the chunk's max |activation| (double buffered over chunks)
+  __shared__ unsigned char s_list[256];       // sparse launches: the tile's active voxels, ascending
+  __shared__ int s_wcnt[4];                   // active voxels among each wave's 64
+  __shared__ int s_cls[27];                   // voxels that are NOT active, per border configuration
   __shared__ unsigned char s_rowok[256];      // aware level 2, delta launches: this staging thread's halo row has been written
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 5, l32 = lane & 31;
   const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_wscale_kernel)
   const bool queued = occ != nullptr;
   const int ncz = Cout / COT;
-  const int n_tile_items = ntiles * B * ncz;
+  // Sparse launches with the fill kernel in front (LION_SPLIT_FILL) queue only the OCCUPIED tiles: (sample, k-th tile of its
+  // list) for k below the largest per-sample count; a sample with fewer occupied tiles skips its surplus items at once.
+  int kmax = ntiles;
+  if (LION_SPLIT_FILL && queued) {
+    const int32_t *nocc = occ + 10 * B * ntiles + 4;
+    int v = 0;
+    for (int i = lane; i < B; i += 64) v = max(v, nocc[i]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    kmax = __builtin_amdgcn_readfirstlane(v);
+  }
+  const int n_tile_items = kmax * B * ncz;
   // consumer-aware buffers (lion_conv3d_tile_occupancy_aware): empty tiles whose output nobody reads store nothing
   const int aware_level = queued ? occ[2 * B * ntiles + 2] : 0;
   const bool aware = aware_level != 0;
@@ -132,7 +229,20 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   // thread t owns voxel t of the tile ((d, h, w) order) for the bookkeeping of the sparse plan
   int n_act = 4 * VB * 32;
   int wmask = 0xf;
-  if (queued) { // round-3 plan: bit w of the tile's flag = wave w's 64-voxel block sees a point; bit 8 = has a reader
+  if (queued && LION_SPLIT_COMPACT) {
+    const unsigned *abits = reinterpret_cast<const unsigned *>(occ + 2 * B * ntiles + 4) + ((size_t)b * ntiles + tile) * 8;
+    const bool t_act = (abits[tid >> 5] >> (tid & 31)) & 1u;
+    const unsigned long long bal = __ballot(t_act);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    if (tid < 27) s_cls[tid] = 0;
+    __syncthreads();
+    int before = 0;
+    n_act = 0;
+#pragma unroll
+    for (int w_ = 0; w_ < 4; ++w_) { const int c = s_wcnt[w_]; before += w_ < wave ? c : 0; n_act += c; }
+    if (t_act) s_list[before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)tid;
+    // (visible to the tap loop behind the first barrier of chunk(); an empty tile never reads it)
+  } else if (queued) { // round-3 plan: bit w of the tile's flag = wave w's 64-voxel block sees a point; bit 8 = has a reader
     const int fw = occ[b * ntiles + tile];
     wmask = fw & 0xf;
     n_act = wmask ? 4 * VB * 32 : 0;
@@ -168,7 +278,11 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
     }
   }
   n_act = __builtin_amdgcn_readfirstlane(n_act);
-  const int my_nvb = ((wmask >> wave) & 1) ? VB : 0; // column blocks this wave runs the taps on: all of its own, or none
+  if (LION_SPLIT_FILL && queued && n_act == 0) continue; // (fewer occupied tiles than kmax: split_fill_kernel wrote this one)
+  // column blocks of 32 active voxels: block j -> wave j % 4, slot j / 4 (dense launches: wave w owns blocks VB w ..)
+  const int nblk = (n_act + 31) >> 5;
+  const bool compact = queued && LION_SPLIT_COMPACT;
+  const int my_nvb = compact ? (wave < nblk ? 1 : 0) + (wave + 4 < nblk ? 1 : 0) : ((wmask >> wave) & 1) ? VB : 0;
   const bool pro_on = PRO && pro_a != nullptr; // the PRO instantiation also serves launches without a prologue (see
   const bool delta = pro_on && tconst != nullptr; // launch_split_t: its register allocation is the better one)
   if (pro_on) {
@@ -373,7 +487,11 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       const int g_ = ln >> 5, l32_ = ln & 31;
 #pragma unroll
       for (int vb = 0; vb < NVB; ++vb) { // halo position of this lane's voxel in the wave's column block vb
-        const int v = (wave * VB + vb) * 32 + l32_;
+        int v = (wave * VB + vb) * 32 + l32_;
+        if (compact) { // the (wave + 4 vb)-th block of the tile's active voxels; lanes past the end repeat the last one
+          const int i = (wave + 4 * vb) * 32 + l32_;
+          v = s_list[i < n_act ? i : n_act - 1];
+        }
         const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
         xq[vb] = sx_lds + (uint32_t)((g_ * HP + (d * HH + h) * HW + w) * 16);
         asm volatile("" : "+v"(xq[vb]));
@@ -472,9 +590,18 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   // waits for the stores issued before it: 18-23 store / wait / store sequences per epilogue (tools/store_wait_scan.py),
   // each a round trip to memory.
   int gvv[VB];
+  bool valid[VB];
 #pragma unroll
   for (int vb = 0; vb < VB; ++vb) {
-    const int v = (wave * VB + vb) * 32 + l32;
+    int v = (wave * VB + vb) * 32 + l32;
+    valid[vb] = true;
+    if constexpr (LION_SPLIT_COMPACT != 0) {
+      if (compact) { // as in the tap loop: the (wave + 4 vb)-th block of the active voxels
+        const int i = (wave + 4 * vb) * 32 + l32;
+        valid[vb] = i < n_act;
+        v = valid[vb] ? s_list[i] : 0;
+      }
+    }
     const int d = v / (TH * TW), h = (v / TW) % TH, w = v % TW;
     const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
     gvv[vb] = (gd * r + gh) * r + gw;
@@ -489,16 +616,51 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         acc[cb][vb][i] = ((acc[cb][vb][i] + cor[cb][vb][i] * (1.f / 2048.f)) * us_x) * us_w + addv[co];
       }
   }
+  if constexpr (LION_SPLIT_COMPACT != 0) {
 #pragma unroll
-  for (int vb = 0; vb < VB; ++vb)
+    for (int vb = 0; vb < VB; ++vb)
+      if (valid[vb]) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
-        const float o = acc[cb][vb][i];
-        yb[(size_t)co * r3 + gvv[vb]] = o;
+          for (int i = 0; i < 16; ++i) {
+            const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+            const float o = acc[cb][vb][i];
+            yb[(size_t)co * r3 + gvv[vb]] = o;
+          }
       }
+  } else {
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int co = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * g;
+          const float o = acc[cb][vb][i];
+          yb[(size_t)co * r3 + gvv[vb]] = o;
+        }
+  }
+  bool t_act = true; // (read again rather than kept alive across the K loop: the kernel sits at the 256-register limit)
+  if (compact) {
+    int tt = tid;
+    asm volatile("" : "+v"(tt));
+    const unsigned *abits = reinterpret_cast<const unsigned *>(occ + 2 * B * ntiles + 4) + ((size_t)b * ntiles + tile) * 8;
+    t_act = (abits[tt >> 5] >> (tt & 31)) & 1u;
+  }
+  if (compact && !t_act) {
+    // the voxels no lane computed: thread t writes voxel t of the tile = bias / the constant response of its border
+    // configuration, exactly what the dense evaluation leaves there (its accumulators are exact zeros)
+    const int d = tid / (TH * TW), h = (tid / TW) % TH, w = tid % TW;
+    const int gd = d0 + d, gh = h0 + h, gw = w0 + w;
+    const int cfg = (((gd == 0 ? 0 : gd == r - 1 ? 2 : 1) * 3 + (gh == 0 ? 0 : gh == r - 1 ? 2 : 1)) * 3 +
+                     (gw == 0 ? 0 : gw == r - 1 ? 2 : 1));
+    const float *addv = delta ? sT + cfg * COT : sbias;
+    float *yv = yb + (gd * r + gh) * r + gw;
+#pragma unroll 8
+    for (int co = 0; co < COT; ++co) yv[(size_t)co * r3] = addv[co];
+    if (STATS) atomicAdd(&s_cls[delta ? cfg : 0], 1); // LDS integer atomic: order free, result exact
+  }
   if (STATS) { // per-tile channel sums, as csrc/conv3d.hip
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -507,7 +669,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int vb = 0; vb < VB; ++vb) {
-          const float o = acc[cb][vb][i];
+          const float o = valid[vb] ? acc[cb][vb][i] : 0.f;
           s1 += o;
           s2 += o * o;
         }
@@ -524,6 +686,19 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
+      if (compact && n_act < 4 * VB * 32) { // the voxels written as constants, in closed form: count x value per configuration
+        if (delta) {
+          for (int c = 0; c < 27; ++c) {
+            const float n = (float)s_cls[c], tv = sT[c * COT + tid];
+            s1 += n * tv;
+            s2 += n * (tv * tv);
+          }
+        } else {
+          const float n = (float)s_cls[0], tv = sbias[tid];
+          s1 += n * tv;
+          s2 += n * (tv * tv);
+        }
+      }
       float *o = stats + (((size_t)b * Cout + co0 + tid) * ntiles + tile) * 2;
       o[0] = s1;
       o[1] = s2;
@@ -570,6 +745,12 @@ static int launch_split_t(const float *x, const u4 *wp, const float *wtail, cons
     if (int e = lion_dynamic_lds(&conv3d_split_kernel<TD, TH, TW, CB, VB, PRO_, ST_, OCC>, LDS, cfg)) return e;   \
     conv3d_split_kernel<TD, TH, TW, CB, VB, PRO_, ST_, OCC><<<grid, 256, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, r, pa, pb, \
                                                                               pbias, tconst, stats, occ, B, tiles); \
+  }
+  if (occ && LION_SPLIT_FILL) { // the empty tiles (and their GroupNorm sums) first, at the stores' rate; disjoint from what the
+    const int FCO = r >= 32 ? 1 : 8; // convolution's items write: 128 KiB of output per workgroup
+    if (Cout % FCO != 0 || tiles > 256) return LION_EUNSUPPORTED;
+    split_fill_kernel<TD, TH, TW><<<B * (Cout / FCO), 256, 0, st>>>(FCO, pa != nullptr && tconst != nullptr, y, bias, tconst, stats,
+                                                                  occ, B, Cout, r, tiles);
   }
   if (pro_inst && stats) LION_SPLIT_GO(true, true)
   else if (pa) LION_SPLIT_GO(true, false)
