@@ -72,15 +72,20 @@ template <int NP, bool READ = false>
 __device__ __forceinline__ void vox_means_and_store(
     const float *__restrict__ feat, float *__restrict__ out, int b, int C, int N, int r3, int lo, int SV, int cs, int CS,
     int my_pts, int my_occ, const int (&posv)[NP], const float (&invp)[NP], const int32_t *slot, const int32_t *ust,
-    float *arena, int arena_words, int ch_cap) {
+    float *arena, int arena_words, int ch_cap, int c_begin = 0, int c_end = -1) {
   const int tid = threadIdx.x;
   const int q4 = SV >> 2; // int4 groups in the slab
-  const int ch_max = min(ch_cap, my_pts > 0 ? min(C, arena_words / (my_pts + my_occ)) : C);
+  // rows of prod are ps = my_pts | 1 words apart: B2 reads them with one lane per CHANNEL (stride ps), an odd stride
+  // touches every LDS bank once
+  const int ps = my_pts | 1;
+  const int ch_max = min(ch_cap, my_pts > 0 ? min(C, arena_words / (ps + my_occ)) : C);
   const int step_c = VT / q4, step_g = VT - step_c * q4;
-  const int c_per = (C + CS - 1) / CS, c_lo = cs * c_per, c_hi = min(C, c_lo + c_per);
+  const int c_per = (C + CS - 1) / CS;
+  // channels [c_lo, c_hi): the (cs, CS) range, or -- c_end >= 0 -- the caller's explicit range (one chunk of the scatter)
+  const int c_lo = c_end >= 0 ? c_begin : cs * c_per, c_hi = c_end >= 0 ? c_end : min(C, cs * c_per + c_per);
   for (int c0 = c_lo; c0 < c_hi; c0 += ch_max) {
     const int ch = min(ch_max, c_hi - c0);
-    float *prod = arena, *vm = arena + ch * my_pts;
+    float *prod = arena, *vm = arena + ch * ps;
     __syncthreads(); // hist/tmp (or the previous chunk's vm) are dead from here on
     if (my_pts > 0) {
       // B1: every lane reads ITS points' feature rows fully coalesced (the 8 slabs of a cloud share
@@ -99,28 +104,57 @@ __device__ __forceinline__ void vox_means_and_store(
         for (int k = 0; k < CU; ++k)
 #pragma unroll
           for (int p = 0; p < NP; ++p)
-            if (posv[p] >= 0 && cl0 + k < ch) prod[(cl0 + k) * my_pts + posv[p]] = mul_rn(f[k][p], invp[p]);
+            if (posv[p] >= 0 && cl0 + k < ch) prod[(cl0 + k) * ps + posv[p]] = mul_rn(f[k][p], invp[p]);
       }
       __syncthreads();
-      // B2: per-voxel means from LDS, summed in ascending point index (vox.cu:59-71)
+      // B2: per-voxel means from LDS, summed in ascending point index (vox.cu:59-71).  Round 5: consecutive lanes take the
+      // CHANNELS of one voxel (item = voxel * ch + channel), not consecutive voxels of one channel: the lanes of a wave then
+      // walk runs of the same length.  With a voxel per lane, the one lane that held a crowded voxel (the chain's latents
+      // put ~900 of a cloud's 2048 points into one) kept its wave for 900 dependent adds while 63 lanes waited, once per
+      // channel: 22 of a workgroup's 38 us (profiles/r05b_scatter_units_wallclock_log.txt).  The order of every sum is
+      // unchanged -- bit-identical.
       const int items = my_occ * ch;
       for (int it = tid; it < items; it += VT) {
-        const int cl = it / my_occ, u = it - cl * my_occ;
+        const int u = it / ch, cl = it - u * ch;
         const int info = ust[u], st = info >> 16, n = info & 0xffff;
-        const float *pr = prod + cl * my_pts + st;
-        // the sum's ORDER is fixed (ascending point index), its operands are not dependent on it: fetch 8 ahead so that
-        // a voxel of n points costs n dependent adds, not n LDS round trips (in-step clouds: n up to ~150; round 4)
+        const float *pr = prod + cl * ps + st;
+        // the sum's ORDER is fixed, its operands do not depend on it: two buffers of 8, the next one is fetched while the
+        // current one is added (reads past the run fetch words that are never added; past the allocation LDS returns 0)
         float acc = add_rn(0.f, pr[0]);
-        int k = 1;
-        for (; k + 8 <= n; k += 8) {
-          float t[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) t[j] = pr[k + j];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc = add_rn(acc, t[j]);
+        if (n <= 8) {   // (nearly every voxel of a Gaussian cloud)
+          for (int k = 1; k < n; ++k) acc = add_rn(acc, pr[k]);
+          vm[cl * my_occ + u] = acc;
+          continue;
         }
-        for (; k < n; ++k) acc = add_rn(acc, pr[k]);
-        vm[it] = acc; // it == cl * my_occ + u
+        float ta[8], tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ta[j] = pr[1 + j];
+        int k = 1;
+        for (;;) {
+          if (k + 8 > n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (k + j < n) acc = add_rn(acc, ta[j]);
+            break;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tb[j] = pr[k + 8 + j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = add_rn(acc, ta[j]);
+          k += 8;
+          if (k + 8 > n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (k + j < n) acc = add_rn(acc, tb[j]);
+            break;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ta[j] = pr[k + 8 + j];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = add_rn(acc, tb[j]);
+          k += 8;
+        }
+        vm[cl * my_occ + u] = acc;
       }
     }
     __syncthreads();
@@ -407,25 +441,101 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t *slot = reinterpret_cast<int32_t *>(smem);
   int32_t *ust = slot + SV;
-  float *arena = reinterpret_cast<float *>(ust + n_words);
+  int32_t *hdr_s = ust + n_words;   // [16][4]: points, occupied voxels, channels per chunk, chunks left with the owner
+  float *arena = reinterpret_cast<float *>(hdr_s + 64);
   const int tid = threadIdx.x;
   const int W = S * CS;
   const int L = blockIdx.x, grp = L / (8 * W), j8 = L - grp * 8 * W;
   const int b = grp * 8 + (j8 & 7), wq = j8 >> 3, slab = wq % S, cs = wq / S;
   if (b >= B) return;
   const VoxPlanPtrs pl = vox_plan_ptrs(const_cast<void *>(plan), B, N, S);
-  const int32_t *h = pl.hdr + ((size_t)b * S + slab) * 4;
-  const int my_pts = h[0], my_occ = h[1];
+  // Round 5 -- empty slabs adopt the extra chunks of crowded ones.  A slab whose points x channels do not fit the LDS arena
+  // walks its channel range in chunks, one after the other in ONE workgroup; the latents of the sampling chain sit in one or
+  // two slabs of a cloud (up to ~1900 of 2048 points in a single voxel) and leave most of the others without a point, so
+  // that workgroup ran four chunks -- each with a ~1900-long chain of ordered adds -- while its neighbours were done after
+  // 10 us of zeros: (64, 2048, 32) took 110 us on the chain's clouds against 61 us on Gaussian ones
+  // (profiles/r05b_scatter_units_wallclock_log.txt).  Now the cloud's workgroups whose own slab is EMPTY take over chunks
+  // of the crowded slabs (and run them first, then their zeros); a cloud without an empty slab -- nearly every Gaussian
+  // one -- keeps the old assignment.  Same arithmetic per (voxel, channel): bit-identical.
+  const int c_per = (C + CS - 1) / CS, cg_lo = cs * c_per, cg_hi = min(C, cg_lo + c_per);
+  if (cg_lo >= cg_hi) return;
+  // one round trip for the cloud's S headers: lane s of every wave holds slab s's (points, occupied voxels, channels per
+  // chunk, chunks); the scans below read them with lane broadcasts
+  int l_pts = 0, l_occ = 0, l_chm = 1, l_nc = 0;
+  {
+    const int ls = tid & 63;
+    if (ls < S) {
+      const int32_t *hs = pl.hdr + ((size_t)b * S + ls) * 4;
+      l_pts = hs[0];
+      l_occ = hs[1];
+      l_chm = min(ch_cap, l_pts > 0 ? min(C, arena_words / ((l_pts | 1) + l_occ)) : C);
+      l_nc = l_pts > 0 ? (cg_hi - cg_lo + l_chm - 1) / l_chm : 1;
+    }
+  }
+  // every point's (slab << 16 | sorted position) and 1 / count: in flight together with the headers, filtered per chunk
+  int posw[NP];
+  float invw[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int i = min(tid + p * VT, N - 1);
+    posw[p] = (tid + p * VT < N) ? pl.pos[(size_t)b * N + i] : -1;   // (slab field 0xffff: nobody's)
+    invw[p] = pl.inv[(size_t)b * N + i];
+  }
+  const unsigned long long empt = __ballot((tid & 63) < S && l_pts == 0);   // bit s: slab s has no point
+  // Who runs what, computed alike by every workgroup of the cloud (lane s = slab s: chunks still with their owner / load of
+  // an adopter in half chunks, its zeros counting one).  Greedy: the last chunk of the slab with the most chunks left goes
+  // to the least loaded adopter as long as the move lowers the larger of the two; an adopter takes at most five.
+  // Clouds of more than 1024 points only (NP >= 2): the 1024-point instantiation runs two workgroups per CU and the
+  // registers of this block cost it that -- (128, 1024, 16) on Gaussian clouds 31 -> 38 us with it, for 54 -> 41 us on the
+  // chain's clouds and nothing on the chain's step (profiles/r05b_scatter_adoption_ab.txt).
+  int rem = l_nc, ld2 = (((empt >> (tid & 63)) & 1) != 0) ? 1 : 0x7fffff, taken = 0;
+  unsigned long long adopted = 0;   // the chunks this workgroup adopted: 12 bits each, (slab << 8) | chunk
+  int n_adopted = 0;
+  if (NP >= 2 && empt != 0) {
+    for (int it = 0; it < 5 * 16; ++it) {
+      int km = (rem << 8) | (63 - (tid & 63)), ka = (ld2 << 8) | (tid & 63);
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        km = max(km, __shfl_xor(km, m));
+        ka = min(ka, __shfl_xor(ka, m));
+      }
+      km = __builtin_amdgcn_readfirstlane(km);
+      ka = __builtin_amdgcn_readfirstlane(ka);
+      const int smax = 63 - (km & 0xff), nmax = km >> 8, a_ = ka & 0xff, la = ka >> 8;
+      if (nmax < 2 || la + 2 >= 2 * nmax) break;
+      if ((tid & 63) == smax) --rem;
+      if ((tid & 63) == a_) {
+        ld2 += 2;
+        if (++taken == 5) ld2 = 0x7fffff;
+      }
+      if (a_ == slab) adopted |= (unsigned long long)((smax << 8) | (nmax - 1)) << (12 * n_adopted++);
+    }
+  }
+  // the headers move to LDS: held in lanes across the chunk loop they cost the 1024-point instantiation 14 registers and
+  // (128, 1024, 16) went from 31 to 37 us
+  if (tid < S) *reinterpret_cast<int4 *>(hdr_s + 4 * tid) = make_int4(l_pts, l_occ, l_chm, rem);
+  __syncthreads();
+  const int own_nc = __builtin_amdgcn_readfirstlane(hdr_s[4 * slab + 3]);
+  n_adopted = __builtin_amdgcn_readfirstlane(n_adopted);   // (uniform by construction; said so for the register allocator)
+  for (int t = 0; t <= n_adopted; ++t) {
+  // adopted chunks first: the zeros of the own slab then drain behind nobody
+  const int slab_u = __builtin_amdgcn_readfirstlane(t < n_adopted ? (int)((adopted >> (12 * t + 8)) & 0xf) : slab);
+  const int k_u = __builtin_amdgcn_readfirstlane(t < n_adopted ? (int)((adopted >> (12 * t)) & 0xff) : 0);
+  // (wave-uniform values: kept in scalar registers -- as vector registers they cost the 1024-point instantiation its
+  // second workgroup per CU)
+  const int my_pts = __builtin_amdgcn_readfirstlane(hdr_s[4 * slab_u]), my_occ = __builtin_amdgcn_readfirstlane(hdr_s[4 * slab_u + 1]),
+            chm_u = __builtin_amdgcn_readfirstlane(hdr_s[4 * slab_u + 2]);
+  // the own slab: the chunks that were not given away (vox_means_and_store walks the range)
+  const int c_begin = cg_lo + k_u * chm_u,
+            c_end = t < n_adopted ? min(cg_hi, c_begin + chm_u) : my_pts > 0 ? min(cg_hi, cg_lo + own_nc * chm_u) : cg_hi;
+  if (t > 0) __syncthreads(); // the previous chunk's store phase is done with slot / the arena
   int posv[NP];
   float invp[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    const int i = min(tid + p * VT, N - 1);
-    const int w = pl.pos[(size_t)b * N + i];
-    const float iv = pl.inv[(size_t)b * N + i];
-    const bool mine = (tid + p * VT < N) && (w >> 16) == slab;
-    posv[p] = mine ? (w & 0xffff) : -1;
-    invp[p] = mine ? iv : 0.f;
+    const bool mine = (posw[p] >> 16) == slab_u;
+    posv[p] = mine ? (posw[p] & 0xffff) : -1;
+    invp[p] = mine ? invw[p] : 0.f;
   }
   if constexpr (READ) {
     // Round 5: the grid's only reader is the sparse convolution that pops occ_flags (lion_conv3d_tile_occupancy, margin 1):
@@ -433,7 +543,7 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
     // z-row (d, h) outside every such halo is never read: its voxels (all empty -- a point's own row lies inside an occupied
     // tile) get slot -2 and phase C stores nothing there.  The chain's clouds leave ~70 % of an r = 32 grid unread.
     __shared__ unsigned char rowneed[1024];   // rows of this slab (SV / r <= 1024)
-    const int nth = r / TH, ntiles = (r / TD) * nth, row0 = (slab * SV) / r, nrows = SV / r;
+    const int nth = r / TH, ntiles = (r / TD) * nth, row0 = (slab_u * SV) / r, nrows = SV / r;
     const int32_t *fl = occ_flags + (size_t)b * ntiles;
     for (int q = tid; q < nrows; q += VT) {
       const int d = (row0 + q) / r, h = (row0 + q) % r;
@@ -448,14 +558,15 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
     for (int v = tid; v < SV; v += VT) slot[v] = -1;
   }
   __syncthreads();
-  const int32_t *ust_g = pl.ust + ((size_t)b * S + slab) * n_words;
-  const int32_t *uvl_g = pl.uvl + ((size_t)b * S + slab) * n_words;
+  const int32_t *ust_g = pl.ust + ((size_t)b * S + slab_u) * n_words;
+  const int32_t *uvl_g = pl.uvl + ((size_t)b * S + slab_u) * n_words;
   for (int u = tid; u < my_occ; u += VT) {
     ust[u] = ust_g[u];
     slot[uvl_g[u]] = u;
   }
-  vox_means_and_store<NP, READ>(feat, out, b, C, N, r3, slab * SV, SV, cs, CS, my_pts, my_occ, posv, invp, slot, ust, arena,
-                                arena_words, ch_cap);
+  vox_means_and_store<NP, READ>(feat, out, b, C, N, r3, slab_u * SV, SV, cs, CS, my_pts, my_occ, posv, invp, slot, ust, arena,
+                                arena_words, ch_cap, c_begin, c_end);
+  } // chunks of this workgroup
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -591,14 +702,14 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
   // channel, for as many channels as fit
   const size_t need_a = (svp + (size_t)p.n_words) * 4;
   const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
-  size_t want = ((size_t)N + nocc) * (C > 0 ? C : 1) * 4;
+  size_t want = ((size_t)N + 1 + nocc) * (C > 0 ? C : 1) * 4;   // (rows of N | 1 words: vox_means_and_store)
   if (want < need_a) want = need_a;
   const size_t avail = fixed < lds_limit ? lds_limit - fixed : 0;
   const size_t arena = want < avail ? want : avail;
   p.arena_words = (int)(arena / 4);
   p.lds = fixed + (size_t)p.arena_words * 4;
   p.fast = r3 <= (1L << 17) && (r3 % 4 == 0) && (p.SV % 4 == 0) && N <= MAXP * VT && N >= 1 &&
-           arena >= need_a && (size_t)p.arena_words >= (size_t)N + nocc;
+           arena >= need_a && (size_t)p.arena_words >= (size_t)N + 1 + nocc;
   size_t o = 0;
   p.off_vox = o; o += up256((size_t)B * 3 * N * 4); // int coords (fallback P1)
   p.total = o;
@@ -754,12 +865,12 @@ static int voxel_scatter_impl(const float *feat, const void *plan, size_t plan_b
   }
   // (the static LDS of the reader-aware instantiation -- its 1-KiB row map -- comes out of the same budget)
   const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - (occ_flags ? 1024 + 64 : 0);
-  const size_t fixed = ((size_t)p.SV + (size_t)p.n_words) * 4;
+  const size_t fixed = ((size_t)p.SV + (size_t)p.n_words + 64) * 4;   // slot | ust | the cloud's slab headers
   const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
-  const size_t want = ((size_t)N + nocc) * C * 4;
+  const size_t want = ((size_t)N + 1 + nocc) * C * 4;
   const size_t avail = fixed < lds_limit ? lds_limit - fixed : 0;
   const size_t arena = want < avail ? want : avail;
-  if (arena / 4 < (size_t)N + nocc) return LION_EUNSUPPORTED;
+  if (arena / 4 < (size_t)N + 1 + nocc) return LION_EUNSUPPORTED;
   const size_t lds = fixed + arena;
   const int grid = ((B + 7) / 8) * 8 * p.S * p.CS;
   const int r3 = r * r * r;

@@ -115,13 +115,16 @@ def test_voxelize_points_fused_p1(bk, orc, N, r, kind):
     assert np.array_equal(host(out), o_out)
 
 
-@pytest.mark.parametrize("C,N,r", [(6, 2048, 32), (70, 2048, 32), (9, 1024, 16), (130, 256, 8), (5, 64, 8), (3, 1000, 16)])
+@pytest.mark.parametrize("C,N,r", [(6, 2048, 32), (70, 2048, 32), (64, 2048, 32), (128, 1024, 16), (9, 1024, 16), (130, 256, 8), (5, 64, 8),
+                                   (3, 1000, 16)])
 @pytest.mark.parametrize("kind", ["gauss", "surface", "clump", "one-voxel"])
 def test_voxel_index_then_scatter_equals_fused_and_oracle(bk, orc, C, N, r, kind):
     """The two-step form the models use (lion_voxel_index once per (cloud, r), lion_voxel_scatter per feature tensor):
     norm_coords / ids / counts and the float means bit-identical to the fused entry point and to the oracle -- also on
     clouds that put hundreds of points into one voxel (2 % outliers set the normalisation; the latents of a sampling
-    chain look like this) and on a cloud that collapses into a single voxel.  vox.cu:18-72, pvcnn2_ada.py:173-188."""
+    chain look like this) and on a cloud that collapses into a single voxel (round 5: on those, the scatter's workgroups
+    of empty slabs take over channel chunks of the crowded slab; the long ordered sums run one lane per channel).
+    vox.cu:18-72, pvcnn2_ada.py:173-188."""
     rng = np.random.default_rng(C + N + r)
     B = 5
     co = surface_cloud(rng, B, N) if kind == "surface" else gaussian_cloud(rng, B, N)
