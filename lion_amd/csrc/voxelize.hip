@@ -118,7 +118,7 @@ __device__ __forceinline__ void vox_means_and_store(
         const int u = it / ch, cl = it - u * ch;
         const int info = ust[u], st = info >> 16, n = info & 0xffff;
         const float *pr = prod + cl * ps + st;
-        // the sum's ORDER is fixed, its operands do not depend on it: two buffers of 8, the next one is fetched while the
+        // the sum's ORDER is fixed, its operands do not depend on it: two buffers of PW, the next one is fetched while the
         // current one is added (reads past the run fetch words that are never added; past the allocation LDS returns 0)
         float acc = add_rn(0.f, pr[0]);
         if (n <= 8) {   // (nearly every voxel of a Gaussian cloud)
@@ -126,33 +126,36 @@ __device__ __forceinline__ void vox_means_and_store(
           vm[cl * my_occ + u] = acc;
           continue;
         }
-        float ta[8], tb[8];
+        // (8 deep, the 1900-point voxel of a chain cloud costs 21 cycles per add: LDS latency shows; the 1024-point
+        // instantiation has no registers for more -- 16 deep it loses its second workgroup per CU)
+        constexpr int PW = NP >= 2 ? 16 : 8;
+        float ta[PW], tb[PW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ta[j] = pr[1 + j];
+        for (int j = 0; j < PW; ++j) ta[j] = pr[1 + j];
         int k = 1;
         for (;;) {
-          if (k + 8 > n) {
+          if (k + PW > n) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < PW; ++j)
               if (k + j < n) acc = add_rn(acc, ta[j]);
             break;
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) tb[j] = pr[k + 8 + j];
+          for (int j = 0; j < PW; ++j) tb[j] = pr[k + PW + j];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc = add_rn(acc, ta[j]);
-          k += 8;
-          if (k + 8 > n) {
+          for (int j = 0; j < PW; ++j) acc = add_rn(acc, ta[j]);
+          k += PW;
+          if (k + PW > n) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < PW; ++j)
               if (k + j < n) acc = add_rn(acc, tb[j]);
             break;
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ta[j] = pr[k + 8 + j];
+          for (int j = 0; j < PW; ++j) ta[j] = pr[k + PW + j];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc = add_rn(acc, tb[j]);
-          k += 8;
+          for (int j = 0; j < PW; ++j) acc = add_rn(acc, tb[j]);
+          k += PW;
         }
         vm[cl * my_occ + u] = acc;
       }
