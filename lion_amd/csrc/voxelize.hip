@@ -505,7 +505,7 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
       km = __builtin_amdgcn_readfirstlane(km);
       ka = __builtin_amdgcn_readfirstlane(ka);
       const int smax = 63 - (km & 0xff), nmax = km >> 8, a_ = ka & 0xff, la = ka >> 8;
-      if (nmax < 2 || la + 2 >= 2 * nmax) break;
+      if (nmax < 2 || nmax > 256 || la + 2 >= 2 * nmax) break;   // (a chunk index has 8 bits in `adopted`)
       if ((tid & 63) == smax) --rem;
       if ((tid & 63) == a_) {
         ld2 += 2;
