@@ -128,7 +128,7 @@ __device__ __forceinline__ void vox_means_and_store(
         }
         // (8 deep, the 1900-point voxel of a chain cloud costs 21 cycles per add: LDS latency shows; the 1024-point
         // instantiation has no registers for more -- 16 deep it loses its second workgroup per CU)
-        constexpr int PW = NP >= 2 ? 16 : 8;
+        constexpr int PW = (NP == 2 || NP == 4) ? 16 : 8;   // (NP = 8, 1024 threads x <= 128 registers: 16 deep spills)
         float ta[PW], tb[PW];
 #pragma unroll
         for (int j = 0; j < PW; ++j) ta[j] = pr[1 + j];

@@ -142,3 +142,23 @@ def test_no_packed_fp32_arithmetic_in_the_library(tmp_path_factory):
         if n:
             bad[f] = n
     assert not bad, bad
+
+
+def test_1024_point_voxelize_kernels_keep_two_workgroups_per_cu(tmp_path_factory):
+    """Round 5: clouds of <= 1024 points run one point per thread in 1024-thread workgroups, TWO per
+    CU on half the LDS each (voxelize.hip::make_plan, two_per_cu) -- 32 waves per CU = 8 per SIMD, which the register file
+    grants only up to 64 VGPRs (and 96 SGPRs) per wave.  The chunk-adoption block of the scatter kernel and a 16-deep
+    prefetch of the ordered sums each pushed the NP = 1 instantiation past that ((128, 1024, 16): 31 -> 38 us,
+    profiles/r05b_scatter_adoption_ab.txt); both are compiled for NP >= 2 only.  The compiler's own occupancy figure
+    of every NP = 1 instantiation must stay 8, and no voxelize kernel may spill."""
+    lst = _listing("voxelize.hip", tmp_path_factory)
+    seen = 0
+    for m in re.finditer(r'^(\S*(?:vox_scatter_kernelILi1E|vox_fused_kernelILb[01]ELi1E)\S*):', lst, re.M):
+        tail = lst[m.end():]
+        occ = int(re.search(r'^; Occupancy: (\d+)', tail, re.M).group(1))
+        vgpr = int(re.search(r'^; NumVgprs: (\d+)', tail, re.M).group(1))
+        assert occ == 8 and vgpr <= 64, (m.group(1), occ, vgpr)
+        seen += 1
+    assert seen == 4, seen   # scatter <1, reader-aware / plain>, fused <with / without features, 1>
+    for m in re.finditer(r'^; ScratchSize: (\d+)', lst, re.M):
+        assert int(m.group(1)) == 0
