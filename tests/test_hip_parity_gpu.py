@@ -116,7 +116,7 @@ def test_voxelize_points_fused_p1(bk, orc, N, r, kind):
 
 
 @pytest.mark.parametrize("C,N,r", [(6, 2048, 32), (70, 2048, 32), (64, 2048, 32), (128, 1024, 16), (9, 1024, 16), (130, 256, 8), (5, 64, 8),
-                                   (3, 1000, 16)])
+                                   (3, 1000, 16), (20, 4096, 32), (12, 8192, 32)])
 @pytest.mark.parametrize("kind", ["gauss", "surface", "clump", "one-voxel"])
 def test_voxel_index_then_scatter_equals_fused_and_oracle(bk, orc, C, N, r, kind):
     """The two-step form the models use (lion_voxel_index once per (cloud, r), lion_voxel_scatter per feature tensor):
