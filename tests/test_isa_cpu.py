@@ -162,3 +162,21 @@ def test_1024_point_voxelize_kernels_keep_two_workgroups_per_cu(tmp_path_factory
     assert seen == 4, seen   # scatter <1, reader-aware / plain>, fused <with / without features, 1>
     for m in re.finditer(r'^; ScratchSize: (\d+)', lst, re.M):
         assert int(m.group(1)) == 0
+
+
+def test_chunk_log_instrumentation_still_applies_to_the_voxelize_source(tmp_path):
+    """tools/vox_chunk_log_build.py writes an instrumented copy of csrc/voxelize.hip by anchoring on source lines (the
+    product file carries no timing code); a refactor that moves an anchor would silently rot the tool the scatter kernel's
+    round-5 findings came from.  The copy must get all five stamps, the log buffer and the reader's entry point."""
+    out = os.path.join(ROOT, "tools", "exp", "voxelize_chunk_log.hip")
+    existed = os.path.exists(out)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "vox_chunk_log_build.py")], cwd=ROOT)
+    try:
+        s = open(out).read()
+        for k in range(5):
+            assert f"vlog[{k}] = wall_clock64();" in s, k
+        assert "g_vlog[8192 * 8]" in s and "int lion_debug_vox_log(unsigned long long *host, int reset)" in s
+        assert "lion_debug_vox_log" not in open(os.path.join(CSRC, "voxelize.hip")).read()   # the product stays clean
+    finally:
+        if not existed:
+            os.remove(out)
