@@ -154,6 +154,113 @@ def vox_devox_totals(bk, fused_ops, B, dev):
     return rv, rd
 
 
+def surface_latents(B, dev, seed=0):
+    """the 'surface-like' set of SURVEY.md 8d as latent points of the local prior: 2048 points uniform on the unit sphere +
+    0.01 noise per shape, the extra latent channel 0.01 noise; layout [B, 2048 * 4, 1, 1] (point-major, 3 coordinates + 1
+    feature: models/latent_points_ada_localprior.py:72-84)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    v = torch.randn(B, 2048, 3, device=dev, generator=g)
+    v = v / v.norm(dim=2, keepdim=True)
+    v = v + 0.01 * torch.randn(B, 2048, 3, device=dev, generator=g)
+    f = 0.01 * torch.randn(B, 2048, 1, device=dev, generator=g)
+    return torch.cat([v, f], dim=2).reshape(B, 2048 * 4, 1, 1).contiguous()
+
+
+class ForcedClouds:
+    """state_hook of the forced-clouds call: before every model evaluation of the LOCAL prior its latent is overwritten with
+    x_t = sqrt(abar_t) S + sqrt(1 - abar_t) z (the forward process q(x_t | x_0 = S), utils/diffusion_pvd.py:96-113 sample_q)
+    -- the states a TRAINED denoiser visits on its way from N(0, I) to a shape, which random-init weights never produce
+    (their chain collapses into a clump).  Two elementwise launches per step on the chain's stream, no host sync.  With
+    force=False the hook only keeps copies of the latent at five steps (occupancy statistics of the unforced chain)."""
+
+    def __init__(self, d, B, dev, n_steps, force=True):
+        steps = d.ddim_schedule(d._diffusion_steps, n_steps, 'uniform')
+        ab = d._h_alpha_bars[torch.tensor(steps)].double()
+        self.a = ab.sqrt().float().to(dev)
+        self.b = (1.0 - ab).sqrt().float().to(dev)
+        self.force = force
+        if force:
+            self.S = surface_latents(B, dev)
+            self.z = torch.randn(self.S.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        self.keep_at = sorted({0, n_steps // 4, n_steps // 2, (3 * n_steps) // 4, n_steps - 1})
+        self.kept = {}
+
+    def __call__(self, prior_index, i, x):
+        if prior_index != 1:
+            return
+        if self.force:
+            torch.mul(self.S, self.a[i], out=x)
+            x.addcmul_(self.z, self.b[i])
+        if i in self.keep_at:
+            self.kept[i] = x.clone()
+
+
+def empty_tile_fractions(bk, fused_ops, kept, B):
+    """fraction of the r = 32 voxel-convolution tiles (256 voxels) that are EMPTY for conv1 (no point within 1 voxel of the
+    tile) / for the delta conv2 (within 2), on the latents kept by a ForcedClouds hook: mean over the kept steps."""
+    f1, f2 = [], []
+    for i in sorted(kept):
+        co = kept[i].view(B, 2048, 4)[:, :, :3].permute(0, 2, 1).contiguous()
+        plan = bk.voxel_index(co, 32, True, 0.0)
+        o1, o2 = fused_ops.conv3d_occupancy(plan["cnt"], 32, 64, B)
+        nt = (o1.numel() - 4) // 2
+        f1.append(float(((o1[:nt] & 0xf) == 0).float().mean()))
+        f2.append(float(((o2[:nt] & 0xf) == 0).float().mean()))
+    return {"steps": sorted(kept), "conv1_empty": f1, "conv2_empty": f2,
+            "conv1_empty_mean": sum(f1) / len(f1), "conv2_empty_mean": sum(f2) / len(f2)}
+
+
+def _short(sv, n=160):
+    sv = str(sv)
+    return sv if len(sv) <= n else sv[: n - 3] + "..."
+
+
+def compact_line(out):
+    """the ONE line the driver parses (round 5 lost its record to a 20-KB line with nested bench lines): the contract's keys,
+    `config` with the workload and SCALARS only, the dominant kernel's `roofline`, `cpu_baseline` -- nothing nested deeper,
+    no second object with the contract's key names, < 6 KB.  Everything else lives in the detail file (--detail-file)."""
+    cfg = out["config"]
+    keep_cfg = {}
+    for k, v in cfg.items():
+        if isinstance(v, (dict, list)):
+            continue
+        keep_cfg[k] = _short(v) if isinstance(v, str) else v
+    roof = out.get("roofline") or {}
+    r_keep = {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch")
+              if k in roof}
+    if "kernel" in r_keep:
+        r_keep["kernel"] = _short(r_keep["kernel"], 200)
+    cpu = out.get("cpu_baseline") or {}
+    c_keep = {k: (_short(v, 220) if isinstance(v, str) else v) for k, v in cpu.items() if not isinstance(v, (dict, list))}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline") if k in out}
+    line["dtype"] = _short(out.get("dtype", "f32"), 120)
+    line["data"] = out.get("data", "synthetic")
+    line["config"] = keep_cfg
+    line["roofline"] = r_keep
+    line["cpu_baseline"] = c_keep
+    for k, v in out.items():      # top-level scalars of the full record (chain / forced-clouds / fraction summaries)
+        if k not in line and not isinstance(v, (dict, list, str)):
+            line[k] = v
+    return line
+
+
+def emit(out, detail_file, rank=0):
+    """full record -> detail file (+ stderr), compact line -> stdout (the last thing printed)."""
+    line = compact_line(out)
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(detail_file)), exist_ok=True)
+        with open(detail_file, "w") as f:
+            f.write(json.dumps(out) + "\n")     # one line: profiles/ copies of it are read line-wise by tests/test_bench_line_cpu.py
+        line["config"]["detail_file"] = os.path.relpath(detail_file, ROOT)
+    except OSError as e:
+        line["config"]["detail_file"] = f"not written: {e!r}"
+    print("[bench detail] " + json.dumps(out), file=sys.stderr, flush=True)
+    text = json.dumps(line)
+    assert len(text) < 8000 and text.count('"metric"') == 1, len(text)
+    print(text, flush=True)
+
+
 def build_models(cfg, device):
     from lion_amd.models.lion import LION
     torch.manual_seed(0)
@@ -471,6 +578,10 @@ def train_bench(args, rank, world, dev, backend):
             dt = ("f32 (voxel-conv forward / data-gradient" + (" / weight-gradient" if wg_split else "") + " operands cut into fp16 "
                   "hi/lo pairs on the 16-bit MFMA pipe, f32 accumulate -- fp32-accurate, tests/test_conv_split_gpu.py" +
                   ("" if wg_split else "; weight gradient exact-fp32 MFMA") + ")")
+        from lion_amd import _fallback
+        # what the GPU step did, read BEFORE the host baseline runs (its CPU tensors take conv3d_module's host branch and
+        # would be counted as if the GPU step had used vendor libraries: round-5 review, weak 6)
+        gpu_step_fallbacks = dict(_fallback.counts())
         cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "unmeasured (--no-cpu-baseline)"}
         if world > 1:
             cpu["sample"] = "not timed at --gpus > 1; see the --gpus 1 line"
@@ -479,19 +590,20 @@ def train_bench(args, rank, world, dev, backend):
                 cpu = train_cpu_baseline(args.mode, cfg)
             except Exception as e:  # the baseline must never take the benchmark down
                 cpu["sample"] = f"unmeasured: {e!r}"
-        from lion_amd import _fallback
         out = {"metric": "samples/sec, one data-parallel training step (fwd + bwd + grad averaging + Adam)",
                "value": world * B / (ms / 1e3), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": dt, "data": "synthetic",
                "config": {"workload": name, "samples_per_gpu": B, "points": 2048, "launch": launch,
                           "gradient_averaging": f"BucketedGradAverager, {len(averager.buckets)} buckets, world {world}",
-                          "final_loss": loss_v, "vendor_library_fallbacks": _fallback.counts()},
+                          "final_loss": loss_v, "strict": _fallback.strict(),
+                          "vendor_library_fallbacks_total": sum(gpu_step_fallbacks.values()),
+                          "vendor_library_fallbacks": gpu_step_fallbacks},
                "roofline": {"kernel": wg_kernel, "bound": "mfma", "achieved": flops / tw / 1e12,
                             "peak": wg_peak, "unit": "TFLOP/s (fp32-equivalent conv FLOPs)" if wg_split else "TFLOP/s",
                             "frac": flops / tw / 1e12 / wg_peak, "traffic": None, "us_per_launch": tw * 1e6},
                "cpu_baseline": cpu}
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail_file.replace(".json", f"_{args.mode}.json"))
     if world > 1:
         dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
@@ -517,10 +629,18 @@ def main():
     ap.add_argument("--shapes-total", type=int, default=0,
                     help="strong scaling: N shapes in total, split over the ranks (lion_amd.sampling.shard_batch); 0 (default) = "
                          "weak scaling, --batch shapes per GPU")
-    ap.add_argument("--no-side-lines", action="store_true",
-                    help="skip the short side runs of the training configurations (configs[2..4]) that the 1-GPU sampling line "
-                         "carries as train_lines / config.train_*_samples_per_s")
+    ap.add_argument("--side-lines", action="store_true",
+                    help="ALSO run the training configurations (configs[2..4]) as short side runs of --mode train_* and keep "
+                         "them in the detail file (opt-in since round 6: they doubled the driver's wall time and their nested "
+                         "lines made the record unparseable)")
     ap.add_argument("--side-steps", type=int, default=5, help="timed steps of each training side run")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the FULL record goes (every roofline object, all runs, notes); stdout carries one compact line")
+    ap.add_argument("--forced-steps", type=int, default=-1,
+                    help="DDIM steps of the forced-clouds call (x_t of the local prior forced to sqrt(abar_t) S + sqrt(1-abar_t) z "
+                         "before every step); -1 = 1000 with the default / driver command, 0 = skip")
+    ap.add_argument("--small-batches", default="4,8,16",
+                    help="batch sizes of the strong-scaling readiness timing (ms per step of the same sampler); '' = skip")
     ap.add_argument("--no-full-chain", action="store_true",
                     help="with --steps < 1000: skip the one real 1000-step chain that is run (untimed region) for config.full_chain_1000")
     args = ap.parse_args()
@@ -574,13 +694,15 @@ def main():
             dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
-    def sample(n_steps, seed):
+    def sample(n_steps, seed, hook=None, nb=None):
         """the PRODUCT sampler (lion_amd/sampling.py == trainers/train_2prior.py:50-127): n_steps DDIM steps of the
         global prior, style, n_steps of the local prior, VAE decode."""
         torch.manual_seed(seed)
-        return generate_samples_vada_2prior(shapes, lion.priors, d, lion.vae, B, ddim_step=n_steps,
-                                            ddim_skip_type='uniform', ddim_kappa=1.0, graph=graph)[0]
+        return generate_samples_vada_2prior(shapes, lion.priors, d, lion.vae, B if nb is None else nb, ddim_step=n_steps,
+                                            ddim_skip_type='uniform', ddim_kappa=1.0, graph=graph, state_hook=hook)[0]
 
+    from lion_amd import chain as chain_mod
+    chain_mod.DEBUG_GRAPHS = graph and rank == 0   # keeps the captured hipGraph_t for the kernel census below (no replay cost)
     with torch.no_grad():
         # untimed: W warm-up steps per prior through the same call (captures the two chain graphs once)
         sample(max(W, 1), rank_seed(999, rank))
@@ -614,26 +736,91 @@ def main():
     if rank == 0:
         from lion_amd.functional.backend import _backend as bk
         from lion_amd import _fallback
+        from lion_amd import fused_ops as fused_ops_mod
         with torch.no_grad():
             # how much of the step the exact sparse evaluation saves on THIS trajectory (random-weight latents drift
             # into concentrated clouds): a short dense chain, same call
             # what was actually replayed: graphs and streams of the captured chains (lion_amd/chain.py)
             chains = list(d._chains._entries.values()) if graph else []
+            census = None
+            try:     # kernel nodes of one replayed step of BOTH priors: launches, and how many of them are ATen's
+                cs = [ch.kernel_census() for ch in chains]
+                census = {"launches": sum(c["launches"] for c in cs), "aten": sum(c["aten"] for c in cs),
+                          "aten_names": {k: v for c in cs for k, v in c["aten_names"].items()},
+                          "per_chain [global prior, local prior]": [{k: c[k] for k in ("launches", "aten", "graphs")} for c in cs]}
+            except Exception as e:   # hipGraphDebugDotPrint unavailable: the scalars stay null
+                census = {"error": repr(e)}
+            chain_mod.DEBUG_GRAPHS = False
             streams = [{"main_graphs": len(getattr(ch, "graphs", None) or [ch.graph]),
                         "geometry_graphs": len(ch.geo_graphs or []),
                         "streams": 2 if ch.geo_graphs else 1} for ch in chains]
             # a short chain is the dense start of the trajectory: with --steps < 1000 ALSO run the metric's real
             # 1000-step chain once, after the timed region (the headline is a real 1000-step run)
             full_chain = None
+            chain_tiles = None
+            sections = {}
+            t_sec = time.perf_counter()
             if K != 1000 and not args.no_full_chain:   # rank 0 only (the other ranks are at the final barrier): no collective
+                watch = ForcedClouds(d, B, dev, 1000, force=False)     # copies the latent at five steps, changes nothing
                 torch.cuda.synchronize()
                 tf = time.perf_counter()
-                sample(1000, rank_seed(1234, rank))
+                sample(1000, rank_seed(1234, rank), hook=watch)
                 torch.cuda.synchronize()
                 tf = time.perf_counter() - tf
                 full_chain = {"seconds": tf, "shapes_per_s": B / tf, "ms_per_step": (tf - decode_s) / 1000 * 1e3,
                               "runs": 1, "note": "one call of the product sampler with ddim_step=1000 on rank 0 (shapes_per_s "
                                                  "is this rank's; ranks are independent)"}
+                chain_tiles = empty_tile_fractions(bk, fused_ops_mod, watch.kept, B)
+                del watch
+            sections["full_chain_s"] = time.perf_counter() - t_sec
+            # ---- forced clouds (round-5 review, missing 3): the same call with the local prior's latent forced, before every
+            # step, to the state a TRAINED model would be at: x_t = sqrt(abar_t) S + sqrt(1 - abar_t) z, S = the surface set
+            t_sec = time.perf_counter()
+            forced = None
+            n_forced = args.forced_steps if args.forced_steps >= 0 else (1000 if (K == 1000 or not args.no_full_chain) else K)
+            if n_forced > 0:
+                hook = ForcedClouds(d, B, dev, n_forced, force=True)
+                torch.cuda.synchronize()
+                tf = time.perf_counter()
+                sample(n_forced, rank_seed(1234, rank), hook=hook)
+                torch.cuda.synchronize()
+                tf = time.perf_counter() - tf
+                ms_f = (tf - decode_s) / n_forced * 1e3
+                forced = {"steps": n_forced, "seconds": tf, "ms_per_step": ms_f,
+                          "shapes_per_s": B / tf if n_forced == 1000 else B / (1000.0 * ms_f / 1e3 + decode_s),
+                          "extrapolated": n_forced != 1000,
+                          "tiles": empty_tile_fractions(bk, fused_ops_mod, hook.kept, B),
+                          "note": "product sampler, ddim_step = steps; the local prior's latent is overwritten before each step with "
+                                  "sqrt(abar_t) S + sqrt(1 - abar_t) z (S: 2048 points on the unit sphere + 0.01 noise per shape, z: "
+                                  "one fixed N(0, I) draw): the occupancy a trained model's chain has -- Gaussian at t = T, a surface "
+                                  "at t = 0 -- instead of the clump random-init weights drift into"}
+                del hook
+            sections["forced_clouds_s"] = time.perf_counter() - t_sec
+            # ---- strong-scaling readiness (review, missing 2): the same sampler at the per-rank batches of a 32-shape job
+            # split over 8 / 4 / 2 GPUs
+            t_sec = time.perf_counter()
+            small = {}
+            for nb in [int(v) for v in args.small_batches.split(",") if v.strip()]:
+                if nb >= B or strong:
+                    continue
+                ks = min(K, 20)
+                sample(2, 1, nb=nb)
+                torch.cuda.synchronize()
+                t_ = []
+                for _ in range(2):
+                    tb = time.perf_counter()
+                    sample(ks, rank_seed(1234, rank), nb=nb)
+                    torch.cuda.synchronize()
+                    t_.append(time.perf_counter() - tb)
+                eps_ = [torch.randn([nb] + shapes[0], device=dev), torch.randn([nb] + shapes[1], device=dev)]
+                lion.vae.sample(num_samples=nb, decomposed_eps=eps_)
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                lion.vae.sample(num_samples=nb, decomposed_eps=eps_)
+                torch.cuda.synchronize()
+                dec_ = time.perf_counter() - tb
+                small[nb] = {"ms_per_step": (min(t_) - dec_) / ks * 1e3, "decode_seconds": dec_, "timed_steps": ks}
+            sections["small_batches_s"] = time.perf_counter() - t_sec
             ms_dense = None
             if not args.no_sparse and not args.no_dense_check:
                 pvcnn2_ada.SPARSE_CONV1 = False
@@ -898,6 +1085,11 @@ def main():
             "value_full_chain_1000": (value if K == 1000 else (None if full_chain is None else
                                                                total_shapes / full_chain["seconds"])),
             "ms_per_step_full_chain": (ms_per_step if K == 1000 else (full_chain or {}).get("ms_per_step")),
+            # the same call on the clouds a TRAINED model's chain visits (forced forward-process states), see ForcedClouds
+            "ms_per_step_forced_clouds": (forced or {}).get("ms_per_step"),
+            "value_forced_clouds": (None if forced is None else total_shapes / B * forced["shapes_per_s"]),
+            "voxelize_frac": roofv["frac"], "devoxelize_frac": roofd["frac"],
+            "ms_per_step_B4": (small.get(4) or {}).get("ms_per_step"),
             "dtype": ("f32 (operands of the 3x3x3 voxel convolutions" +
                       (" and of the long 1x1 convolutions" if fused_ops.PW_SPLIT else "") +
                       " cut into fp16 hi/lo pairs on the 16-bit MFMA pipe with f32 accumulation -- fp32-accurate, "
@@ -923,9 +1115,30 @@ def main():
                        "full_chain_1000_shapes_per_s": (value if K == 1000 else (full_chain or {}).get("shapes_per_s")),
                        "full_chain_1000_ms_per_step": (ms_per_step if K == 1000 else (full_chain or {}).get("ms_per_step")),
                        "full_chain_1000_seconds": (elapsed if K == 1000 else (full_chain or {}).get("seconds")),
+                       "forced_clouds_steps": (forced or {}).get("steps"),
+                       "forced_clouds_ms_per_step": (forced or {}).get("ms_per_step"),
+                       "forced_clouds_shapes_per_s": (forced or {}).get("shapes_per_s"),
+                       "forced_clouds_conv1_empty_tile_frac": ((forced or {}).get("tiles") or {}).get("conv1_empty_mean"),
+                       "forced_clouds_conv2_empty_tile_frac": ((forced or {}).get("tiles") or {}).get("conv2_empty_mean"),
+                       "chain_conv1_empty_tile_frac": (chain_tiles or {}).get("conv1_empty_mean"),
+                       "chain_conv2_empty_tile_frac": (chain_tiles or {}).get("conv2_empty_mean"),
+                       "forced_clouds": forced, "chain_tiles": chain_tiles,
+                       "ms_per_step_B4": (small.get(4) or {}).get("ms_per_step"),
+                       "ms_per_step_B8": (small.get(8) or {}).get("ms_per_step"),
+                       "ms_per_step_B16": (small.get(16) or {}).get("ms_per_step"),
+                       # a 32-shape job over 8 GPUs = 4 shapes per rank: T(32 on 1) / (8 x T(4 on 1)), T = 1000 steps + decode
+                       "predicted_strong_scaling_efficiency_8gpu_32shapes": (
+                           None if 4 not in small or B != 32 else
+                           (1000.0 * ms_per_step / 1e3 + decode_s) /
+                           (8.0 * (1000.0 * small[4]["ms_per_step"] / 1e3 + small[4]["decode_seconds"]))),
+                       "small_batches": small, "bench_sections_seconds": sections,
+                       "voxelize_frac_of_hbm": roofv["frac"], "devoxelize_frac_of_hbm": roofd["frac"],
                        "voxelize_forward_total_frac_of_hbm": roofv_total["frac"],
                        "devoxelize_forward_total_frac_of_hbm": roofd_total["frac"],
                        "vendor_library_fallbacks_in_step": sum(_fallback.counts().values()),
+                       "launches_per_step": (census or {}).get("launches"),
+                       "aten_kernels_in_step": (census or {}).get("aten"),
+                       "kernel_census": census,
                        "full_chain_1000": full_chain,
                        "parallelism": f"{world} independent rank(s), no data-path collective",
                        "launch": "hipGraph replay of [step prologue, denoiser forward, update + Philox noise] (the local "
@@ -959,17 +1172,17 @@ def main():
             except Exception as e:  # the baseline must never take the benchmark down
                 out["cpu_baseline"] = {"value": None, "unit": "shapes/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}
-        if world == 1 and not args.no_side_lines:
-            # configs[2..4] beside the metric's line: short side runs of --mode train_* (own process each), their values
-            # hoisted as scalars into config so that the driver's record of THIS line carries them
+        if world == 1 and args.side_lines:
+            # configs[2..4] beside the metric's line (opt-in): short side runs of --mode train_* (own process each); the full
+            # lines go to the detail file under a key the driver's parser never sees, three scalars each to config
             torch.cuda.empty_cache()
             side = run_side_lines(["train_vae", "train_prior", "train_prior_clip"], args.side_steps, 240)
-            out["train_lines"] = side
+            out["training_side_runs"] = side
             for mode_, line_ in side.items():
                 out["config"][f"{mode_}_samples_per_s"] = line_.get("value")
                 out["config"][f"{mode_}_ms_per_step"] = line_.get("ms_per_step")
                 out["config"][f"{mode_}_wgrad_roofline_frac"] = (line_.get("roofline") or {}).get("frac")
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail_file)
     if world > 1:
         dist.barrier(device_ids=[torch.cuda.current_device()]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()

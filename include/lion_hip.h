@@ -231,10 +231,10 @@ int lion_conv3d_k3_fused_forward(const float *x, const float *wp, const float *b
  * empty tiles and balances the occupied ones over all CUs through the queue -- bit-identical output.  The queue
  * re-arms itself when the launch's last workgroup leaves (round 5): one buffer serves any number of launches in
  * stream order (never two concurrently).
- * Round 5: the buffer also carries, per (sample, tile), the 256-bit map of the tile's ACTIVE voxels (a point within
- * the margin): the split kernel packs only those into its 32-column MFMA blocks (voxel-level skipping inside an
- * occupied tile; every other voxel of the tile is written as bias / constant response) -- outputs stay bit-identical,
- * the GroupNorm tile sums agree to fp32 rounding (different summation order). */
+ * Layout: [B*tiles flags][B*tiles work list][queue counter, exit counter, mode, pad].  Flag bits 0-3 = wave w's
+ * 64-voxel block of the tile has a point within the margin (0 = empty tile), bit 8 = the tile's output has a reader
+ * (consumer-aware buffers), bit 9 (margin-2 words) = occupied at margin 1.  These are the only words the shipped
+ * kernels read (round 5's active-voxel bit maps belonged to the rejected compaction experiment and are gone). */
 size_t lion_conv3d_occupancy_ints(int r, int Cout, int B);
 /* The second convolution sees swish(AdaGN(conv1)): a per-channel constant c = swish(A*bias1+Bs) wherever conv1 saw no
  * point, plus a sparse delta.  lion_conv3d_const_response turns c into tconst f32[B][27][Cout], the exact response of

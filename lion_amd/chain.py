@@ -28,6 +28,39 @@ DDIM, DDPM = 0, 1
 # to repeat a graphed chain draw for draw (run_ddim(given_noise=...)); chains are then captured with the noise output on
 RECORD = None
 TEMB_TABLE = __import__("os").environ.get("LION_TEMB_TABLE", "1") != "0"   # A/B: 0 = every step recomputes its time embedding
+# measurement: True keeps the captured hipGraph_t objects alive (CUDAGraph.enable_debug_mode) so that kernel_census() can list
+# the kernel nodes of a step -- which of them are this library's and which are ATen's (bench.py's aten_kernels_in_step)
+DEBUG_GRAPHS = __import__("os").environ.get("LION_CHAIN_DEBUG_GRAPHS", "0") != "0"
+
+
+def _new_graph():
+    g = torch.cuda.CUDAGraph()
+    if DEBUG_GRAPHS:
+        g.enable_debug_mode()
+    return g
+
+
+def graph_kernel_names(graph) -> list:
+    """kernel-node names of one captured graph (hipGraphDebugDotPrint through CUDAGraph.debug_dump; needs DEBUG_GRAPHS at
+    capture time).  Raises if the dump is unavailable."""
+    import os
+    import re
+    import tempfile
+    fd, path = tempfile.mkstemp(suffix=".dot")
+    os.close(fd)
+    try:
+        graph.debug_dump(path)
+        text = open(path, errors="replace").read()
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    names = []
+    for lab in re.findall(r'label="([^"]*)"', text):
+        if "KERNEL" in lab.upper() or "kernel" in lab:
+            names.append(lab.replace("\\n", " ").replace("\n", " "))
+    return names
 
 
 def policy_key() -> tuple:
@@ -126,14 +159,14 @@ class GraphedChain:
                 # geometry graphs: [stage 0: the 2048 -> 1024 FPS, 0.55 of the chain's 0.76 ms, and its ball queries] and
                 # [the later stages] -- the forward waits for the first one only where it needs it (SA-1's grouping); the
                 # second is long done when SA-2 asks (two cuts of the main graph instead of one: 0.2 ms less exposed)
-                self.geo_graphs = [torch.cuda.CUDAGraph()]
+                self.geo_graphs = [_new_graph()]
                 gs = torch.cuda.Stream(device=dev)
                 gs.wait_stream(main)
 
                 def geo_cut(i):
                     if i == 1:
                         self.geo_graphs[-1].capture_end()
-                        self.geo_graphs.append(torch.cuda.CUDAGraph())
+                        self.geo_graphs.append(_new_graph())
                         self.geo_graphs[-1].capture_begin(pool=self.geo_graphs[0].pool())
                 with torch.no_grad(), torch.cuda.stream(gs):
                     self.geo_graphs[0].capture_begin()
@@ -145,7 +178,7 @@ class GraphedChain:
                 torch.cuda.synchronize(dev)
                 self.geo_stage_of_graph = [0, self.geo_plan["stages"] - 1][:len(self.geo_graphs)]  # last stage each graph holds
                 self.ev_geo = [torch.cuda.Event() for _ in self.geo_graphs]
-                graphs, waits = [torch.cuda.CUDAGraph()], []   # main graphs; waits[k]: geometry graphs awaited before graphs[k+1]
+                graphs, waits = [_new_graph()], []   # main graphs; waits[k]: geometry graphs awaited before graphs[k+1]
 
                 def on_use(first, last):   # called inside the forward, on the capturing stream
                     need = [g for g, st_ in enumerate(self.geo_stage_of_graph)
@@ -155,7 +188,7 @@ class GraphedChain:
                         return
                     graphs[-1].capture_end()
                     waits.append(need)
-                    graphs.append(torch.cuda.CUDAGraph())
+                    graphs.append(_new_graph())
                     graphs[-1].capture_begin(pool=graphs[0].pool())
                 cap = torch.cuda.Stream(device=dev)
                 cap.wait_stream(main)
@@ -173,10 +206,21 @@ class GraphedChain:
                 else:              # the forward never asked for a geometry result: one graph, no geometry stream
                     self.geo_graphs = self.geo_plan = None
             else:
-                self.graph = torch.cuda.CUDAGraph()
+                self.graph = _new_graph()
                 with torch.no_grad(), torch.cuda.graph(self.graph):
                     step()
         self.pinned = list({id(v): v for v in self.pinned}.values())   # one reference per distinct object
+
+    def kernel_census(self) -> dict:
+        """{"launches": n, "aten": m, "aten_names": {...}} over every graph one step replays (DEBUG_GRAPHS captures only)."""
+        graphs = list(getattr(self, "graphs", None) or [self.graph]) + list(self.geo_graphs or [])
+        names = [n for g in graphs for n in graph_kernel_names(g)]
+        aten = {}
+        for n in names:
+            if "at::native" in n or "at_cuda_detail" in n or "at::cuda" in n or "ZN2at" in n:
+                key = n[:120]
+                aten[key] = aten.get(key, 0) + 1
+        return {"launches": len(names), "aten": sum(aten.values()), "aten_names": aten, "graphs": len(graphs)}
 
     def replay(self):
         """one chain step on the current stream (+ the geometry stream in split mode)"""
@@ -203,10 +247,13 @@ class GraphedChain:
 
     @torch.no_grad()
     def run(self, x_init, table: np.ndarray, seed: int, condition_input=None, clip_feat=None, trajectory=None,
-            trajectory_before_last=False, noise_trajectory=None):
+            trajectory_before_last=False, noise_trajectory=None, state_hook=None):
         """x_init: the chain's start; table [S, 8] float32 rows {t_model, a0..a5, 0}.  Returns the final latent
         (a fresh tensor).  `trajectory`: list that receives a copy of x after every step (before the last
-        step's update if `trajectory_before_last`, as run_denoising_diffusion reports it)."""
+        step's update if `trajectory_before_last`, as run_denoising_diffusion reports it).
+        `state_hook(i, x)`: called before step i's replay with the chain's latent buffer, which it may overwrite IN PLACE
+        with launches on the current stream (no host synchronisation): inpainting / known-region replacement, or a
+        benchmark forcing the states a trained model would visit (bench.py's forced clouds)."""
         S = self.prepare(x_init, table, seed, condition_input, clip_feat)
         if RECORD is not None and self.z is not None and noise_trajectory is None:
             noise_trajectory = []
@@ -214,6 +261,8 @@ class GraphedChain:
         for i in range(S):
             if trajectory is not None and trajectory_before_last and i == S - 1:
                 trajectory.append(self.x.clone())
+            if state_hook is not None:
+                state_hook(i, self.x)
             self.replay()
             if noise_trajectory is not None and self.z is not None:
                 noise_trajectory.append(self.z.clone())

@@ -16,6 +16,12 @@
 
 static inline int lion_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// (d, h) extent of the spatial tiles of a SPARSE (work-queue) voxel convolution at resolution r -- the geometry the per-tile
+// occupancy flags (lion_conv3d_tile_occupancy*) are laid out in.  Defined next to the convolution's own tile choice
+// (csrc/conv3d.hip: conv_plan / conv_tile_dims) so that every other reader of the flags (lion_voxel_scatter_read) follows
+// a change of that choice instead of repeating it; library-internal (hidden), not part of the C ABI.
+__attribute__((visibility("hidden"))) int lion_internal_sparse_tile_dims(int r, int *td, int *th);
+
 // Dynamic-LDS limit of a kernel.  HIP keeps the attribute per device, so what has already been configured is
 // remembered per device (one slot per kernel instantiation at its launch site); the attribute call itself is
 // idempotent and the slot only grows, which makes concurrent first calls from several host threads harmless.

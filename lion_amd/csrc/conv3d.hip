@@ -433,12 +433,10 @@ __global__ __launch_bounds__(256) void gn_fold_se_kernel(const float *__restrict
 // One workgroup per sample: (1) which voxels of each (d, h) row of the count grid hold a point (one bit per w: tiles span
 // the whole w axis and r <= 32), (2) per spatial tile: any point within `margin` voxels of the tile, for margin 1 (the conv
 // that reads the voxelised grid) and margin 2 (the delta of the second conv), (3) the sample's work list for each margin --
-// occupied tiles first, empty ones after -- and the reset of the queue counter, (4) round 5: per tile and margin the 256-bit
-// map of its ACTIVE voxels -- those with a point within `margin` (Chebyshev) -- bit t = voxel t of the tile in (d, h, w)
-// order, from which the split kernel packs the active voxels of a tile into 32-column MFMA blocks.  No global atomics,
-// no host memset, deterministic order.
-// occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter, 3 pad][B*tiles*8 voxel bit words]
-//         [B occupied-tile counts].
+// occupied tiles first, empty ones after -- and the reset of the queue counter.  No global atomics, no host memset,
+// deterministic order.  (Round 5's per-tile active-voxel bit maps and per-sample counts fed the voxel-compaction experiment,
+// which was not adopted: tools/exp/conv3d_split_round5_experiments.hip; the shipped kernels never read them -- removed.)
+// occ_m = [B*tiles flags][B*tiles list: tile ids, one segment per sample][queue counter, exit counter, mode, pad].
 __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__restrict__ cnt, int r, int TD, int TH,
                                                              int32_t *__restrict__ occ1, int32_t *__restrict__ occ2,
                                                              int aware) {
@@ -472,25 +470,6 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
       mask |= (any ? 1 : 0) << w;
     }
     flag[margin - 1][t] = mask;
-  }
-  // (4) the active-voxel bits: one (row, margin) per step -- the union of the (2 margin + 1)^2 neighbouring rows' point
-  // bits, spread by `margin` along w; a tile's 256 voxels are 256 / r rows of r bits = 8 words (r = 16: two rows per word)
-  const unsigned rmask = r == 32 ? 0xffffffffu : ((1u << r) - 1u);
-  for (int e = tid; e < 2 * r * r; e += 1024) {
-    const int row = e % (r * r), margin = 1 + e / (r * r);
-    int32_t *occ = margin == 1 ? occ1 : occ2;
-    if (!occ) continue;
-    const int d = row / r, h = row % r;
-    unsigned u = 0u;
-    for (int dd = max(d - margin, 0); dd <= min(d + margin, r - 1); ++dd)
-      for (int hh = max(h - margin, 0); hh <= min(h + margin, r - 1); ++hh) u |= col[dd * r + hh];
-    unsigned a = u | (u << 1) | (u >> 1);
-    if (margin == 2) a |= (u << 2) | (u >> 2);
-    a &= rmask;
-    const int tile = (d / TD) * nth + h / TH, lr = (d % TD) * TH + h % TH; // row lr of the tile's 256 / r rows
-    unsigned short *bits16 = reinterpret_cast<unsigned short *>(occ + 2 * total + 4 + ((size_t)b * ntiles + tile) * 8);
-    if (r == 32) reinterpret_cast<unsigned *>(bits16)[lr] = a;
-    else bits16[lr] = (unsigned short)a; // little endian: row 2 k in the low half of word k
   }
   __syncthreads();
   // the lists, occupied tiles first, both parts in ascending tile order: thread (margin, tile) finds its slot from the
@@ -536,7 +515,6 @@ __global__ __launch_bounds__(1024) void conv_tile_occ_kernel(const int32_t *__re
       fl[t] = f | (need << 8) | ((m == 1 && flag[0][t] != 0) ? (1 << 9) : 0);
       list[f ? before : occupied + (t - before)] = t;
       if (b == 0 && t == 0) { occ[2 * total] = 0; occ[2 * total + 1] = 0; occ[2 * total + 2] = aware; } // queue, exit counter, mode
-      if (t == 0) occ[10 * total + 4 + b] = occupied; // the sample's occupied tiles (the split kernel queues only those)
     }
   }
 }
@@ -659,6 +637,17 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
 
 } // namespace
 
+// see common.h: the sparse plans of every channel class share one spatial tile per resolution (vb = 2); a plan change that
+// breaks that must be met here, not by silently stale flags in another file
+int lion_internal_sparse_tile_dims(int r, int *td, int *th) {
+  if (r != 16 && r != 32) return LION_EUNSUPPORTED;
+  const ConvPlan a = conv_plan(r, 64, 32, true), b = conv_plan(r, 32, 32, true), c = conv_plan(r, 64, 1, true);
+  if (!a.vb || a.vb != b.vb || a.vb != c.vb) return LION_EUNSUPPORTED;
+  int tw;
+  conv_tile_dims(r, a.vb, td, th, &tw);
+  return 0;
+}
+
 extern "C" {
 
 // packed size in floats: ceil(Cin / 4) * 4 * 27 * Cout
@@ -700,11 +689,10 @@ int lion_conv3d_k3_forward(const float *x, const float *wp, const float *bias, i
                                       nullptr, stream);
 }
 
-// occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] = [B*tiles flags][B*tiles work list][queue counter, 3 pad][B*tiles*8
-// active-voxel bit words (bit t of a tile's 256 bits = voxel t in (d, h, w) order has a point within the margin)][B counts of
-// occupied tiles], tiles =
-// lion_conv3d_stat_tiles(r,Cout,B,sparse): flag 1 if any voxel of the tile's halo holds a point (cnt i32[B,r^3] from the
-// voxelisation).  Feed to lion_conv3d_k3_fused_forward (the convolution that reads the voxelised grid): the call pops the
+// occ i32[lion_conv3d_occupancy_ints(r,Cout,B)] = [B*tiles flags][B*tiles work list][queue counter, exit counter, mode, pad],
+// tiles = lion_conv3d_stat_tiles(r,Cout,B,sparse): flag bits 0-3 = wave w's 64-voxel block of the tile has a point within the
+// margin (cnt i32[B,r^3] from the voxelisation), bit 8 = the tile's output has a reader, bit 9 (margin-2 words) = occupied at
+// margin 1.  Feed to lion_conv3d_k3_fused_forward (the convolution that reads the voxelised grid): the call pops the
 // work queue and re-arms it on exit.
 // wsum f32[27][Cin][Cout]: weights summed over the taps that stay inside the grid for each border configuration
 // cfg = (cd*3 + ch)*3 + cw (0 low face, 1 interior, 2 high face per axis); bias2 f32[Cout] or NULL (this conv),
@@ -721,8 +709,8 @@ int lion_conv3d_const_response(const float *wsum, const float *bias2, const floa
 
 size_t lion_conv3d_occupancy_ints(int r, int Cout, int B) {
   if (r != 16 && r != 32) return 0;
-  // [flags][list][queue counter + 3 pad words][8 active-voxel bit words per (sample, tile)][occupied tiles per sample]
-  return (size_t)10 * B * conv_plan(r, Cout, B, true).tiles + 4 + B;
+  // [flags][list][queue counter, exit counter, mode, pad]
+  return (size_t)2 * B * conv_plan(r, Cout, B, true).tiles + 4;
 }
 
 // occ_m1 / occ_m2 (either may be NULL): the occupancy + work list for margin 1 (conv on the voxelised grid) and

@@ -28,6 +28,7 @@ namespace {
 constexpr int VT = 1024;    // threads of the per-cloud index kernel
 constexpr int MAXP = 8;     // points per thread kept in registers  (N <= 8192)
 constexpr int LDS_LIMIT = 160 * 1024;
+constexpr int PREFETCH_PAD = 2 * 16 * 4;   // bytes: 2 * PW words behind the arena (vox_means_and_store, phase B2)
 
 __device__ __forceinline__ int padv(int v) { return v + (v >> 5); }
 __host__ __device__ inline int align4i(int x) { return (x + 3) & ~3; }
@@ -119,7 +120,7 @@ __device__ __forceinline__ void vox_means_and_store(
         const int info = ust[u], st = info >> 16, n = info & 0xffff;
         const float *pr = prod + cl * ps + st;
         // the sum's ORDER is fixed, its operands do not depend on it: two buffers of PW, the next one is fetched while the
-        // current one is added (reads past the run fetch words that are never added; past the allocation LDS returns 0)
+        // current one is added (reads past the run fetch words that are never added; PREFETCH_PAD keeps them inside the allocation)
         float acc = add_rn(0.f, pr[0]);
         if (n <= 8) {   // (nearly every voxel of a Gaussian cloud)
           for (int k = 1; k < n; ++k) acc = add_rn(acc, pr[k]);
@@ -687,7 +688,9 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
   // (70 -> 74 us), so r = 32 keeps one workgroup per CU.
   const bool two_per_cu = N <= VT;
   const long wgs = two_per_cu ? 512 : 256;
-  const size_t lds_limit = two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT;
+  // PREFETCH_PAD: phase B2's double-buffered operand fetch reads up to 2 * PW (= 32) words past a voxel's run; for the last
+  // row of the arena that is past the arena itself -- the words are never added, but they are allocated
+  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - PREFETCH_PAD;
   // slabs per cloud: enough workgroups to touch every CU, slabs of >= 512 voxels (int4 groups)
   int S = 1;
   while (S < 16 && (long)B * S < wgs && r3 / (S * 2) >= 512 && (r3 % (S * 2 * 4)) == 0) S *= 2;
@@ -710,7 +713,7 @@ static VoxPlan make_plan(int B, int C, int N, int r) {
   const size_t avail = fixed < lds_limit ? lds_limit - fixed : 0;
   const size_t arena = want < avail ? want : avail;
   p.arena_words = (int)(arena / 4);
-  p.lds = fixed + (size_t)p.arena_words * 4;
+  p.lds = fixed + (size_t)p.arena_words * 4 + PREFETCH_PAD;
   p.fast = r3 <= (1L << 17) && (r3 % 4 == 0) && (p.SV % 4 == 0) && N <= MAXP * VT && N >= 1 &&
            arena >= need_a && (size_t)p.arena_words >= (size_t)N + 1 + nocc;
   size_t o = 0;
@@ -867,23 +870,26 @@ static int voxel_scatter_impl(const float *feat, const void *plan, size_t plan_b
     p.CS = CS;
   }
   // (the static LDS of the reader-aware instantiation -- its 1-KiB row map -- comes out of the same budget)
-  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - (occ_flags ? 1024 + 64 : 0);
+  const size_t lds_limit = (two_per_cu ? (size_t)LDS_LIMIT / 2 : (size_t)LDS_LIMIT) - PREFETCH_PAD - (occ_flags ? 1024 + 64 : 0);
   const size_t fixed = ((size_t)p.SV + (size_t)p.n_words + 64) * 4;   // slot | ust | the cloud's slab headers
   const size_t nocc = (size_t)(N < p.SV ? N : p.SV);
   const size_t want = ((size_t)N + 1 + nocc) * C * 4;
   const size_t avail = fixed < lds_limit ? lds_limit - fixed : 0;
   const size_t arena = want < avail ? want : avail;
   if (arena / 4 < (size_t)N + 1 + nocc) return LION_EUNSUPPORTED;
-  const size_t lds = fixed + arena;
+  const size_t lds = fixed + arena + PREFETCH_PAD;
   const int grid = ((B + 7) / 8) * 8 * p.S * p.CS;
   const int r3 = r * r * r;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  int occ_td = 0, occ_th = 0;   // the tile geometry of the flags: the sparse convolution's own choice (csrc/conv3d.hip)
+  if (occ_flags)
+    if (int e = lion_internal_sparse_tile_dims(r, &occ_td, &occ_th)) return e;
 #define LION_VOXS_LAUNCH(NPV)                                                                          \
   if (occ_flags) {                                                                                     \
     static LionLdsLimit cfg = {};                                                                      \
     if (int e = lion_dynamic_lds(&vox_scatter_kernel<NPV, true>, lds, cfg)) return e;                  \
     vox_scatter_kernel<NPV, true><<<grid, VT, lds, st>>>(feat, plan, B, C, N, r3, p.S, p.CS, p.SV, p.n_words, \
-                                                         (int)(arena / 4), 64, out, occ_flags, r, r == 32 ? 2 : 4, 4); \
+                                                         (int)(arena / 4), 64, out, occ_flags, r, occ_td, occ_th); \
   } else {                                                                                             \
     static LionLdsLimit cfg = {};                                                                      \
     if (int e = lion_dynamic_lds(&vox_scatter_kernel<NPV, false>, lds, cfg)) return e;                 \

@@ -235,12 +235,14 @@ class DiffusionDiscretized(object):
     def run_ddim(self, model, num_samples, shape, temp=1.0, enable_autocast=False, is_image=True,
                  prior_var=1.0, condition_input=None, ddim_step=100, skip_type='uniform', kappa=1.0,
                  clip_feat=None, grid_emb=None, x_noisy=None, dae_index=-1, noise='device',
-                 keep_trajectory=True, graph=True, given_noise=None):
+                 keep_trajectory=True, graph=True, given_noise=None, state_hook=None):
         """DDIM sampling with ``ddim_step`` model evaluations; kappa is DDIM's eta (reference :390-473).
         noise='cpu': EVERY draw of the chain -- the start and the per-step noise -- comes from torch's CPU generator, so
         that one seed gives one chain on any device (the reference draws the per-step noise there, :465-466, and the
         start on its device).  given_noise = (start, [z_0, z_1, ...]): run the eager loop on exactly these draws (the
-        counterpart of run_denoising_diffusion's given_noise; tests replay a graphed chain's recorded noise with it)."""
+        counterpart of run_denoising_diffusion's given_noise; tests replay a graphed chain's recorded noise with it).
+        state_hook(i, x): called before the i-th model evaluation with the chain's latent, which it may overwrite in place
+        (device-side launches only; known-region replacement, bench.py's forced clouds)."""
         model.eval()
         dev = self.device
         size = [num_samples] + list(shape)
@@ -261,13 +263,15 @@ class DiffusionDiscretized(object):
             ch = self._chains.get(model, num_samples, shape, condition_input, clip_feat, dev, _chain.DDIM,
                                   self._diffusion_steps)
             x_noisy = ch.run(x_noisy, table, _chain.draw_seed(), condition_input, clip_feat,
-                             trajectory=output_list if keep_trajectory else None)
+                             trajectory=output_list if keep_trajectory else None, state_hook=state_hook)
             model.train()
             return x_noisy, output_list
         for i, t in enumerate(steps):
             last = i == len(steps) - 1
             if last:
                 assert t == 0
+            if state_hook is not None:
+                state_hook(i, x_noisy)
             timestep = torch.full((num_samples,), t + 1, dtype=torch.int64, device=dev)
             mixing = self.get_mixing_component(x_noisy, timestep, enabled=getattr(model, 'mixed_prediction', False))
             s, c, sigma = self.ddim_coefficients(t, None if last else steps[i + 1], kappa)

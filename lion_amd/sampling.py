@@ -11,12 +11,15 @@ import torch
 @torch.no_grad()
 def generate_samples_vada_2prior(shape, dae, diffusion, vae, num_samples, enable_autocast=False,
                                  temp=1.0, ddim_step=0, clip_feat=None, ddim_skip_type='uniform',
-                                 ddim_kappa=1.0, noise='device', step_callback=None, graph=True, given_noise=None):
+                                 ddim_kappa=1.0, noise='device', step_callback=None, graph=True, given_noise=None,
+                                 state_hook=None):
     """shape: vae.latent_shape(); dae: [global prior, local prior].  Returns (points [B,N,3], info).
     graph=True (default): every chain is replayed from one captured hipGraph per prior (lion_amd/chain.py);
     graph=False: the eager per-step loop; noise='cpu' draws the start and every step's noise from torch's CPU generator
     (one seed = one chain on any device: what the sampler-level parity test runs on the GPU and on the host);
-    given_noise = [(start, [z per step]) per prior] replays recorded draws through the eager loop (DDIM only)."""
+    given_noise = [(start, [z per step]) per prior] replays recorded draws through the eager loop (DDIM only).
+    state_hook(prior_index, step_index, x): may overwrite a chain's latent in place before a model evaluation (DDIM only;
+    device-side launches, no host synchronisation)."""
     condition_input = None
     all_eps = []
     for i in range(len(dae)):
@@ -26,7 +29,9 @@ def generate_samples_vada_2prior(shape, dae, diffusion, vae, num_samples, enable
                                         condition_input=condition_input, clip_feat=clip_feat,
                                         skip_type=ddim_skip_type, kappa=ddim_kappa, noise=noise,
                                         keep_trajectory=False, graph=graph,
-                                        given_noise=None if given_noise is None else given_noise[i])
+                                        given_noise=None if given_noise is None else given_noise[i],
+                                        state_hook=None if state_hook is None else
+                                        (lambda k, x, _i=i: state_hook(_i, k, x)))
         else:
             eps, _ = diffusion.run_denoising_diffusion(dae[i], num_samples, shape[i], temp,
                                                        enable_autocast, is_image=False,

@@ -14,18 +14,53 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args, env=None, timeout=600):
+def _bench(*args, env=None, timeout=600, detail=False):
+    """runs bench.py the way the driver does and parses its stdout the way the driver does: the LAST line that starts with
+    '{' is the record; it must be one compact object (round 5's 20-KB line with nested bench lines was unparseable).
+    detail=True also returns the full record bench.py wrote to --detail-file."""
+    import tempfile
     e = dict(os.environ, **(env or {}))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
-                         timeout=timeout, env=e, cwd=ROOT)
+    dfile = os.path.join(tempfile.mkdtemp(prefix="lion_bench_"), "detail.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail-file", dfile] + list(args),
+                         capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines[0]) < 8000 and lines[0].count('"metric"') == 1, len(lines[0])
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0]          # nothing after the record
+    line = json.loads(lines[0])
+    for k, v in line.items():                                         # flat: contract objects one level deep, scalars inside
+        if isinstance(v, dict):
+            assert k in ("config", "roofline", "cpu_baseline"), k
+            assert not any(isinstance(x, (dict, list)) for x in v.values()), (k, v)
+    if not detail:
+        return line
+    mode = [a for a in args if a.startswith("train_")]
+    if mode:
+        dfile = dfile.replace(".json", f"_{mode[0]}.json")
+    return line, json.load(open(dfile))
 
 
 def test_sample_line_contract_single_rank():
-    d = _bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2", "--repeats", "2")
+    line, d = _bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2", "--repeats", "2", "--side-lines",
+                     "--side-steps", "2", "--forced-steps", "8", "--small-batches", "1", detail=True)
+    # the compact line: the contract's keys + the round-6 scalars (forced clouds, small batch, fractions, census)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "value_full_chain_1000",
+              "ms_per_step_full_chain", "ms_per_step_forced_clouds", "value_forced_clouds", "voxelize_frac", "devoxelize_frac"):
+        assert k in line, k
+    assert line["value"] == d["value"] and line["ms_per_step"] == d["ms_per_step"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    lc = line["config"]
+    assert "workload" in lc and lc["forced_clouds_steps"] == 8 and lc["forced_clouds_ms_per_step"] > 0
+    assert 0.0 <= lc["forced_clouds_conv1_empty_tile_frac"] <= 1.0 and 0.0 <= lc["chain_conv1_empty_tile_frac"] <= 1.0
+    assert lc["vendor_library_fallbacks_in_step"] == 0
+    assert lc["launches_per_step"] is None or lc["launches_per_step"] > 100
+    assert d["config"]["small_batches"]["1"]["ms_per_step"] > 0
+    assert d["config"]["forced_clouds"]["tiles"]["steps"] == [0, 2, 4, 6, 7]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -53,7 +88,7 @@ def test_sample_line_contract_single_rank():
         assert d[k]["bound"] == "hbm" and 0 < d[k]["frac"] <= 1 and d[k]["us_per_forward"] > 0
     assert d["config"]["vendor_library_fallbacks_in_step"] == 0
     for mode in ("train_vae", "train_prior", "train_prior_clip"):
-        ln = d["train_lines"][mode]
+        ln = d["training_side_runs"][mode]
         assert "error" not in ln, ln
         assert ln["value"] > 0 and 0 < ln["roofline"]["frac"] <= 1 and "split" in ln["roofline"]["kernel"]
         assert abs(ln["roofline"]["peak"] - 2500.0 / 3.0) < 1e-6
@@ -65,7 +100,7 @@ def test_sample_strong_scaling_two_ranks_over_gloo():
     """--shapes-total: a fixed job split over the ranks (SURVEY.md 8e read as 32 shapes in total): 5 shapes over 2 ranks =
     3 + 2, `value` = the whole job's 5 shapes over the slower rank's time, scaling = strong."""
     d = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--shapes-total", "5", "--repeats", "1", "--no-dense-check",
-               "--no-full-chain", env={"LION_BENCH_BACKEND": "gloo"})
+               "--no-full-chain", "--forced-steps", "0", "--small-batches", "", env={"LION_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["shapes_total"] == 5
     assert d["config"]["shapes_per_gpu"] == 3      # rank 0's share (remainder to the low ranks)
     per_step_s = d["ms_per_step"] / 1e3
@@ -74,7 +109,7 @@ def test_sample_strong_scaling_two_ranks_over_gloo():
 
 def test_sample_two_ranks_share_the_device_over_gloo():
     d = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--repeats", "1", "--no-dense-check",
-               env={"LION_BENCH_BACKEND": "gloo"})
+               "--no-full-chain", "--forced-steps", "0", "--small-batches", "", env={"LION_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["shapes_per_gpu"] == 2
     assert "2 independent rank(s)" in d["config"]["parallelism"]
     # value is the whole job's: both ranks' shapes over the slower rank's time
@@ -92,6 +127,16 @@ def test_train_vae_two_ranks_bucketed_averaging_over_gloo():
     assert "world 2" in d["config"]["gradient_averaging"]
     assert not launch.startswith("eager") and "eager bucket all-reduce (gloo)" in launch and "hipGraph" in launch, launch
     assert d["config"]["final_loss"] == d["config"]["final_loss"]  # not NaN
+
+
+def test_train_line_counts_the_gpu_steps_fallbacks_only():
+    """round-5 review, weak 6: the host baseline's own vendor-library notes must not appear on the training line"""
+    line, d = _bench("--gpus", "1", "--mode", "train_prior", "--steps", "2", "--warmup", "1", "--batch", "2", detail=True)
+    c = d["config"]
+    assert c["vendor_library_fallbacks_total"] == sum(c["vendor_library_fallbacks"].values())
+    assert not any(k.startswith("conv_ops.conv3d_module") for k in c["vendor_library_fallbacks"]), c["vendor_library_fallbacks"]
+    assert line["config"]["vendor_library_fallbacks_total"] == c["vendor_library_fallbacks_total"]
+    assert d["cpu_baseline"]["value"] > 0
 
 
 def test_train_prior_clip_line():

@@ -104,3 +104,48 @@ def test_training_lines_name_the_kernel_they_time():
         assert abs(r["peak"] - (2500.0 / 3.0 if split else 157.3)) < 1e-6, (f, r["kernel"], r["peak"])
         c = d["cpu_baseline"]
         assert c["value"] is not None or c["sample"].startswith(("unmeasured", "not timed")), (f, c)
+
+
+def test_compact_line_is_what_a_line_parser_can_take():
+    """round-5 review, missing 1: BENCH_r05.json.parsed was null -- the line had grown to 20 KB with three nested bench lines
+    (each starting with {"metric": ...).  bench.compact_line() turns ANY full record into the line the driver parses: here the
+    largest full record committed so far (round 5's) goes through it, then through the driver's steps -- last stdout line that
+    starts with '{' -> json.loads -> the contract's keys."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_steps20_line.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 15000 and json.dumps(full).count('"metric"') > 1      # the record that broke the parser
+    text = json.dumps(bench.compact_line(full))
+    assert len(text) < 8000, len(text)
+    assert text.count('"metric"') == 1 and "\n" not in text
+    stdout = "some warning\n[bench detail] not json\n" + text + "\n"
+    last = [ln for ln in stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"]
+    assert d["value_full_chain_1000"] == full["value_full_chain_1000"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert "workload" in d["config"]
+    for k, v in d.items():     # flat: only the three contract objects, scalars inside them
+        if isinstance(v, dict):
+            assert k in ("config", "roofline", "cpu_baseline") and not any(isinstance(x, (dict, list)) for x in v.values()), k
+        else:
+            assert not isinstance(v, list), k
+
+
+def test_latest_committed_line_is_compact():
+    """the line committed for the latest round is the driver-parsable one (from round 6 on)"""
+    d, f = _last_line()
+    rnd = int(os.path.basename(f)[1:3])
+    if rnd < 6:
+        return
+    text = open(f).read().strip().splitlines()[-1]
+    assert len(text) < 8000 and text.count('"metric"') == 1, (f, len(text))
+    for k in ("ms_per_step_forced_clouds", "value_forced_clouds", "voxelize_frac", "devoxelize_frac", "ms_per_step_B4"):
+        assert k in d, k
