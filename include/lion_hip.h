@@ -134,6 +134,12 @@ int lion_three_nn_interpolate_forward(const float *points, const float *centers,
                                       const float *cfeat, int B, int C, int N, int M,
                                       float *out, int32_t *idx, float *wgt,
                                       lionStream_t stream);
+/* PointNetFPModule.forward (pvcnn2_ada.py:403-411) with its two torch.cat folded in: out f32[B][C1+C2+C3][N] = [interp(cfeat
+ * f32[B][C1][M]) ; interp(temb[b*ld_t + c] taken as a [C2][M] constant row) ; skip f32[B][C3][N]] (C2 / C3 may be 0).  Same
+ * three products and two sums per value as lion_three_nn_interpolate_forward on the materialised concatenation. */
+int lion_three_nn_interpolate_cat_forward(const float *points, const float *centers, const float *cfeat, const float *temb,
+                                          int ld_t, const float *skip, int B, int C1, int C2, int C3, int N, int M,
+                                          float *out, int32_t *idx, float *wgt, lionStream_t stream);
 int lion_three_nn_interpolate_backward(const float *gy, const int32_t *idx, const float *wgt,
                                        int B, int C, int N, int M, float *gx,
                                        lionStream_t stream);
@@ -190,6 +196,23 @@ int lion_chain_begin_step(const float *table, int n_steps, int32_t *counter, flo
 int lion_chain_update_noise(int mode, const float *x, const float *eps, size_t numel, const float *cur,
                             const uint32_t *seed /* device u32[2]: lo, hi */, uint32_t stream_id, float *out,
                             float *z_out, lionStream_t stream);
+/* Round 6 -- no ATen kernel inside a captured step.  lion_chain_begin_step_temb additionally copies row i of the chain's
+ * time-embedding table temb_table f32[n_steps][temb_width] to temb_out (was an index_select per step).
+ * lion_chain_update_noise_cm: x / out f32[B][N][4] (the point-major latent of the local prior, latent_dim 1), eps_cm the
+ * denoiser's CHANNEL-major output f32[B][4][N] -- the permute(0, 2, 1).contiguous() of
+ * models/latent_points_ada_localprior.py:84 folded into the update's read; same arithmetic, same Philox counters. */
+int lion_chain_begin_step_temb(const float *table, int n_steps, int32_t *counter, float *t_out, int B, float *cur,
+                               const float *temb_table, int temb_width, float *temb_out, lionStream_t stream);
+int lion_chain_update_noise_cm(int mode, const float *x, const float *eps_cm, int B, int N, const float *cur,
+                               const uint32_t *seed, uint32_t stream_id, float *out, float *z_out, lionStream_t stream);
+/* x f32[B][N][D] (point-major latent; 3 <= D <= 8) -> channel-major all f32[B][D][N], coords f32[B][3][N] (rows 0-2),
+ * rest f32[B][D-3][N]; each output may be NULL: the view / permute / slice / contiguous head of
+ * models/latent_points_ada_localprior.py:72-84 + models/latent_points_ada.py:118-121 in one launch. */
+int lion_latent_unpack(const float *x, int B, int N, int D, float *all, float *coords, float *rest, lionStream_t stream);
+/* out f32[B][Ca+Ct][N] = cat(a f32[B][Ca][N], t[b*ld_t + c] broadcast along N): torch.cat([features, temb], dim=1) of
+ * models/latent_points_ada.py:139,147 (temb = the time embedding expanded over the points).  N % 4 == 0. */
+int lion_concat_broadcast(const float *a, const float *t, int B, int Ca, int Ct, int N, int ld_t, float *out,
+                          lionStream_t stream);
 
 /* ---- C3: nn.Conv3d(kernel 3, stride 1, padding 1) of PVConv, models/pvcnn2_ada.py:211-222 --------
  * fp32-input MFMA implicit GEMM (exact fp32).  Weights are re-packed once per weight tensor:

@@ -105,6 +105,11 @@ SIGNATURES = {
     "lion_ddpm_update": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp, _vp]),
     "lion_chain_begin_step": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
     "lion_chain_update_noise": (_i, [_i, _vp, _vp, _sz, _vp, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "lion_chain_begin_step_temb": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "lion_chain_update_noise_cm": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "lion_latent_unpack": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lion_concat_broadcast": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lion_three_nn_interpolate_cat_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
 _ERR = {-1: "LION_EINVAL (bad shape / null pointer)",

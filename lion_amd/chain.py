@@ -30,6 +30,7 @@ RECORD = None
 TEMB_TABLE = __import__("os").environ.get("LION_TEMB_TABLE", "1") != "0"   # A/B: 0 = every step recomputes its time embedding
 # measurement: True keeps the captured hipGraph_t objects alive (CUDAGraph.enable_debug_mode) so that kernel_census() can list
 # the kernel nodes of a step -- which of them are this library's and which are ATen's (bench.py's aten_kernels_in_step)
+CHANNEL_MAJOR_EPS = __import__("os").environ.get("LION_CHAIN_CM_EPS", "1") != "0"   # A/B: 0 = the model transposes its output
 DEBUG_GRAPHS = __import__("os").environ.get("LION_CHAIN_DEBUG_GRAPHS", "0") != "0"
 
 
@@ -70,7 +71,7 @@ def policy_key() -> tuple:
     from .models import pvcnn2_ada
     return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, geometry.ENABLED,
             geometry.SPLIT_GRAPH, conv_ops.SPLIT, fused_ops.PW_SPLIT, pvcnn2_ada.VOX_PLAN, TEMB_TABLE, fused_ops.MAX_RECOMPUTE,
-            pvcnn2_ada.SKIP_UNREAD, pvcnn2_ada.SKIP_UNREAD_LEVEL2)
+            pvcnn2_ada.SKIP_UNREAD, pvcnn2_ada.SKIP_UNREAD_LEVEL2, CHANNEL_MAJOR_EPS)
 
 
 class GraphedChain:
@@ -103,14 +104,34 @@ class GraphedChain:
         self.pinned = []         # strong references to every packed / mirrored weight the captured launches point at
         lib = _lib.load()
 
+        # the local prior hands back its channel-major [B, 4, N] output; the update reads it in that layout (round 6: no
+        # transposing ATen copy at the end of a step)
+        n_pts, n_cls = getattr(model, "num_points", 0), getattr(model, "num_classes", 0)
+        self.cm_out = (CHANNEL_MAJOR_EPS and hasattr(model, "geometry_source") and n_cls == 4
+                       and int(np.prod(shape)) == n_pts * n_cls and not getattr(model, "mixed_prediction", False))
+
         def step():
             st = _lib.stream_ptr(dev)
-            _lib.check(lib.lion_chain_begin_step(_lib.ptr(self.table), self.capacity, _lib.ptr(self.counter),
-                                                 _lib.ptr(self.t), num_samples, _lib.ptr(self.cur), st),
-                       "chain_begin_step")
             extra = {}
-            if self.temb_table is not None:   # cur[7] holds the step index (begin_step_kernel), bit-cast into a float slot
-                extra["temb"] = self.temb_table.index_select(0, self.cur[7:8].view(torch.int32))
+            if self.temb_table is not None:   # the step's time-embedding row, copied by the prologue kernel itself
+                _lib.check(lib.lion_chain_begin_step_temb(_lib.ptr(self.table), self.capacity, _lib.ptr(self.counter),
+                                                          _lib.ptr(self.t), num_samples, _lib.ptr(self.cur),
+                                                          _lib.ptr(self.temb_table), self.temb_row.numel(),
+                                                          _lib.ptr(self.temb_row), st), "chain_begin_step_temb")
+                extra["temb"] = self.temb_row
+            else:
+                _lib.check(lib.lion_chain_begin_step(_lib.ptr(self.table), self.capacity, _lib.ptr(self.counter),
+                                                     _lib.ptr(self.t), num_samples, _lib.ptr(self.cur), st),
+                           "chain_begin_step")
+            if self.cm_out:
+                pred = model(x=self.x, t=self.t, condition_input=self.cond, clip_feat=self.clip, channel_major_out=True,
+                             **extra)
+                eps = pred.float().contiguous()
+                assert tuple(eps.shape) == (num_samples, n_cls, n_pts)
+                _lib.check(lib.lion_chain_update_noise_cm(mode, _lib.ptr(self.x), _lib.ptr(eps), num_samples, n_pts,
+                                                          _lib.ptr(self.cur), _lib.ptr(self.seed), 0, _lib.ptr(self.x),
+                                                          _lib.ptr(self.z), _lib.stream_ptr(dev)), "chain_update_noise_cm")
+                return
             pred = model(x=self.x, t=self.t, condition_input=self.cond, clip_feat=self.clip, **extra)
             eps = pred.float().contiguous()
             _lib.check(lib.lion_chain_update_noise(mode, _lib.ptr(self.x), _lib.ptr(eps), self.x.numel(),
@@ -134,6 +155,7 @@ class GraphedChain:
             with torch.no_grad():
                 row = model.time_embedding(torch.ones(1, device=dev))
             self.temb_table = torch.zeros((self.capacity,) + tuple(row.shape[1:]), device=dev)
+            self.temb_row = torch.zeros((1,) + tuple(row.shape[1:]), device=dev)
         main = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(main)

@@ -85,7 +85,8 @@ __device__ __forceinline__ void normal4(uint64_t quad, uint32_t step, uint32_t s
 }
 
 __global__ void begin_step_kernel(const float *__restrict__ table, int n_steps, int32_t *counter,
-                                  float *__restrict__ t_out, int B, float *__restrict__ cur) {
+                                  float *__restrict__ t_out, int B, float *__restrict__ cur,
+                                  const float *__restrict__ temb_table, int temb_width, float *__restrict__ temb_out) {
   __shared__ int step;
   if (threadIdx.x == 0) {
     int i = *counter;
@@ -99,6 +100,8 @@ __global__ void begin_step_kernel(const float *__restrict__ table, int n_steps, 
   if (threadIdx.x < 7) cur[threadIdx.x] = row[threadIdx.x];
   if (threadIdx.x == 7) cur[7] = __int_as_float(i);
   if (threadIdx.x == 0) *counter = i + 1;
+  if (temb_table)   // the step's row of the chain's time-embedding table (was an ATen index_select per step)
+    for (int k = threadIdx.x; k < temb_width; k += blockDim.x) temb_out[k] = temb_table[(size_t)i * temb_width + k];
 }
 
 // MODE 0: DDIM  out = x*a0 + (a1*eps + a2*z)                     (a = {s, c, sigma})
@@ -106,7 +109,7 @@ __global__ void begin_step_kernel(const float *__restrict__ table, int n_steps, 
 template <int MODE>
 __global__ void update_noise_kernel(const float *__restrict__ x, const float *__restrict__ eps, size_t numel,
                                     const float *__restrict__ cur, const uint32_t *__restrict__ seed_words,
-                                    uint32_t stream_id, float *__restrict__ out, float *__restrict__ z_out) {
+                                    uint32_t stream_id, float *__restrict__ out, float *__restrict__ z_out, int cm_points) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = q * 4;
   if (i >= numel) return;
@@ -117,7 +120,15 @@ __global__ void update_noise_kernel(const float *__restrict__ x, const float *__
   normal4(q, step, stream_id, seed, z);
   float xv[4], ev[4], o[4];
   const bool full = i + 3 < numel;
-  if (full) {
+  if (cm_points) {
+    // x is [B][N][4] (point-major latent), eps the denoiser's channel-major output [B][4][N]: quad q = (b, n) takes its four
+    // channels from four rows -- the permute(0, 2, 1).contiguous() copy of the model's output folded into this read
+    const float4 t = *reinterpret_cast<const float4 *>(x + i);
+    xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+    const size_t b = q / (size_t)cm_points, n = q - b * (size_t)cm_points;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ev[j] = eps[(b * 4 + j) * (size_t)cm_points + n];
+  } else if (full) {
     const float4 t = *reinterpret_cast<const float4 *>(x + i), u = *reinterpret_cast<const float4 *>(eps + i);
     xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
     ev[0] = u.x; ev[1] = u.y; ev[2] = u.z; ev[3] = u.w;
@@ -173,7 +184,18 @@ int lion_ddpm_update(const float *x, const float *eps, const float *z, size_t nu
 int lion_chain_begin_step(const float *table, int n_steps, int32_t *counter, float *t_out, int B, float *cur,
                           lionStream_t stream) {
   if (!table || !counter || !t_out || !cur || n_steps <= 0 || B <= 0) return LION_EINVAL;
-  begin_step_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(table, n_steps, counter, t_out, B, cur);
+  begin_step_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(table, n_steps, counter, t_out, B, cur, nullptr, 0,
+                                                                    nullptr);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_chain_begin_step_temb(const float *table, int n_steps, int32_t *counter, float *t_out, int B, float *cur,
+                               const float *temb_table, int temb_width, float *temb_out, lionStream_t stream) {
+  if (!table || !counter || !t_out || !cur || n_steps <= 0 || B <= 0) return LION_EINVAL;
+  if (!temb_table || !temb_out || temb_width <= 0) return LION_EINVAL;
+  begin_step_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(table, n_steps, counter, t_out, B, cur, temb_table,
+                                                                    temb_width, temb_out);
   LION_LAUNCH_CHECK();
   return 0;
 }
@@ -186,8 +208,21 @@ int lion_chain_update_noise(int mode, const float *x, const float *eps, size_t n
   const size_t quads = (numel + 3) / 4;
   const unsigned blocks = (unsigned)((quads + 255) / 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (mode == 0) update_noise_kernel<0><<<blocks, 256, 0, st>>>(x, eps, numel, cur, seed, stream_id, out, z_out);
-  else update_noise_kernel<1><<<blocks, 256, 0, st>>>(x, eps, numel, cur, seed, stream_id, out, z_out);
+  if (mode == 0) update_noise_kernel<0><<<blocks, 256, 0, st>>>(x, eps, numel, cur, seed, stream_id, out, z_out, 0);
+  else update_noise_kernel<1><<<blocks, 256, 0, st>>>(x, eps, numel, cur, seed, stream_id, out, z_out, 0);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_chain_update_noise_cm(int mode, const float *x, const float *eps_cm, int B, int N, const float *cur,
+                               const uint32_t *seed, uint32_t stream_id, float *out, float *z_out, lionStream_t stream) {
+  if (!x || !eps_cm || !cur || !seed || !out || B <= 0 || N <= 0 || (mode != 0 && mode != 1)) return LION_EINVAL;
+  if (((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)z_out)) & 15) != 0) return LION_EINVAL;
+  const size_t numel = (size_t)B * N * 4, quads = (size_t)B * N;
+  const unsigned blocks = (unsigned)((quads + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 0) update_noise_kernel<0><<<blocks, 256, 0, st>>>(x, eps_cm, numel, cur, seed, stream_id, out, z_out, N);
+  else update_noise_kernel<1><<<blocks, 256, 0, st>>>(x, eps_cm, numel, cur, seed, stream_id, out, z_out, N);
   LION_LAUNCH_CHECK();
   return 0;
 }

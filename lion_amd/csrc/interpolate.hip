@@ -119,6 +119,41 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float *__res
     *o = add_rn(add_rn(mul_rn(f[a1], w1), mul_rn(f[a2], w2)), mul_rn(f[a3], w3));
 }
 
+// The FP module's [3-NN interpolation of cat(centre features, time embedding) ; skip features] in ONE pass
+// (models/pvcnn2_ada.py PointNetFPModule.forward :403-411 fed by models/latent_points_ada.py's torch.cat([features, temb])):
+// rows [0, C1) interpolate cfeat, rows [C1, C1 + C2) interpolate the per-sample constants temb[b * ld_t + c] -- the same three
+// products and two sums as on a materialised [B, C2, M] broadcast -- rows [C1 + C2, C1 + C2 + C3) copy skip[b][c][j].
+template <int CT>
+__global__ __launch_bounds__(256) void three_nn_interp_cat_kernel(const float *__restrict__ cfeat,
+                                                                  const float *__restrict__ temb, int ld_t,
+                                                                  const float *__restrict__ skip,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ wgt, int C1, int C2, int C3,
+                                                                  int N, int M, float *__restrict__ out) {
+  const int b = blockIdx.z, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const int32_t *id = idx + (size_t)b * 3 * N;
+  const float *w = wgt + (size_t)b * 3 * N;
+  const float w1 = w[j], w2 = w[j + N], w3 = w[j + 2 * N];
+  const int a1 = min(max(id[j], 0), M - 1), a2 = min(max(id[j + N], 0), M - 1),
+            a3 = min(max(id[j + 2 * N], 0), M - 1);
+  const int C = C1 + C2 + C3;
+  const int c0 = blockIdx.y * CT, c1 = min(C, c0 + CT);
+  float *o = out + ((size_t)b * C + c0) * N + j;
+#pragma unroll 4
+  for (int c = c0; c < c1; ++c, o += N) {
+    if (c < C1) {
+      const float *f = cfeat + ((size_t)b * C1 + c) * M;
+      *o = add_rn(add_rn(mul_rn(f[a1], w1), mul_rn(f[a2], w2)), mul_rn(f[a3], w3));
+    } else if (c < C1 + C2) {
+      const float t = temb[(size_t)b * ld_t + c - C1];
+      *o = add_rn(add_rn(mul_rn(t, w1), mul_rn(t, w2)), mul_rn(t, w3));
+    } else {
+      *o = skip[((size_t)b * C3 + c - C1 - C2) * N + j];
+    }
+  }
+}
+
 // gradient: rows[CT][M] accumulated in LDS, written once
 __global__ __launch_bounds__(512) void three_nn_interp_grad_kernel(const float *__restrict__ gy,
                                                                    const int32_t *__restrict__ idx,
@@ -184,6 +219,30 @@ int lion_three_nn_interpolate_forward(const float *points, const float *centers,
   case 4:  three_nn_interp_kernel<4><<<grid, 256, 0, st>>>(cfeat, idx, wgt, C, N, M, out); break;
   default: three_nn_interp_kernel<2><<<grid, 256, 0, st>>>(cfeat, idx, wgt, C, N, M, out); break;
   }
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_three_nn_interpolate_cat_forward(const float *points, const float *centers, const float *cfeat, const float *temb,
+                                          int ld_t, const float *skip, int B, int C1, int C2, int C3, int N, int M,
+                                          float *out, int32_t *idx, float *wgt, lionStream_t stream) {
+  if (!points || !centers || !cfeat || !out || !idx || !wgt || B <= 0 || N <= 0 || M <= 0 || C1 <= 0) return LION_EINVAL;
+  if (C2 < 0 || C3 < 0 || (C2 > 0 && !temb) || (C3 > 0 && !skip) || ld_t < 0) return LION_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  three_nn_kernel<<<dim3(lion_cdiv(N, 256 / NN_SPLIT), B), 256, 0, st>>>(points, centers, N, M, idx, wgt);
+  LION_LAUNCH_CHECK();
+  const int C = C1 + C2 + C3, pt = lion_cdiv(N, 256);
+  int ct = 16;
+  while (ct > 2 && (long)B * pt * lion_cdiv(C, ct) < 2048) ct >>= 1;
+  dim3 grid(pt, lion_cdiv(C, ct), B);
+#define LION_NN_CAT(CT_) three_nn_interp_cat_kernel<CT_><<<grid, 256, 0, st>>>(cfeat, temb, ld_t, skip, idx, wgt, C1, C2, C3, N, M, out)
+  switch (ct) {
+  case 16: LION_NN_CAT(16); break;
+  case 8:  LION_NN_CAT(8); break;
+  case 4:  LION_NN_CAT(4); break;
+  default: LION_NN_CAT(2); break;
+  }
+#undef LION_NN_CAT
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -177,6 +177,44 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ 
   }
 }
 
+
+// x f32[B][N][D] (point-major latent, models/latent_points_ada_localprior.py:72-84) -> the channel-major tensors the
+// denoiser's forward takes apart with permute / slice / contiguous (three ATen copies per step): all [B][D][N], coords
+// [B][3][N] = rows 0-2, rest [B][D-3][N]; any of them may be NULL.  One workgroup stages 256 points x D through registers:
+// reads coalesced over (n, d), writes coalesced over n.
+__global__ __launch_bounds__(256) void latent_unpack_kernel(const float *__restrict__ x, int N, int D,
+                                                            float *__restrict__ all, float *__restrict__ coords,
+                                                            float *__restrict__ rest) {
+  __shared__ float tile[256 * 9];
+  const int b = blockIdx.y, n0 = blockIdx.x * 256, tid = threadIdx.x;
+  const int np = min(256, N - n0);
+  const float *src = x + ((size_t)b * N + n0) * D;
+  for (int i = tid; i < np * D; i += 256) tile[(i / D) * (D + 1) + i % D] = src[i];
+  __syncthreads();
+  if (tid >= np) return;
+  for (int d = 0; d < D; ++d) {
+    const float v = tile[tid * (D + 1) + d];
+    if (all) all[((size_t)b * D + d) * N + n0 + tid] = v;
+    if (coords && d < 3) coords[((size_t)b * 3 + d) * N + n0 + tid] = v;
+    if (rest && d >= 3) rest[((size_t)b * (D - 3) + d - 3) * N + n0 + tid] = v;
+  }
+}
+
+// out f32[B][Ca + Ct][N]: rows [0, Ca) = a f32[B][Ca][N], rows [Ca, Ca + Ct) = t[b * ld_t + c] broadcast along N
+// (torch.cat([features, temb.expand(..., N)], dim=1), models/latent_points_ada.py forward)
+__global__ __launch_bounds__(256) void concat_broadcast_kernel(const float *__restrict__ a, const float *__restrict__ t,
+                                                               int Ca, int Ct, int N4, int ld_t, float4 *__restrict__ out) {
+  const int row = blockIdx.y, C = Ca + Ct, b = row / C, c = row % C;
+  float4 *o = out + (size_t)row * N4;
+  if (c < Ca) {
+    const float4 *s = reinterpret_cast<const float4 *>(a) + ((size_t)b * Ca + c) * N4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N4; i += gridDim.x * 256) o[i] = s[i];
+  } else {
+    const float v = t[(size_t)b * ld_t + c - Ca];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N4; i += gridDim.x * 256) o[i] = make_float4(v, v, v, v);
+  }
+}
+
 } // namespace
 
 extern "C" {
@@ -237,6 +275,25 @@ int lion_se_gate(const float *chmean, const float *w1, const float *w2, int B, i
   if (!chmean || !w1 || !w2 || !A || !Bs || B <= 0 || C <= 0 || H <= 0) return LION_EINVAL;
   if (C > 1024 || H > 128) return LION_EUNSUPPORTED;
   se_gate_kernel<<<B, 256, 0, static_cast<hipStream_t>(stream)>>>(chmean, w1, w2, C, H, A, Bs);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_latent_unpack(const float *x, int B, int N, int D, float *all, float *coords, float *rest, lionStream_t stream) {
+  if (!x || B <= 0 || N <= 0 || D < 3 || D > 8 || (!all && !coords && !rest)) return LION_EINVAL;
+  if (rest && D == 3) return LION_EINVAL;
+  latent_unpack_kernel<<<dim3(lion_cdiv(N, 256), B), 256, 0, static_cast<hipStream_t>(stream)>>>(x, N, D, all, coords, rest);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_concat_broadcast(const float *a, const float *t, int B, int Ca, int Ct, int N, int ld_t, float *out,
+                          lionStream_t stream) {
+  if (!a || !t || !out || B <= 0 || Ca <= 0 || Ct <= 0 || N <= 0 || ld_t < 0) return LION_EINVAL;
+  if (N % 4 != 0 || ((((uintptr_t)a) | ((uintptr_t)out)) & 15) != 0) return LION_EUNSUPPORTED;
+  const int N4 = N / 4;
+  concat_broadcast_kernel<<<dim3(lion_cdiv(N4, 256) > 4 ? 4 : lion_cdiv(N4, 256), B * (Ca + Ct)), 256, 0,
+                            static_cast<hipStream_t>(stream)>>>(a, t, Ca, Ct, N4, ld_t, reinterpret_cast<float4 *>(out));
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -139,6 +139,28 @@ class _HipBackend:
             "three_nearest_neighbors_interpolate_forward")
         return out, idx, wgt
 
+    def three_nearest_neighbors_interpolate_cat_forward(self, points_coords, centers_coords, centers_features, temb_rows,
+                                                        ld_t, skip):
+        """[interpolate(cat(centers_features, temb)) ; skip] in one pass (lion_three_nn_interpolate_cat_forward): temb_rows
+        f32[B-strided, C2] with row stride ld_t floats (0 = one row for the whole batch) or None, skip f32[B,C3,N] or None
+        -> (out f32[B,C1+C2+C3,N], idx i32[B,3,N], wgt f32[B,3,N])."""
+        _lib.require_cuda(points_coords, centers_coords, centers_features, skip)
+        _f32(points_coords, "points_coords"); _f32(centers_coords, "centers_coords")
+        _f32(centers_features, "centers_features")
+        b, c1, m = centers_features.shape
+        n = points_coords.shape[2]
+        c2 = 0 if temb_rows is None else int(temb_rows.shape[1])
+        c3 = 0 if skip is None else int(skip.shape[1])
+        dev = points_coords.device
+        out = torch.empty((b, c1 + c2 + c3, n), device=dev, dtype=torch.float32)
+        idx = torch.empty((b, 3, n), device=dev, dtype=torch.int32)
+        wgt = torch.empty((b, 3, n), device=dev, dtype=torch.float32)
+        _lib.check(self.lib.lion_three_nn_interpolate_cat_forward(
+            _lib.ptr(points_coords), _lib.ptr(centers_coords), _lib.ptr(centers_features), _lib.ptr(temb_rows), int(ld_t),
+            _lib.ptr(skip), b, c1, c2, c3, n, m, _lib.ptr(out), _lib.ptr(idx), _lib.ptr(wgt), _lib.stream_ptr(dev)),
+            "three_nearest_neighbors_interpolate_cat_forward")
+        return out, idx, wgt
+
     def three_nearest_neighbors_interpolate_backward(self, grad_y, indices, weights, m):
         _lib.require_cuda(grad_y, indices, weights)
         _f32(grad_y, "grad_y"); _i32(indices, "indices"); _f32(weights, "weights")

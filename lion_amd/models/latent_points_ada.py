@@ -6,7 +6,7 @@ import torch.nn as nn
 
 import contextlib
 
-from .. import geometry
+from .. import fused_ops, geometry
 from . import pvcnn2_ada
 from .adagn import StylePlan
 from .pvcnn2_ada import (LinearAttention, SharedMLP, create_mlp_components,
@@ -110,7 +110,10 @@ class PVCNN2Unet(nn.Module):
 
     def forward(self, inputs, **kwargs):
         B = inputs.shape[0]
-        coords = inputs[:, :self.input_dim, :].contiguous()
+        # a caller that built `inputs` from a point-major latent has the two slices already (fused_ops.latent_unpack)
+        coords = kwargs.get('coords', None)
+        if coords is None:
+            coords = inputs[:, :self.input_dim, :].contiguous()
         features = inputs
         temb = kwargs.get('t', None)
         if temb is not None:
@@ -137,20 +140,26 @@ class PVCNN2Unet(nn.Module):
             else contextlib.nullcontext()
         # one GEMM for every AdaGN projection; FPS / ball-query chain on a side stream (inference)
         vplans = pvcnn2_ada.voxel_plans() if pvcnn2_ada.FUSE_INFERENCE and not self.training else contextlib.nullcontext()
+        own = pvcnn2_ada.own_kernels(inputs) and not self.training
         with self._style_plan.projected(style), geo, vplans:
             coords_list, in_features_list = [], []
             for i, sa_blocks in enumerate(self.sa_layers):
                 in_features_list.append(features)
                 coords_list.append(coords)
                 if i > 0 and temb is not None:
-                    features = torch.cat([features, temb], dim=1)
+                    cat = fused_ops.concat_broadcast(features, temb) if own else None   # (ATen's cat otherwise)
+                    features = torch.cat([features, temb], dim=1) if cat is None else cat
                 features, coords, temb, _ = sa_blocks((features, coords, temb, style))
 
-            in_features_list[0] = inputs[:, 3:, :].contiguous()
+            rest = kwargs.get('rest', None)
+            in_features_list[0] = inputs[:, 3:, :].contiguous() if rest is None else rest
             if self.global_att is not None:
                 features = self.global_att(features)
             for fp_idx, fp_blocks in enumerate(self.fp_layers):
-                cf = torch.cat([features, temb], dim=1) if temb is not None else features
+                if own:   # the FP module's fused interpolation concatenates (lion_three_nn_interpolate_cat_forward)
+                    cf = (features, temb)
+                else:
+                    cf = torch.cat([features, temb], dim=1) if temb is not None else features
                 features, coords, temb, _ = fp_blocks(
                     (coords_list[-1 - fp_idx], coords, cf, in_features_list[-1 - fp_idx], temb, style))
 

@@ -2,7 +2,9 @@
 ``models/latent_points_ada_localprior.py:16-84`` (PVCNN2Prior)."""
 import torch
 
+from .. import fused_ops
 from .latent_points_ada import PVCNN2Unet, _FP_BLOCKS
+from .pvcnn2_ada import own_kernels
 from .utils import mask_inactive_variables
 
 
@@ -40,16 +42,27 @@ class PVCNN2Prior(PVCNN2Unet):
         needs to compute the FPS / ball-query chain of a step ahead of the forward (lion_amd/chain.py, geometry.py)"""
         if self.mixed_prediction and self.is_active is not None:   # forward() masks first: the geometry must see the same x
             x = mask_inactive_variables(x, self.is_active)
+        if own_kernels(x) and self.input_dim == 3 and 3 <= self.num_classes <= 8:
+            return self.sa_modules(), fused_ops.latent_unpack(x, self.num_points, self.num_classes, False, True, False)[1]
         pts = x.view(-1, self.num_points, self.num_classes).permute(0, 2, 1).contiguous()
         return self.sa_modules(), pts[:, :self.input_dim, :].contiguous()
 
     def forward(self, x, t, *args, **kwargs):
-        """x: [B, N*D] or [B, N*D, 1, 1] -> same shape (predicted noise)."""
+        """x: [B, N*D] or [B, N*D, 1, 1] -> same shape (predicted noise).
+        channel_major_out=True (chain runners, lion_amd/chain.py): return the network's own [B, D, N] output instead -- the
+        chain's update kernel reads it in that layout (lion_chain_update_noise_cm), saving the transposing copy."""
         assert 'condition_input' in kwargs, 'require condition_input'
         if self.mixed_prediction and self.is_active is not None:
             x = mask_inactive_variables(x, self.is_active)
         input_shape = x.shape
-        x = x.view(-1, self.num_points, self.num_classes).permute(0, 2, 1).contiguous()
+        extra = {}
+        if own_kernels(x) and self.input_dim == 3 and 3 < self.num_classes <= 8:
+            # one launch: [B, N, D] -> [B, D, N] + the coordinate and feature slices the forward would cut out of it
+            x, extra['coords'], extra['rest'] = fused_ops.latent_unpack(x, self.num_points, self.num_classes)
+        else:
+            x = x.view(-1, self.num_points, self.num_classes).permute(0, 2, 1).contiguous()
         out = super().forward(x, t=t, style=kwargs['condition_input'].squeeze(-1).squeeze(-1),
-                              clip_feat=kwargs.get('clip_feat', None), temb=kwargs.get('temb', None))
+                              clip_feat=kwargs.get('clip_feat', None), temb=kwargs.get('temb', None), **extra)
+        if kwargs.get('channel_major_out', False):
+            return out.contiguous()
         return out.permute(0, 2, 1).contiguous().view(input_shape)

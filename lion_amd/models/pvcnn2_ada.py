@@ -566,9 +566,18 @@ class PointNetFPModule(nn.Module):
             points_coords, centers_coords, centers_features, points_features, time_emb, style = inputs
         else:
             raise NotImplementedError
-        interpolated = F.nearest_neighbor_interpolate(points_coords, centers_coords, centers_features)
-        if points_features is not None:
-            interpolated = torch.cat([interpolated, points_features], dim=1)
+        interpolated = None
+        if isinstance(centers_features, tuple):
+            # inference (models/latent_points_ada.py): (features, temb) not yet concatenated -- the interpolation reads both
+            # and appends the skip features in the same pass (was two torch.cat copies around it)
+            cfeat, ctemb = centers_features
+            interpolated = fused_ops.three_nn_interpolate_cat(points_coords, centers_coords, cfeat, ctemb, points_features)
+            if interpolated is None:
+                centers_features = torch.cat([cfeat, ctemb], dim=1)
+        if interpolated is None:
+            interpolated = F.nearest_neighbor_interpolate(points_coords, centers_coords, centers_features)
+            if points_features is not None:
+                interpolated = torch.cat([interpolated, points_features], dim=1)
         if time_emb is not None:
             time_emb = time_emb[:, :, 0:1].expand(-1, -1, points_coords.shape[-1])
         return self.mlp(interpolated, style), points_coords, time_emb, style

@@ -101,7 +101,7 @@ def test_host_side_plan_functions():
     assert lib.lion_conv3d_stat_tiles(16, 128, 32, 0) == 4096 // 512
     assert lib.lion_conv3d_stat_tiles(8, 128, 32, 0) == 512 // 128        # r = 8: one MFMA column block per wave
     assert lib.lion_conv3d_stat_tiles(7, 64, 32, 0) == 0
-    assert lib.lion_conv3d_occupancy_ints(32, 64, 32) == 10 * 32 * 128 + 4 + 32    # flags, list, queue (+3 pad), 8 voxel-bit words per tile, occupied tiles per sample
+    assert lib.lion_conv3d_occupancy_ints(32, 64, 32) == 2 * 32 * 128 + 4    # flags, list, [queue, exit counter, mode, pad]
     assert lib.lion_conv3d_occupancy_ints(8, 64, 32) == 0                  # never sparse at r = 8
     assert lib.lion_conv3d_packed_floats(64, 3) == 4 * 27 * 64             # Cin padded to 4
     assert lib.lion_conv3d_wgrad_workspace_floats(32, 64, 64, 32) == 32 * 1 * 64 * 64 * 27 + 64   # one partial per workgroup (round 3) + the split kernel's maxima / scales (round 4)

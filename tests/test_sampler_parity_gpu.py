@@ -29,7 +29,7 @@ from conftest import fill_
 pytestmark = gpu = pytest.mark.gpu
 SEED = 20260924
 GEOMETRY = ("voxelize_points_forward", "voxel_index", "furthest_point_sampling", "ball_query",
-            "three_nearest_neighbors_interpolate_forward")
+            "three_nearest_neighbors_interpolate_forward", "three_nearest_neighbors_interpolate_cat_forward")
 
 
 class Recorder:
@@ -52,7 +52,7 @@ class Recorder:
             elif name == "voxel_index":
                 if out is not None:
                     self._log.append(("vox", int(a[1]), out["ind"].cpu().numpy().copy(), out["cnt"].cpu().numpy().copy()))
-            elif name == "three_nearest_neighbors_interpolate_forward":
+            elif name in ("three_nearest_neighbors_interpolate_forward", "three_nearest_neighbors_interpolate_cat_forward"):
                 self._log.append(("nn3", 0, out[1].detach().cpu().numpy().copy(), None))
             else:
                 self._log.append((name, 0, out.detach().cpu().numpy().copy(), None))
