@@ -418,19 +418,15 @@ class PVConv(nn.Module):
         occ1 = occ2 = None
         if SPARSE_CONV1 and counts is not None and r >= 16:
             occ1, occ2 = _occupancy(counts, r, conv1.out_channels, grid.shape[0], self._aware_level())
-        y1, st1 = fused_ops.conv3d_fused(grid, conv1, None, True, occ1)  # skips all-zero tiles
+        # round 6: each convolution's tail folds its own GroupNorm sums (+ the SE gate behind conv2) -- csrc/fold.h; the
+        # separate lion_groupnorm_fold[_se] launches remain for the fp32 kernel and under LION_FOLD_IN_PRODUCER=0
         f1, g1 = gn1.affine(style)
-        a1, b1, _ = fused_ops.groupnorm_fold(st1, gn1.norm, f1, g1, r ** 3)
+        y1, (a1, b1) = fused_ops.conv3d_fused(grid, conv1, None, True, occ1,   # skips all-zero tiles
+                                              fold=fused_ops.FoldSpec(gn1.norm, f1, g1, r ** 3))
         # conv2's activated input = per-channel constant + a delta that is non-zero only near the points
-        y2, st2 = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True, occ2, prev_conv=conv1)
         f2, g2 = gn2.affine(style)
-        merged = fused_ops.groupnorm_fold_se(st2, gn2.norm, f2, g2, r ** 3, se) if se is not None else None
-        if merged is not None:     # fold + SE gate in one launch
-            a2, b2 = merged
-        else:
-            a2, b2, m2 = fused_ops.groupnorm_fold(st2, gn2.norm, f2, g2, r ** 3)
-            if se is not None:
-                a2, b2 = fused_ops.se_gate_(a2, b2, m2, se)  # mean over the grid of AdaGN2(y2) is affine in mean(y2)
+        y2, (a2, b2) = fused_ops.conv3d_fused(y1, conv2, (a1, b1), True, occ2, prev_conv=conv1,
+                                              fold=fused_ops.FoldSpec(gn2.norm, f2, g2, r ** 3, se))
         return fused_ops.devoxelize_affine(y2, voxel_coords, r, a2, b2, plan=_devox_plan(voxel_coords, r))
 
     def forward(self, inputs):
