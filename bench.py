@@ -582,6 +582,7 @@ def train_bench(args, rank, world, dev, backend):
         # what the GPU step did, read BEFORE the host baseline runs (its CPU tensors take conv3d_module's host branch and
         # would be counted as if the GPU step had used vendor libraries: round-5 review, weak 6)
         gpu_step_fallbacks = dict(_fallback.counts())
+        gpu_step_fallback_reasons = _fallback.reasons(12)
         cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": "unmeasured (--no-cpu-baseline)"}
         if world > 1:
             cpu["sample"] = "not timed at --gpus > 1; see the --gpus 1 line"
@@ -598,7 +599,8 @@ def train_bench(args, rank, world, dev, backend):
                           "gradient_averaging": f"BucketedGradAverager, {len(averager.buckets)} buckets, world {world}",
                           "final_loss": loss_v, "strict": _fallback.strict(),
                           "vendor_library_fallbacks_total": sum(gpu_step_fallbacks.values()),
-                          "vendor_library_fallbacks": gpu_step_fallbacks},
+                          "vendor_library_fallbacks": gpu_step_fallbacks,
+                          "vendor_library_fallback_shapes": gpu_step_fallback_reasons},
                "roofline": {"kernel": wg_kernel, "bound": "mfma", "achieved": flops / tw / 1e12,
                             "peak": wg_peak, "unit": "TFLOP/s (fp32-equivalent conv FLOPs)" if wg_split else "TFLOP/s",
                             "frac": flops / tw / 1e12 / wg_peak, "traffic": None, "us_per_launch": tw * 1e6},
@@ -701,8 +703,6 @@ def main():
         return generate_samples_vada_2prior(shapes, lion.priors, d, lion.vae, B if nb is None else nb, ddim_step=n_steps,
                                             ddim_skip_type='uniform', ddim_kappa=1.0, graph=graph, state_hook=hook)[0]
 
-    from lion_amd import chain as chain_mod
-    chain_mod.DEBUG_GRAPHS = graph and rank == 0   # keeps the captured hipGraph_t for the kernel census below (no replay cost)
     with torch.no_grad():
         # untimed: W warm-up steps per prior through the same call (captures the two chain graphs once)
         sample(max(W, 1), rank_seed(999, rank))
@@ -742,15 +742,20 @@ def main():
             # into concentrated clouds): a short dense chain, same call
             # what was actually replayed: graphs and streams of the captured chains (lion_amd/chain.py)
             chains = list(d._chains._entries.values()) if graph else []
+            # launches of one replayed step of the local prior's chain and how many of them are ATen's: from the rocprofv3 kernel
+            # trace of this command (tools/census_run.sh + tools/step_census.py -> profiles/r*_step_census_B32.json); a kernel
+            # trace cannot be taken inside this process (hipGraphDebugDotPrint writes nothing on ROCm 7.2: tools/graph_census_probe.py)
             census = None
-            try:     # kernel nodes of one replayed step of BOTH priors: launches, and how many of them are ATen's
-                cs = [ch.kernel_census() for ch in chains]
-                census = {"launches": sum(c["launches"] for c in cs), "aten": sum(c["aten"] for c in cs),
-                          "aten_names": {k: v for c in cs for k, v in c["aten_names"].items()},
-                          "per_chain [global prior, local prior]": [{k: c[k] for k in ("launches", "aten", "graphs")} for c in cs]}
-            except Exception as e:   # hipGraphDebugDotPrint unavailable: the scalars stay null
-                census = {"error": repr(e)}
-            chain_mod.DEBUG_GRAPHS = False
+            import glob as _glob
+            for f_ in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_step_census_B%d.json" % B)), reverse=True):
+                try:
+                    c_ = json.load(open(f_))
+                    census = {"launches": c_["launches_per_step"], "aten": c_["aten_kernels_per_step"],
+                              "aten_names": c_.get("aten_names"), "source": os.path.relpath(f_, ROOT),
+                              "profile_commit": c_.get("profile_commit")}
+                    break
+                except Exception:
+                    continue
             streams = [{"main_graphs": len(getattr(ch, "graphs", None) or [ch.graph]),
                         "geometry_graphs": len(ch.geo_graphs or []),
                         "streams": 2 if ch.geo_graphs else 1} for ch in chains]
@@ -1138,6 +1143,7 @@ def main():
                        "vendor_library_fallbacks_in_step": sum(_fallback.counts().values()),
                        "launches_per_step": (census or {}).get("launches"),
                        "aten_kernels_in_step": (census or {}).get("aten"),
+                       "launch_census_source": (census or {}).get("source"),
                        "kernel_census": census,
                        "full_chain_1000": full_chain,
                        "parallelism": f"{world} independent rank(s), no data-path collective",

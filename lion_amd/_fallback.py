@@ -11,6 +11,7 @@ import os
 from collections import Counter
 
 _COUNTS = Counter()
+_REASONS = Counter()
 _STRICT = os.environ.get("LION_STRICT", "0") not in ("", "0")
 
 
@@ -23,6 +24,8 @@ def strict(on=None) -> bool:
 
 def note(site: str, reason: str = "") -> None:
     _COUNTS[site] += 1
+    if reason:
+        _REASONS[f"{site}: {reason}"] += 1
     if _STRICT:
         raise RuntimeError(f"LION_STRICT: {site} left the HIP kernels for the vendor library" + (f" ({reason})" if reason else ""))
 
@@ -31,5 +34,11 @@ def counts() -> dict:
     return dict(_COUNTS)
 
 
+def reasons(top: int = 20) -> dict:
+    """the most frequent (site: reason) pairs -- which shapes left the library's kernels"""
+    return dict(_REASONS.most_common(top))
+
+
 def reset() -> None:
     _COUNTS.clear()
+    _REASONS.clear()

@@ -28,41 +28,7 @@ DDIM, DDPM = 0, 1
 # to repeat a graphed chain draw for draw (run_ddim(given_noise=...)); chains are then captured with the noise output on
 RECORD = None
 TEMB_TABLE = __import__("os").environ.get("LION_TEMB_TABLE", "1") != "0"   # A/B: 0 = every step recomputes its time embedding
-# measurement: True keeps the captured hipGraph_t objects alive (CUDAGraph.enable_debug_mode) so that kernel_census() can list
-# the kernel nodes of a step -- which of them are this library's and which are ATen's (bench.py's aten_kernels_in_step)
 CHANNEL_MAJOR_EPS = __import__("os").environ.get("LION_CHAIN_CM_EPS", "1") != "0"   # A/B: 0 = the model transposes its output
-DEBUG_GRAPHS = __import__("os").environ.get("LION_CHAIN_DEBUG_GRAPHS", "0") != "0"
-
-
-def _new_graph():
-    g = torch.cuda.CUDAGraph()
-    if DEBUG_GRAPHS:
-        g.enable_debug_mode()
-    return g
-
-
-def graph_kernel_names(graph) -> list:
-    """kernel-node names of one captured graph (hipGraphDebugDotPrint through CUDAGraph.debug_dump; needs DEBUG_GRAPHS at
-    capture time).  Raises if the dump is unavailable."""
-    import os
-    import re
-    import tempfile
-    fd, path = tempfile.mkstemp(suffix=".dot")
-    os.close(fd)
-    try:
-        graph.debug_dump(path)
-        text = open(path, errors="replace").read()
-    finally:
-        try:
-            os.remove(path)
-        except OSError:
-            pass
-    names = []
-    for lab in re.findall(r'label="([^"]*)"', text):
-        if "KERNEL" in lab.upper() or "kernel" in lab:
-            names.append(lab.replace("\\n", " ").replace("\n", " "))
-    return names
-
 
 def policy_key() -> tuple:
     """The module-level switches that decide WHICH kernels a forward launches: a captured graph is only valid for the
@@ -71,7 +37,8 @@ def policy_key() -> tuple:
     from .models import pvcnn2_ada
     return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, geometry.ENABLED,
             geometry.SPLIT_GRAPH, conv_ops.SPLIT, fused_ops.PW_SPLIT, pvcnn2_ada.VOX_PLAN, TEMB_TABLE, fused_ops.MAX_RECOMPUTE,
-            pvcnn2_ada.SKIP_UNREAD, pvcnn2_ada.SKIP_UNREAD_LEVEL2, CHANNEL_MAJOR_EPS)
+            pvcnn2_ada.SKIP_UNREAD, pvcnn2_ada.SKIP_UNREAD_LEVEL2, CHANNEL_MAJOR_EPS, fused_ops.FOLD_IN_PRODUCER,
+            fused_ops.FOLD_MAX_TILES)
 
 
 class GraphedChain:
@@ -181,14 +148,14 @@ class GraphedChain:
                 # geometry graphs: [stage 0: the 2048 -> 1024 FPS, 0.55 of the chain's 0.76 ms, and its ball queries] and
                 # [the later stages] -- the forward waits for the first one only where it needs it (SA-1's grouping); the
                 # second is long done when SA-2 asks (two cuts of the main graph instead of one: 0.2 ms less exposed)
-                self.geo_graphs = [_new_graph()]
+                self.geo_graphs = [torch.cuda.CUDAGraph()]
                 gs = torch.cuda.Stream(device=dev)
                 gs.wait_stream(main)
 
                 def geo_cut(i):
                     if i == 1:
                         self.geo_graphs[-1].capture_end()
-                        self.geo_graphs.append(_new_graph())
+                        self.geo_graphs.append(torch.cuda.CUDAGraph())
                         self.geo_graphs[-1].capture_begin(pool=self.geo_graphs[0].pool())
                 with torch.no_grad(), torch.cuda.stream(gs):
                     self.geo_graphs[0].capture_begin()
@@ -200,7 +167,7 @@ class GraphedChain:
                 torch.cuda.synchronize(dev)
                 self.geo_stage_of_graph = [0, self.geo_plan["stages"] - 1][:len(self.geo_graphs)]  # last stage each graph holds
                 self.ev_geo = [torch.cuda.Event() for _ in self.geo_graphs]
-                graphs, waits = [_new_graph()], []   # main graphs; waits[k]: geometry graphs awaited before graphs[k+1]
+                graphs, waits = [torch.cuda.CUDAGraph()], []   # main graphs; waits[k]: geometry graphs awaited before graphs[k+1]
 
                 def on_use(first, last):   # called inside the forward, on the capturing stream
                     need = [g for g, st_ in enumerate(self.geo_stage_of_graph)
@@ -210,7 +177,7 @@ class GraphedChain:
                         return
                     graphs[-1].capture_end()
                     waits.append(need)
-                    graphs.append(_new_graph())
+                    graphs.append(torch.cuda.CUDAGraph())
                     graphs[-1].capture_begin(pool=graphs[0].pool())
                 cap = torch.cuda.Stream(device=dev)
                 cap.wait_stream(main)
@@ -228,21 +195,10 @@ class GraphedChain:
                 else:              # the forward never asked for a geometry result: one graph, no geometry stream
                     self.geo_graphs = self.geo_plan = None
             else:
-                self.graph = _new_graph()
+                self.graph = torch.cuda.CUDAGraph()
                 with torch.no_grad(), torch.cuda.graph(self.graph):
                     step()
         self.pinned = list({id(v): v for v in self.pinned}.values())   # one reference per distinct object
-
-    def kernel_census(self) -> dict:
-        """{"launches": n, "aten": m, "aten_names": {...}} over every graph one step replays (DEBUG_GRAPHS captures only)."""
-        graphs = list(getattr(self, "graphs", None) or [self.graph]) + list(self.geo_graphs or [])
-        names = [n for g in graphs for n in graph_kernel_names(g)]
-        aten = {}
-        for n in names:
-            if "at::native" in n or "at_cuda_detail" in n or "at::cuda" in n or "ZN2at" in n:
-                key = n[:120]
-                aten[key] = aten.get(key, 0) + 1
-        return {"launches": len(names), "aten": sum(aten.values()), "aten_names": aten, "graphs": len(graphs)}
 
     def replay(self):
         """one chain step on the current stream (+ the geometry stream in split mode)"""

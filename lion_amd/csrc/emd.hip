@@ -200,6 +200,191 @@ __global__ __launch_bounds__(256) void emd_pass3_cost_kernel(const float *__rest
   }
 }
 
+// ---- round 6: the evaluation path (lion_emd_cost) on a shorter instruction stream ---------------------------------------
+// The three passes of a level evaluate exp(level * d(k, l)) for all N x M pairs each: 30 N M evaluations per pair of clouds,
+// every one 8 VALU operations for the distance + 2 multiplies + v_exp_f32 (quarter rate) + accumulate = 16-19 issue slots of
+// the non-packed fp32 pipe -- the launches sit AT that issue rate (1.45 ms at 32 x 2048^2 = 64 G slots / 39 T slots per second),
+// not at the transcendental rate the roofline is priced against.  Fewer slots per evaluation:
+//   * coordinates are pre-scaled by s = sqrt(-level * log2(e)) when a tile is staged (and the row's own point once), so that
+//     exp(level * d) = exp2(-d') with d' the squared distance of the scaled points: 3 subtractions, 1 multiply, 2 fused
+//     multiply-adds, and v_exp_f32 on the negated operand -- no level multiply, no log2(e) multiply;
+//   * pass 3 of a level and pass 1 of the NEXT level walk the same row over the same tiles: one kernel, one distance per
+//     pair, the next level's exponent is d' * (level' / level) (0.25, or 0 before the last level);
+//   * true squared distances for the cost come back as d' / s^2.
+// Sums keep their order (ascending l inside each wave's quarter of a tile, the four quarters merged in a fixed order).  The
+// weights differ from the literal expression by fp32 rounding of the exponent (<= 1e-5 relative), inside what v_exp_f32
+// itself imposes (tests: cost 1e-4, the materialised match 2e-3); lion_emd_approxmatch keeps the literal kernels.
+__device__ __forceinline__ float sqd_fma(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+__device__ __forceinline__ float exp2_neg(float a) { return __builtin_amdgcn_exp2f(-a); }
+
+// Rows per lane: two (128 rows per workgroup, 512 workgroups at B = 32: two waves per SIMD) -- one 16-byte LDS broadcast read
+// feeds two evaluations.  Measured (32 x 2048^2, rocprofv3): pass 2 37.3 -> 39.7 us, pass 3 + 1 76.7 -> 70.0 us, whole call
+// 1169 -> 1132 us: the passes are NOT bound by LDS return bandwidth; what is left is the issue stream itself -- per pair
+// 7.4 full-rate VALU instructions + one v_exp_f32 (two in the fused pass) -- at the clock the board sustains under it.
+constexpr int EMD_RPL = 2;
+constexpr int EMD_FROWS = EMD_ROWS * EMD_RPL;
+
+#define EMD_MERGE2(red_, wave_, lane_, v_)                                                        \
+  __syncthreads();                                                                                 \
+  _Pragma("unroll") for (int q_ = 0; q_ < EMD_RPL; ++q_) red_[(wave_ * EMD_RPL + q_) * EMD_ROWS + lane_] = v_[q_]; \
+  __syncthreads();                                                                                 \
+  _Pragma("unroll") for (int q_ = 0; q_ < EMD_RPL; ++q_)                                           \
+    v_[q_] = add_rn(add_rn(add_rn(red_[q_ * EMD_ROWS + lane_], red_[(EMD_RPL + q_) * EMD_ROWS + lane_]), \
+                           red_[(2 * EMD_RPL + q_) * EMD_ROWS + lane_]), red_[(3 * EMD_RPL + q_) * EMD_ROWS + lane_]);
+
+// scale / inv_s2: s and 1 / s^2 of THIS level (s = 0 at level 0: every weight is exp(0) = 1, distances unscaled)
+__global__ __launch_bounds__(256) void emd_fast_pass1_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                             int n, int m, float scale, const float *__restrict__ remainL,
+                                                             const float *__restrict__ remainR, float *__restrict__ ratioL) {
+  __shared__ float4 tile[EMD_TILE];
+  __shared__ float red[4 * EMD_FROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, k0r = blockIdx.x * EMD_FROWS + lane;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  float x1[EMD_RPL], y1[EMD_RPL], z1[EMD_RPL], suml[EMD_RPL];
+#pragma unroll
+  for (int q = 0; q < EMD_RPL; ++q) {
+    const int k = k0r + q * EMD_ROWS;
+    x1[q] = y1[q] = z1[q] = 0.f;
+    if (k < n) { x1[q] = p1[k * 3] * scale; y1[q] = p1[k * 3 + 1] * scale; z1[q] = p1[k * 3 + 2] * scale; }
+    suml[q] = wave == 0 ? 1e-9f : 0.f;
+  }
+  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, m - l0);
+    __syncthreads();
+    for (int l = tid; l < ln; l += 256)
+      tile[l] = make_float4(p2[(size_t)(l0 + l) * 3] * scale, p2[(size_t)(l0 + l) * 3 + 1] * scale,
+                            p2[(size_t)(l0 + l) * 3 + 2] * scale, remainR[(size_t)b * m + l0 + l]);
+    __syncthreads();
+    const int l1 = min(ln, (wave + 1) * EMD_SUB);
+#pragma unroll 4
+    for (int l = wave * EMD_SUB; l < l1; ++l) {
+      const float4 v = tile[l];
+#pragma unroll
+      for (int q = 0; q < EMD_RPL; ++q)
+        suml[q] = __fmaf_rn(exp2_neg(sqd_fma(v.x, v.y, v.z, x1[q], y1[q], z1[q])), v.w, suml[q]);
+    }
+  }
+  EMD_MERGE2(red, wave, lane, suml)
+  if (wave == 0)
+#pragma unroll
+    for (int q = 0; q < EMD_RPL; ++q) {
+      const int k = k0r + q * EMD_ROWS;
+      if (k < n) ratioL[(size_t)b * n + k] = div_rn(remainL[(size_t)b * n + k], suml[q]);
+    }
+}
+
+__global__ __launch_bounds__(256) void emd_fast_pass2_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                             int n, int m, float scale, const float *__restrict__ ratioL,
+                                                             float *__restrict__ remainR, float *__restrict__ ratioR) {
+  __shared__ float4 tile[EMD_TILE];
+  __shared__ float red[4 * EMD_FROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, l0r = blockIdx.x * EMD_FROWS + lane;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  float x2[EMD_RPL], y2[EMD_RPL], z2[EMD_RPL], sumr[EMD_RPL];
+#pragma unroll
+  for (int q = 0; q < EMD_RPL; ++q) {
+    const int l = l0r + q * EMD_ROWS;
+    x2[q] = y2[q] = z2[q] = 0.f;
+    if (l < m) { x2[q] = p2[l * 3] * scale; y2[q] = p2[l * 3 + 1] * scale; z2[q] = p2[l * 3 + 2] * scale; }
+    sumr[q] = 0.f;
+  }
+  for (int k0 = 0; k0 < n; k0 += EMD_TILE) {
+    const int kn = min(EMD_TILE, n - k0);
+    __syncthreads();
+    for (int k = tid; k < kn; k += 256)
+      tile[k] = make_float4(p1[(size_t)(k0 + k) * 3] * scale, p1[(size_t)(k0 + k) * 3 + 1] * scale,
+                            p1[(size_t)(k0 + k) * 3 + 2] * scale, ratioL[(size_t)b * n + k0 + k]);
+    __syncthreads();
+    const int k1 = min(kn, (wave + 1) * EMD_SUB);
+#pragma unroll 4
+    for (int k = wave * EMD_SUB; k < k1; ++k) {
+      const float4 v = tile[k];
+#pragma unroll
+      for (int q = 0; q < EMD_RPL; ++q)
+        sumr[q] = __fmaf_rn(exp2_neg(sqd_fma(x2[q], y2[q], z2[q], v.x, v.y, v.z)), v.w, sumr[q]);
+    }
+  }
+  EMD_MERGE2(red, wave, lane, sumr)
+  if (wave == 0)
+#pragma unroll
+    for (int q = 0; q < EMD_RPL; ++q) {
+      const int l = l0r + q * EMD_ROWS;
+      if (l < m) {
+        const float rr = remainR[(size_t)b * m + l];
+        const float sr = mul_rn(sumr[q], rr);
+        const float consumption = fminf(div_rn(rr, add_rn(sr, 1e-9f)), 1.0f);
+        ratioR[(size_t)b * m + l] = mul_rn(consumption, rr);
+        remainR[(size_t)b * m + l] = fmaxf(0.0f, sub_rn(rr, sr));
+      }
+    }
+}
+
+// pass 3 of this level (cost form) + pass 1 of the next level (NEXT: next_ratio = level' / level, 0 for the step onto level 0)
+template <bool FIRST, bool NEXT>
+__global__ __launch_bounds__(256) void emd_fast_pass31_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                              int n, int m, float scale, float inv_s2, float next_ratio,
+                                                              float *__restrict__ ratioL, const float *__restrict__ ratioR,
+                                                              const float *__restrict__ remainR, float *__restrict__ remainL,
+                                                              float *__restrict__ costrow) {
+  __shared__ float4 tile[EMD_TILE];
+  __shared__ float trem[EMD_TILE];
+  __shared__ float red[4 * EMD_FROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, k0r = blockIdx.x * EMD_FROWS + lane;
+  const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + (size_t)b * m * 3;
+  const float cs = scale > 0.f ? scale : 1.f;          // level 0: plain coordinates, weights exp(0) = 1
+  const float ws = scale > 0.f ? 1.f : 0.f, c2 = scale > 0.f ? inv_s2 : 1.f;
+  float x1[EMD_RPL], y1[EMD_RPL], z1[EMD_RPL], rl[EMD_RPL], suml[EMD_RPL], crow[EMD_RPL], sum1[EMD_RPL];
+#pragma unroll
+  for (int q = 0; q < EMD_RPL; ++q) {
+    const int k = k0r + q * EMD_ROWS;
+    x1[q] = y1[q] = z1[q] = rl[q] = 0.f;
+    if (k < n) { x1[q] = p1[k * 3] * cs; y1[q] = p1[k * 3 + 1] * cs; z1[q] = p1[k * 3 + 2] * cs; rl[q] = ratioL[(size_t)b * n + k]; }
+    suml[q] = crow[q] = 0.f;
+    sum1[q] = wave == 0 ? 1e-9f : 0.f;
+  }
+  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, m - l0);
+    __syncthreads();
+    for (int l = tid; l < ln; l += 256) {
+      tile[l] = make_float4(p2[(size_t)(l0 + l) * 3] * cs, p2[(size_t)(l0 + l) * 3 + 1] * cs,
+                            p2[(size_t)(l0 + l) * 3 + 2] * cs, ratioR[(size_t)b * m + l0 + l]);
+      if (NEXT) trem[l] = remainR[(size_t)b * m + l0 + l];
+    }
+    __syncthreads();
+    const int l1 = min(ln, (wave + 1) * EMD_SUB);
+#pragma unroll 4
+    for (int l = wave * EMD_SUB; l < l1; ++l) {
+      const float4 v = tile[l];
+      const float tr = NEXT ? trem[l] : 0.f;
+#pragma unroll
+      for (int q = 0; q < EMD_RPL; ++q) {
+        const float dp = sqd_fma(v.x, v.y, v.z, x1[q], y1[q], z1[q]);
+        const float w = (exp2_neg(dp * ws) * rl[q]) * v.w;
+        suml[q] += w;
+        crow[q] = __fmaf_rn(dp * c2, w, crow[q]);
+        if (NEXT) sum1[q] = __fmaf_rn(exp2_neg(dp * next_ratio), tr, sum1[q]);
+      }
+    }
+  }
+  EMD_MERGE2(red, wave, lane, suml)
+  EMD_MERGE2(red, wave, lane, crow)
+  if (NEXT) { EMD_MERGE2(red, wave, lane, sum1) }
+  if (wave == 0)
+#pragma unroll
+    for (int q = 0; q < EMD_RPL; ++q) {
+      const int k = k0r + q * EMD_ROWS;
+      if (k < n) {
+        const float rem = fmaxf(0.0f, sub_rn(remainL[(size_t)b * n + k], suml[q]));
+        remainL[(size_t)b * n + k] = rem;
+        costrow[(size_t)b * n + k] = FIRST ? crow[q] : add_rn(costrow[(size_t)b * n + k], crow[q]);
+        if (NEXT) ratioL[(size_t)b * n + k] = div_rn(rem, sum1[q]);   // pass 1 of the next level (emd_kernel.cu:50-81)
+      }
+    }
+}
+
 // cost[b] = sum_k costrow[b][k]: 256 strided partials, then a fixed tree (deterministic)
 __global__ __launch_bounds__(256) void emd_costrow_sum_kernel(const float *__restrict__ costrow, int n,
                                                               float *__restrict__ cost) {
@@ -388,16 +573,28 @@ int lion_emd_cost(const float *xyz1, const float *xyz2, int B, int N, int M, flo
   else { multiL = (float)(M / N); multiR = 1.f; }
   const int nmax = N > M ? N : M;
   emd_init_kernel<<<dim3(lion_cdiv(nmax, 256), B), 256, 0, st>>>(N, M, multiL, multiR, remainL, remainR);
-  const dim3 gn(lion_cdiv(N, EMD_ROWS), B), gm(lion_cdiv(M, EMD_ROWS), B);
+  const dim3 gn(lion_cdiv(N, EMD_FROWS), B), gm(lion_cdiv(M, EMD_FROWS), B);
+  // round 6 (see emd_fast_*): pass 1 of the first level, then per level [pass 2, pass 3 + pass 1 of the next level]
+  const float LOG2E = 1.4426950408889634f;
+  auto level_of = [](int j) { return j == -2 ? 0.f : -powf(4.0f, (float)j); };   // :45-48
+  auto scale_of = [&](float level) { return level < 0.f ? sqrtf(-level * LOG2E) : 0.f; };
+  emd_fast_pass1_kernel<<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, scale_of(level_of(7)), remainL, remainR, ratioL);
   for (int j = 7; j >= -2; --j) {
-    float level = -powf(4.0f, (float)j); // :45-48
-    if (j == -2) level = 0.f;
-    emd_pass1_kernel<<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, remainL, remainR, ratioL);
-    emd_pass2_kernel<<<gm, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, remainR, ratioR);
-    if (j == 7)
-      emd_pass3_cost_kernel<true><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, ratioR, remainL, costrow);
-    else
-      emd_pass3_cost_kernel<false><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, level, ratioL, ratioR, remainL, costrow);
+    const float level = level_of(j), sc = scale_of(level);
+    const float inv_s2 = sc > 0.f ? 1.0f / (sc * sc) : 1.f;
+    emd_fast_pass2_kernel<<<gm, 256, 0, st>>>(xyz1, xyz2, N, M, sc, ratioL, remainR, ratioR);
+    if (j == -2) {
+      emd_fast_pass31_kernel<false, false><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, sc, inv_s2, 0.f, ratioL, ratioR, remainR,
+                                                                remainL, costrow);
+    } else {
+      const float next_ratio = level_of(j - 1) / level;     // 0.25; 0 for the step onto level 0
+      if (j == 7)
+        emd_fast_pass31_kernel<true, true><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, sc, inv_s2, next_ratio, ratioL, ratioR,
+                                                               remainR, remainL, costrow);
+      else
+        emd_fast_pass31_kernel<false, true><<<gn, 256, 0, st>>>(xyz1, xyz2, N, M, sc, inv_s2, next_ratio, ratioL, ratioR,
+                                                                remainR, remainL, costrow);
+    }
   }
   emd_costrow_sum_kernel<<<B, 256, 0, st>>>(costrow, N, cost);
   LION_LAUNCH_CHECK();

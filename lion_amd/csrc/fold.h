@@ -57,7 +57,7 @@ __device__ __forceinline__ void lion_fold_store2(float *o, float s1, float s2, b
 }
 
 // the fold of sample b by one workgroup (all its threads must call; the first 256 work).  stats f32[B][C][T][2].
-__device__ __attribute__((noinline)) void lion_fold_sample(const LionFold &f, int b, const float *stats, unsigned char *scratch) {
+__device__ __forceinline__ void lion_fold_sample(const LionFold &f, int b, const float *stats, unsigned char *scratch) {
   double(*cs)[2] = reinterpret_cast<double(*)[2]>(scratch + 16);
   float *sA = reinterpret_cast<float *>(scratch + 16 + 256 * 2 * 8), *sB = sA + 256, *sm = sB + 256, *sh = sm + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, C = f.C, T = f.T, cpg = C / f.G;

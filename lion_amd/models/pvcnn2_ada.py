@@ -267,6 +267,8 @@ def run_layers(layers, x, style, conv):
             x = layer(x, style)
         elif isinstance(layer, (nn.Conv1d, nn.Conv2d, nn.Conv3d)):
             x = conv(layer, x)
+        elif isinstance(layer, SE3d) and train_ops.se3d_trainable(layer, x):
+            x = train_ops.se3d(layer, x)     # one differentiable op on the library's kernels (round 6)
         else:
             x = layer(x)
         i += 1

@@ -15,6 +15,12 @@ from . import _lib
 
 ENABLED = os.environ.get("LION_TRAIN_FUSE", "1") != "0"
 PWCONV = os.environ.get("LION_TRAIN_PWCONV", "1") != "0"   # 1x1 convolutions of the training path on own kernels
+# ... from this many columns (B x L) on.  Round 4 had measured the library GEMM faster below 2^18 columns (prior step 82 vs 88 ms);
+# with round 5's kernels it is the other way round (round 6, one box, profiles/r06_train_pwconv_ab.txt): VAE step 110.1 ms at
+# 2^18 -> 101.8 at 2^16 -> 96.9 at 2^13 -> 96.7 at 2^11 -> 97.1 with every layer; prior step 61.9 -> 58.4 -> 56.1 -> 56.1 -> 72.9.
+# The last number is the global prior's 2048-wide layers on [32, C, 1, 1] activations (32 columns: a weight-streaming skinny
+# GEMM, not what these kernels are tiled for): they stay on the rocBLAS matrix product, everything from 512 columns on is ours.
+PWCONV_MIN_COLS = int(os.environ.get("LION_TRAIN_PWCONV_MIN_COLS", "512"))
 
 
 def usable(x) -> bool:
@@ -117,6 +123,68 @@ def adagn_act(x, norm, factor=None, bias=None, act=True):
     return _AdaGNAct.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act))
 
 
+class _SE3d(torch.autograd.Function):
+    """y = x * sigmoid(W2 relu(W1 mean_voxels(x))) -- SE3d (reference models/pvcnn2_ada.py:27-41) as ONE differentiable op:
+    forward = row sums + one scaling pass; backward = one pass for sum_n gy x (the gate's gradient) + one fused apply
+    dx = gate gy + d mean / L; the [B, C] algebra of the two bias-free Linear layers is written out by hand (a few small
+    launches).  ATen runs the reference expression as three chained mean() reductions, a broadcast multiply, and in backward
+    two more broadcast multiplies, an expand and three reductions over the 268-MB grid."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        L = x[0, 0].numel()
+        st = _lib.stream_ptr(x.device)
+        stats = torch.empty(B * C, 2, device=x.device, dtype=torch.float32)
+        _lib.check(lib.lion_row_stats(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats")
+        mean = (stats[:, 0] / float(L)).reshape(B, C)
+        h = torch.relu(mean @ w1.t())
+        g = torch.sigmoid(h @ w2.t()).contiguous()
+        zero = torch.zeros_like(g)
+        y = torch.empty_like(x)
+        _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(g), _lib.ptr(zero), B * C, L, 0, _lib.ptr(y), st), "affine_act")
+        ctx.save_for_backward(x, w1, w2, mean, h, g)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w1, w2, mean, h, g = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C = x.shape[:2]
+        L = x[0, 0].numel()
+        st = _lib.stream_ptr(x.device)
+        zero = torch.zeros_like(g)
+        S = torch.empty(B * C, 2, device=x.device, dtype=torch.float32)
+        _lib.check(lib.lion_affine_act_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(g), _lib.ptr(zero), B * C, L, 0,
+                                                 _lib.ptr(S), st), "affine_act_bwd_stats")
+        dg = S[:, 1].reshape(B, C)                 # sum over the voxels of gy * x
+        dpre2 = dg * g * (1.0 - g)
+        dw2 = dpre2.t() @ h if ctx.needs_input_grad[2] else None
+        dpre1 = (dpre2 @ w2) * (h > 0).to(h.dtype)
+        dw1 = dpre1.t() @ mean if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Q = ((dpre1 @ w1) / float(L)).contiguous()   # d loss / d x through the mean: the same for every voxel of a channel
+            dx = torch.empty_like(x)
+            _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(g), _lib.ptr(zero), _lib.ptr(Q),
+                                                     _lib.ptr(zero), B * C, L, 0, _lib.ptr(dx), st), "affine_act_bwd_apply")
+        return dx, dw1, dw2
+
+
+def se3d_trainable(se, x) -> bool:
+    fc = getattr(se, "fc", None)
+    return (usable(x) and fc is not None and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear) and fc[0].bias is None
+            and isinstance(fc[2], torch.nn.Linear) and fc[2].bias is None)
+
+
+def se3d(se, x):
+    return _SE3d.apply(x, se.fc[0].weight, se.fc[2].weight)
+
+
 class _PwConv(torch.autograd.Function):
     """kernel-size-1 convolution, every direction on the library's kernels: forward and the data gradient on the 1x1
     MFMA kernels (the data gradient = the same kernel on the transposed matrix), the weight gradient on
@@ -159,11 +227,7 @@ def pwconv_trainable(conv, x) -> bool:
         return False
     lib = _lib.load()
     L = x[0, 0].numel()
-    # Where it pays (measured, B = 32): the grouped set-abstraction layers -- B L = 2^20 columns, <= 128 channels -- whose
-    # library backward is two transposing copies + a GEMM with K = 10^6 (1.45 ms per layer against 0.1 here): VAE step
-    # 157 -> 131 ms.  On the [32, C, 2048] layers of the prior (B L = 65536, up to 512 channels) the library GEMM is the
-    # faster one (prior step 82 vs 88 ms with everything here), so those stay on the matrix-product form.
-    return (x.shape[0] * L >= (1 << 18) and lib.lion_pwconv_stat_tiles(conv.out_channels, conv.in_channels, L) > 0
+    return (x.shape[0] * L >= PWCONV_MIN_COLS and lib.lion_pwconv_stat_tiles(conv.out_channels, conv.in_channels, L) > 0
             and (x.data_ptr() & 15) == 0)
 
 

@@ -101,7 +101,7 @@ def test_trainable_pwconv_matches_float64_autograd(shape):
         B, I, O, L = shape
         conv = torch.nn.Conv1d(I, O, 1).cuda()
         x = torch.randn(B, I, L, device="cuda").requires_grad_(True)
-    # straight through the Function: pwconv_trainable() is the POLICY (only the long layers take this path in a model)
+    # straight through the Function: pwconv_trainable() is the POLICY (layers from 512 columns on take this path in a model)
     y = train_ops._PwConv.apply(x, conv.weight, conv.bias)
     gy = torch.randn_like(y)
     y.backward(gy)
@@ -117,12 +117,18 @@ def test_trainable_pwconv_matches_float64_autograd(shape):
     assert (conv.bias.grad.double() - b64.grad).abs().max().item() <= tol(b64.grad)
 
 
-def test_pwconv_policy_takes_the_long_layers_only():
+def test_pwconv_policy_takes_every_layer_from_512_columns_on():
+    """round 6 (profiles/r06_train_pwconv_ab.txt): own kernels from B x L = 512 columns on; the global prior's [B, C, 1, 1]
+    layers (32 columns: weight-streaming skinny GEMMs) stay on the rocBLAS matrix product"""
     from lion_amd import train_ops
     long_ = torch.randn(8, 35, 1024, 32, device="cuda", requires_grad=True)
-    short = torch.randn(8, 256, 2048, device="cuda", requires_grad=True)
+    mid = torch.randn(8, 256, 2048, device="cuda", requires_grad=True)
+    short = torch.randn(32, 128, 16, 1, device="cuda", requires_grad=True)
+    skinny = torch.randn(32, 2048, 1, 1, device="cuda", requires_grad=True)
     assert train_ops.pwconv_trainable(torch.nn.Conv2d(35, 64, 1).cuda(), long_)
-    assert not train_ops.pwconv_trainable(torch.nn.Conv1d(256, 256, 1).cuda(), short)
+    assert train_ops.pwconv_trainable(torch.nn.Conv1d(256, 256, 1).cuda(), mid)
+    assert train_ops.pwconv_trainable(torch.nn.Conv2d(128, 768, 1).cuda(), short)
+    assert not train_ops.pwconv_trainable(torch.nn.Conv2d(2048, 2048, 1).cuda(), skinny)
 
 
 @pytest.mark.parametrize("shape", [(3, 32, 4096), (2, 64, 16, 16, 16)])
@@ -260,3 +266,44 @@ def test_adagn_act_broadcast_factors_when_batch_equals_channels(fshape, bshape):
             core = core[:-1]
         want = leaf.grad.sum_to_size(core).reshape(t.shape)
         assert (t.grad.double() - want).abs().max().item() <= 3 * tol(want)
+
+
+@pytest.mark.parametrize("B,C,r", [(3, 64, 16), (2, 128, 8), (2, 32, 32)])
+def test_se3d_training_op_matches_float64_autograd(B, C, r):
+    """train_ops.se3d (row sums + one scaling pass forward; one reduction + one fused apply backward) == the module's own
+    expression (reference models/pvcnn2_ada.py:27-41) in float64 autograd: output, d x, d fc weights"""
+    from lion_amd import train_ops
+    from lion_amd.models.pvcnn2_ada import SE3d
+    torch.manual_seed(B + C + r)
+    se = SE3d(C).cuda()
+    x = (torch.randn(B, C, r, r, r, device="cuda") * 0.8 + 0.3).requires_grad_(True)
+    gy = torch.randn(B, C, r, r, r, device="cuda")
+    assert train_ops.se3d_trainable(se, x)
+    y = train_ops.se3d(se, x)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), se.fc[0].weight.grad.clone(), se.fc[2].weight.grad.clone())
+    se64 = SE3d(C).cuda().double()
+    se64.load_state_dict({k: v.double() for k, v in se.state_dict().items()})
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = SE3d.forward(se64, x64)
+    y64.backward(gy.double())
+    want = (y64.detach(), x64.grad, se64.fc[0].weight.grad, se64.fc[2].weight.grad)
+    for name, g, w in zip(("y", "dx", "dw1", "dw2"), got, want):
+        err = (g.double() - w).abs().max().item()
+        assert err <= 2e-5 * max(w.abs().max().item(), 1e-3), (name, err, w.abs().max().item())
+
+
+def test_training_walk_takes_the_se3d_op():
+    """run_layers routes an SE3d behind the second AdaGN of a PVConv through train_ops.se3d when gradients are on"""
+    from unittest import mock
+    from lion_amd import train_ops
+    from lion_amd.models import pvcnn2_ada
+    se = pvcnn2_ada.SE3d(32).cuda()
+    x = torch.randn(2, 32, 8, 8, 8, device="cuda", requires_grad=True)
+    with mock.patch.object(train_ops, "se3d", wraps=train_ops.se3d) as spy:
+        y = pvcnn2_ada.run_layers([se], x, None, None)
+    assert spy.call_count == 1 and y.shape == x.shape
+    with torch.no_grad():    # inference / no-grad: the module's own forward
+        with mock.patch.object(train_ops, "se3d", wraps=train_ops.se3d) as spy:
+            pvcnn2_ada.run_layers([se], x.detach(), None, None)
+        assert spy.call_count == 0

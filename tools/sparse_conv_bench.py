@@ -49,12 +49,10 @@ for c, r, n in ((64, 32, 2048), (32, 32, 2048), (128, 16, 1024)):
         nt = lib.lion_conv3d_stat_tiles(r, c, B, 1)
         o1, o2 = fo.conv3d_occupancy(cnt, r, c, B)
         fr = [1 - ((o.view(-1)[:B * nt] & 0xf) != 0).float().mean().item() for o in (o1, o2)]
-        act, blk = [], []
-        for o in (o1, o2):
-            w = o.view(-1)[2 * B * nt + 4:2 * B * nt + 4 + 8 * B * nt].view(B * nt, 8).cpu().numpy().astype("uint32")
-            per_tile = ((w[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B * nt, 256).sum(1)
-            act.append(per_tile.sum() / (B * nt * 256.0))
-            blk.append(((per_tile + 31) // 32).sum() / (B * nt * 8.0))
+        # active voxels (a point within the margin) from the count grid itself (round 5's bit maps left the occupancy buffer)
+        g_ = (cnt.view(B, 1, r, r, r) > 0).float()
+        act = [torch.nn.functional.max_pool3d(g_, 2 * m_ + 1, 1, m_).mean().item() for m_ in (1, 2)]
+        blk = [float("nan"), float("nan")]
         t_occ = t(lambda: fo.conv3d_occupancy(cnt, r, c, B))
         with torch.no_grad():
             y1, _ = fo.conv3d_fused(grid, conv1, None, True, None)
