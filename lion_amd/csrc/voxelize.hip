@@ -495,7 +495,10 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
   int rem = l_nc, ld2 = (((empt >> (tid & 63)) & 1) != 0) ? 1 : 0x7fffff, taken = 0;
   unsigned long long adopted = 0;   // the chunks this workgroup adopted: 12 bits each, (slab << 8) | chunk
   int n_adopted = 0;
-  if (NP >= 2 && empt != 0) {
+#ifndef LION_VOXS_ADOPT     // A/B builds: tools/build_variant.sh noadopt 'voxelize:-DLION_VOXS_ADOPT=0'
+#define LION_VOXS_ADOPT 1
+#endif
+  if (LION_VOXS_ADOPT && NP >= 2 && empt != 0) {
     for (int it = 0; it < 5 * 16; ++it) {
       int km = (rem << 8) | (63 - (tid & 63)), ka = (ld2 << 8) | (tid & 63);
 #pragma unroll

@@ -120,7 +120,7 @@ class GraphedTrainStep:
     (annealed KL weight) are 0-d device tensors in `inputs`, refreshed with `set_scalar`.
     Construction runs `warmup` eager steps and one or two more for the capture on whatever `inputs` holds -- real
     updates, Adam moments and step counters included.  With `restore=True` (default) the parameters and the optimizer
-    state are snapshotted first and written back IN PLACE afterwards (the captured graph keeps pointing at the same
+    state (and the buffers of `modules`, if given) are snapshotted first and written back IN PLACE afterwards (the captured graph keeps pointing at the same
     state tensors), so the caller's first step starts from the weights, moments and step count it handed in, exactly as
     the eager / reference trainer would (hvae_trainer.py:90-154); `restore=False` keeps the consumed steps.
     The gradient layout is frozen
@@ -128,11 +128,14 @@ class GraphedTrainStep:
     ``grad`` stays None, as the reference's averaging leaves them)."""
 
     def __init__(self, forward_backward, inputs: dict, params, optimizer, averager=None, mode=None, warmup=3,
-                 restore=True):
+                 restore=True, modules=()):
         import os
         import torch.distributed as dist
         self.fb, self.inputs, self.params = forward_backward, dict(inputs), list(params)
         self.opt, self.avg = optimizer, averager
+        # module BUFFERS the warm-up / capture steps may mutate (running statistics, counters): rewound with the parameters.
+        # The released LION networks have none (GroupNorm everywhere); a caller whose model does passes `modules=[model]`.
+        self._buffers = [b for m in modules for b in m.buffers()]
         world = dist.get_world_size() if dist.is_initialized() else 1
         backend = dist.get_backend() if dist.is_initialized() else None
         if mode is None:
@@ -171,12 +174,15 @@ class GraphedTrainStep:
             st = self.opt.state.get(p, None)
             snap.append((p, p.detach().clone(),
                          None if not st else {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}))
+        self._buffer_snapshot = [b.detach().clone() for b in self._buffers]
         return snap
 
     def _restore(self, snap):
         """write the snapshot back THROUGH the live tensors: the captured graphs hold their addresses.  State that did not
         exist before construction (lazily created by the warm-up steps) goes back to its initial value, zero."""
         with torch.no_grad():
+            for b, value in zip(self._buffers, getattr(self, "_buffer_snapshot", [])):
+                b.copy_(value)
             for p, value, st in snap:
                 p.copy_(value)
                 live = self.opt.state.get(p, None)

@@ -259,3 +259,36 @@ def test_graphed_train_step_whole_split_and_eager_agree():
     assert l_w == l_s == l_e == l_r
     for a, b, c, d_ in zip(p_w, p_s, p_e, p_r):
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d_)
+
+
+def test_graphed_train_step_rewinds_module_buffers_too():
+    """round-5 advisor: the warm-up / capture steps of GraphedTrainStep are real steps; buffers a model mutates in its forward
+    (running statistics, counters) are rewound with the parameters when the caller names the modules"""
+    from lion_amd.training import GraphedTrainStep
+
+    class Counting(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(8, 8)
+            self.register_buffer("calls", torch.zeros((), dtype=torch.float32))
+
+        def forward(self, x):
+            self.calls += 1.0
+            return self.lin(x)
+    torch.manual_seed(0)
+    net = Counting().cuda()
+    params = list(net.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+    x = torch.randn(4, 8, device="cuda")
+
+    def fb(x):
+        opt.zero_grad(set_to_none=False)
+        loss = net(x).pow(2).mean()
+        loss.backward()
+        return loss.detach(), None
+    st = GraphedTrainStep(fb, {"x": x.clone()}, params, opt, None, mode="whole", warmup=3, modules=[net])
+    assert float(net.calls) == 0.0          # the construction's steps left no trace
+    st(x=x)
+    st(x=x)
+    torch.cuda.synchronize()
+    assert float(net.calls) == 2.0
