@@ -172,6 +172,16 @@ class DiffusionDiscretized(object):
             raise NotImplementedError(skip_type)
         return sorted(tau, reverse=True)
 
+    def ddim_table(self, steps, kappa):
+        """[S, 8] float32 rows {t_model, s, c, sigma, 0...} of a DDIM chain over the descending timesteps `steps`: what a
+        captured chain reads its per-step scalars from (lion_amd/chain.py)"""
+        table = np.zeros((len(steps), 8), np.float32)
+        for i, t in enumerate(steps):
+            last = i == len(steps) - 1
+            s_, c_, sigma_ = self.ddim_coefficients(t, None if last else steps[i + 1], kappa)
+            table[i, :4] = (t + 1, s_, c_, sigma_)
+        return table
+
     def _noise(self, size, source, device):
         if source == 'cpu':  # the reference's stream: torch.randn(size).to(device), :465-466
             return torch.randn(size).to(device)
@@ -255,11 +265,7 @@ class DiffusionDiscretized(object):
         kwargs = {'grid_emb': grid_emb} if grid_emb is not None else {}
         output_list = []
         if graph and noise == 'device' and _chain.graphable(model, x_noisy, enable_autocast, kwargs):
-            table = np.zeros((len(steps), 8), np.float32)
-            for i, t in enumerate(steps):
-                last = i == len(steps) - 1
-                s_, c_, sigma_ = self.ddim_coefficients(t, None if last else steps[i + 1], kappa)
-                table[i, :4] = (t + 1, s_, c_, sigma_)
+            table = self.ddim_table(steps, kappa)
             ch = self._chains.get(model, num_samples, shape, condition_input, clip_feat, dev, _chain.DDIM,
                                   self._diffusion_steps)
             x_noisy = ch.run(x_noisy, table, _chain.draw_seed(), condition_input, clip_feat,

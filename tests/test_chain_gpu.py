@@ -261,3 +261,4 @@ def test_split_graph_chain_equals_the_single_graph_chain(small_lion):
                 assert torch.equal(a, b), (B, i, (a - b).abs().max().item())
     finally:
         geometry.SPLIT_GRAPH = saved
+
