@@ -463,15 +463,20 @@ def demo_bench(args, rank, world, dev):
     assert tuple(pts.shape) == (1, 2048, 3) and bool(torch.isfinite(pts).all())
     lat = sorted(times[1:])[len(times[1:]) // 2]
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "seconds per shape (latency), 1 x 2048 pts, %d DDIM steps per prior + decode" % K, "value": lat,
             "unit": "s", "n_gpus": world, "steps": K, "warmup": 1, "ms_per_step": lat / K * 1e3, "higher_is_better": False,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[0]: demo.py chair prior, 1 shape x 2048 pts, %d DDIM steps, on the GPU" % K,
                        "calls_timed": len(times) - 1, "first_call_seconds_incl_graph_capture": times[0],
-                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+                       "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "scheduler_parity": "demo.py's diffusers.DDPMScheduler (v0.11.1, not installed, not vendored) is a restatement "
+                                           "here: parity UNPINNED at that boundary (INTEGRATION.md section 4); this line times the "
+                                           "in-tree DDIM sampler the trainers / eval use"},
+            "roofline": {"kernel": "see the --mode sample line", "bound": "mfma", "achieved": None, "peak": None, "unit": "TFLOP/s",
+                         "frac": None, "traffic": None},
             "cpu_baseline": {"value": None, "unit": "s", "cores": os.cpu_count(), "kind": "port",
-                             "sample": "see the --mode sample line"}}), flush=True)
+                             "sample": "see the --mode sample line"}}, args.detail_file.replace(".json", "_demo.json"))
 
 
 def train_bench(args, rank, world, dev, backend):
@@ -1041,7 +1046,12 @@ def main():
             roof_cd = {"kernel": "chamfer_fwd_kernel: 32 pairs of 2048-point clouds, both directions (csrc/chamfer.hip)",
                        "bound": "valu", "achieved": cd_flops / tcd / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                        "frac": cd_flops / tcd / 1e12 / MFMA_F32_PEAK_TF, "us_per_call": tcd * 1e6,
-                       "note": "2 N M distance evaluations x 8 flop per pair (SURVEY.md 8d) against the fp32 vector peak (157.3 TF)"}
+                       "valu_instructions_per_pair": 11.44,
+                       "frac_of_valu_issue_rate": 11.44 * (2.0 * Ne * Ne * B) / tcd / (MFMA_F32_PEAK_TF * 1e12 / 2.0),
+                       "note": "2 N M distance evaluations x 8 flop per pair (SURVEY.md 8d) against the fp32 vector peak (157.3 TF, which "
+                               "counts an FMA per lane and clock).  The bit-exact expression is 3 sub + 3 mul + 2 add + compare + 2 selects "
+                               "= 11.44 VALU instructions per pair in the ISA (no FMA: the oracle's roundings), so the ceiling of THIS "
+                               "instruction stream is 78.6 T lane-instructions/s / 11.44; frac_of_valu_issue_rate relates the launch to it"}
             temd = ev_time_graph(lambda: earth_mover_distance_nograd(ea, eb, transpose=False), 5)
             emd_evals = 30.0 * Ne * Ne * B
             exp_peak = MFMA_F32_PEAK_TF * 1e12 / 2.0 / 4.0        # lane-instructions/s (157.3 TF / 2 flop per FMA), quarter rate
@@ -1050,7 +1060,9 @@ def main():
                         "achieved": emd_evals / temd / 1e12, "peak": exp_peak / 1e12, "unit": "T exp-distance evaluations/s",
                         "frac": emd_evals / temd / exp_peak, "us_per_call": temd * 1e6,
                         "note": "30 N M exp-distance evaluations per pair (SURVEY.md 8d); peak = fp32 vector lane rate "
-                                "(157.3e12 / 2) / 4: transcendentals issue at quarter rate"}
+                                "(157.3e12 / 2) / 4: transcendentals issue at quarter rate.  Round 6: exp2 on pre-scaled coordinates, "
+                                "pass 3 fused with the next level's pass 1 (21 launches instead of 30, 8.4 full-rate VALU instructions "
+                                "per evaluation where there were 13.4): csrc/emd.hip emd_fast_*"}
             p2, p1 = torch.randn(B, 3, 2048, device=dev), None
             tfps = ev_time_graph(lambda: bk.furthest_point_sampling(p2, 1024), 3)
             cen = p2[:, :, :1024].contiguous()

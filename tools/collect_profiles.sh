@@ -1,4 +1,4 @@
-# Round profile set (run through gpurun from the repo root): everything the roofline numbers of DESIGN.md / bench.py are
+# Round profile set (run through gpurun from the repo root; round 6: compact line + detail file, step census, training tables): everything the roofline numbers of DESIGN.md / bench.py are
 # checked against.  Output: gpurun_out/profiles/<tag>_*; copy what should be judged into profiles/ and stamp it with the
 # commit (tools/stamp_profiles.py -- the GPU box has no .git).
 # The driver's command runs UNTRACED first (<tag>_bench_steps20_line.json): rocprofv3 changes how graphs replay (round 2's
@@ -6,29 +6,32 @@
 # stored as <tag>_bench_steps20_TRACED_line.json and only serves the per-kernel tables.
 # SHORT=1 (second argument "short"): only what a change of the sampling path's kernels moves -- the two bench lines, the traced step,
 # operator / conv benches, traffic and MFMA-busy passes (training lines, probes and the 1x1 / wgrad benches keep their last set).
-TAG=${1:-r05}
+TAG=${1:-r06}
 SHORT=0; [ "${2:-}" = short ] && SHORT=1
 R=$PWD; O=$R/gpurun_out/profiles; mkdir -p $O
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
-python bench.py --no-side-lines > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
-[ $SHORT = 1 ] || python bench.py --mode demo > $O/${TAG}_bench_demo.json 2>> $O/${TAG}_bench_default.err
-[ $SHORT = 1 ] || python bench.py --mode train_vae > $O/${TAG}_bench_train_vae.json 2>> $O/${TAG}_bench_default.err
-[ $SHORT = 1 ] || python bench.py --mode train_prior > $O/${TAG}_bench_train_prior.json 2>> $O/${TAG}_bench_default.err
-[ $SHORT = 1 ] || python bench.py --mode train_prior_clip > $O/${TAG}_bench_train_prior_clip.json 2>> $O/${TAG}_bench_default.err
-( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-dense-check --no-side-lines --no-full-chain > $O/${TAG}_bench_steps20_TRACED_line.json 2> /dev/null )
+# the driver's command, untraced: the compact line on stdout + the full record (detail file); wall time of the command beside it
+/usr/bin/time -f "%e s wall" -o $O/${TAG}_bench_steps20_wall.txt python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file $O/${TAG}_bench_steps20_detail.json > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
+python bench.py --forced-steps 0 --small-batches "" --detail-file $O/${TAG}_bench_default_1000steps_detail.json > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
+[ $SHORT = 1 ] || python bench.py --mode demo --detail-file $O/${TAG}_bench_detail.json > $O/${TAG}_bench_demo.json 2>> $O/${TAG}_bench_default.err
+[ $SHORT = 1 ] || bash tools/train_profile.sh $TAG > $O/${TAG}_train_profile.log 2>&1
+[ $SHORT = 1 ] || cp gpurun_out/train_prof/${TAG}_* $O/ 2>/dev/null
+# kernel trace of the same command (rocprofv3 changes how graphs replay: its line is stored as *_TRACED_* and only serves the
+# per-kernel tables) -> per-kernel stats, timeline and the launch census of one replayed step (B = 32, and B = 4 for strong scaling)
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_trace -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-dense-check --no-full-chain --forced-steps 0 --small-batches "" --detail-file /tmp/_traced_detail.json > $O/${TAG}_bench_steps20_TRACED_line.json 2> /dev/null )
 python tools/kstats.py $O/step_trace 70 > $O/${TAG}_bench_steps20_kernel_stats.txt 2>&1
 python tools/trace_gaps.py $O/step_trace begin_step_kernel --top 45 --last 9 > $O/${TAG}_bench_steps20_timeline.txt 2>&1
+python tools/step_census.py $O/step_trace --json $O/${TAG}_step_census_B32.json > $O/${TAG}_step_census_B32.txt 2>&1
+cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --output-format csv -d $O/step_trace4 -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --batch 4 --repeats 1 --no-cpu-baseline --no-dense-check --no-full-chain --forced-steps 0 --small-batches "" --detail-file /tmp/_traced_detail.json > /dev/null 2>&1 )
+python tools/step_census.py $O/step_trace4 --json $O/${TAG}_step_census_B4.json > $O/${TAG}_step_census_B4.txt 2>&1
+rm -rf $O/step_trace4
 python tools/conv_split_bench.py > $O/${TAG}_conv_split_bench.txt 2>/dev/null
 python tools/sparse_conv_bench.py > $O/${TAG}_sparse_conv_bench.txt 2>/dev/null
 python tools/kbench.py > $O/${TAG}_kbench.txt 2>/dev/null
 [ $SHORT = 1 ] || python tools/victims_beside_conv.py --replays 40 > $O/${TAG}_victims_beside_conv.txt 2>/dev/null
 [ $SHORT = 1 ] || python tools/pw_bench.py > $O/${TAG}_pw_bench.txt 2>/dev/null
 [ $SHORT = 1 ] || python tools/wgrad_bench.py > $O/${TAG}_wgrad_bench.txt 2>/dev/null
-[ $SHORT = 1 ] || ./tools/exp/grid_barrier_probe > $O/${TAG}_grid_barrier_probe.txt 2>/dev/null
-[ $SHORT = 1 ] || python tools/vox_clump_bench.py --no-traj > $O/${TAG}_vox_clump_bench.txt 2>/dev/null
 [ $SHORT = 1 ] || python tools/determinism_probe.py 32 5 > $O/${TAG}_determinism_probe.json 2>/dev/null
-[ $SHORT = 1 ] || timeout 120 python tools/rccl_capture_probe.py > $O/${TAG}_rccl_capture_probe.json 2>/dev/null
-cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
 # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE passes) of the kernels the bench line's rooflines are about -- the in-step
 # forms: bench.py reads profiles/r*_{conv_instep,vox_scatter_64_2048_32,devox_affine_64_2048_32}_traffic.json into roofline.traffic
 bash tools/prof_traffic.sh conv_instep conv3d_split_kernel -- python tools/one_conv_instep.py > /dev/null 2>&1
