@@ -615,7 +615,10 @@ __global__ __launch_bounds__(DVR_NT) void devox_ring_kernel(const float *__restr
   }
 }
 
-// One workgroup per (b, c) slab; slab accumulated in LDS.
+// One workgroup per (b, c, part of the grid); its part accumulated in LDS.  gridDim.z parts (round 6: two at r = 32 -- a
+// 128-KiB slab allowed ONE workgroup per CU, so its zero / atomic / store phases ran back to back with nothing beside them;
+// two 64-KiB halves let a second workgroup's atomics run under the first one's stores; every workgroup scans all 8 N
+// entries and keeps those that fall into its part).
 __global__ __launch_bounds__(1024) void devox_bwd_lds_kernel(const float *__restrict__ gy,
                                                              const int32_t *__restrict__ inds,
                                                              const float *__restrict__ wgts, int C,
@@ -625,7 +628,8 @@ __global__ __launch_bounds__(1024) void devox_bwd_lds_kernel(const float *__rest
   float *slab = reinterpret_cast<float *>(smem);
   const int tid = threadIdx.x, nt = blockDim.x;
   const int c = blockIdx.x, b = blockIdx.y;
-  for (int v = tid * 4; v < r3; v += nt * 4)
+  const int part = r3 / gridDim.z, lo = blockIdx.z * part;    // (r3 % (4 gridDim.z) == 0: checked by the launcher)
+  for (int v = tid * 4; v < part; v += nt * 4)
     *reinterpret_cast<float4 *>(slab + v) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const float *g = gy + ((size_t)b * C + c) * N;
@@ -635,13 +639,13 @@ __global__ __launch_bounds__(1024) void devox_bwd_lds_kernel(const float *__rest
     const float gv = g[i];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int ix = min(max(id[(size_t)q * N + i], 0), r3 - 1);
-      atomicAdd(slab + ix, mul_rn(wg[(size_t)q * N + i], gv)); // ds_add_f32
+      const int ix = min(max(id[(size_t)q * N + i], 0), r3 - 1) - lo;
+      if (ix >= 0 && ix < part) atomicAdd(slab + ix, mul_rn(wg[(size_t)q * N + i], gv)); // ds_add_f32
     }
   }
   __syncthreads();
-  float *o = gx + ((size_t)b * C + c) * r3;
-  for (int v = tid * 4; v < r3; v += nt * 4)
+  float *o = gx + ((size_t)b * C + c) * r3 + lo;
+  for (int v = tid * 4; v < part; v += nt * 4)
     *reinterpret_cast<float4 *>(o + v) = *reinterpret_cast<const float4 *>(slab + v);
 }
 
@@ -826,12 +830,16 @@ int lion_trilinear_devoxelize_backward(const float *gy, const int32_t *inds, con
                                        lionStream_t stream) {
   if (!gy || !inds || !wgts || !gx || B <= 0 || C <= 0 || N <= 0 || r3 <= 0) return LION_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)r3 * 4;
-  if (lds <= 128 * 1024 && (r3 % 4) == 0) {
+  if ((size_t)r3 * 4 <= 128 * 1024 && (r3 % 4) == 0) {
+    // (64, 2048, 32), B = 32, one box: 1 part 203 us, 2 parts 189 us, 4 parts 254 us, 8 parts 349 us -- every workgroup scans
+    // all 8 N (index, weight) pairs, so more parts cost more than their overlap returns
+    int parts = (size_t)r3 * 4 > 64 * 1024 ? 2 : 1;
+    if (r3 % (4 * parts) != 0) parts = 1;
+    const size_t lds = (size_t)(r3 / parts) * 4;
     static LionLdsLimit configured = {};
     if (int e = lion_dynamic_lds(&devox_bwd_lds_kernel, lds, configured)) return e;
     const int nt = r3 >= 16384 ? 1024 : 256;
-    devox_bwd_lds_kernel<<<dim3(C, B), nt, lds, st>>>(gy, inds, wgts, C, N, r3, gx);
+    devox_bwd_lds_kernel<<<dim3(C, B, parts), nt, lds, st>>>(gy, inds, wgts, C, N, r3, gx);
     LION_LAUNCH_CHECK();
     return 0;
   }

@@ -10,7 +10,9 @@ TAG=${1:-r06}
 SHORT=0; [ "${2:-}" = short ] && SHORT=1
 R=$PWD; O=$R/gpurun_out/profiles; mkdir -p $O
 # the driver's command, untraced: the compact line on stdout + the full record (detail file); wall time of the command beside it
-/usr/bin/time -f "%e s wall" -o $O/${TAG}_bench_steps20_wall.txt python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file $O/${TAG}_bench_steps20_detail.json > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
+T0=$(python -c "import time; print(time.time())")
+python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file $O/${TAG}_bench_steps20_detail.json > $O/${TAG}_bench_steps20_line.json 2> $O/${TAG}_bench_default.err
+python -c "import time, sys; print('python bench.py --gpus 1 --steps 20 --warmup 5: %.1f s wall (process start to exit)' % (time.time() - float(sys.argv[1])))" $T0 > $O/${TAG}_bench_steps20_wall.txt
 python bench.py --forced-steps 0 --small-batches "" --detail-file $O/${TAG}_bench_default_1000steps_detail.json > $O/${TAG}_bench_default_1000steps.json 2>> $O/${TAG}_bench_default.err
 [ $SHORT = 1 ] || python bench.py --mode demo --detail-file $O/${TAG}_bench_detail.json > $O/${TAG}_bench_demo.json 2>> $O/${TAG}_bench_default.err
 [ $SHORT = 1 ] || bash tools/train_profile.sh $TAG > $O/${TAG}_train_profile.log 2>&1
