@@ -103,7 +103,7 @@ def ev_time_graph(fn, iters, warm=2):
 def hbm_roofline(kernel, algorithmic_bytes, seconds):
     """achieved = SURVEY.md 8d algorithmic bytes / HIP-event time; frac against the 8.0 TB/s spec, frac_of_copy_ceiling
     against the 6.29 TB/s a float4 copy reaches on this part (MI355X_MICROARCH.md).  traffic: HBM bytes per launch
-    come from separate rocprofv3 --pmc passes (tools/prof_traffic.sh -> profiles/r02_*_traffic.json), they cannot be
+    come from separate rocprofv3 --pmc passes (tools/prof_traffic.sh -> profiles/archive/r02_*_traffic.json), they cannot be
     collected inside this process, hence null here."""
     gbs = algorithmic_bytes / seconds / 1e9
     return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -5,7 +5,7 @@
 # located the FPS failures of round 2 there: ONE float2 expression (8 packed instructions) in fps_reg_kernel makes it
 # return wrong samples in 37-40 of 40 graph replays when its waves share SIMDs with conv3d_split_kernel's dense
 # v_mfma_f32_32x32x16_f16 stream; the same kernel without packed fp32 -- with or without s_setprio, at 52, 200 or 256
-# registers -- is right in every one of 100+ replays (profiles/r03_fps_*).  The SLP vectoriser
+# registers -- is right in every one of 100+ replays (profiles/archive/r03_fps_*).  The SLP vectoriser
 # bought nothing measurable anywhere (step, convolutions, 1x1 convolutions, operators: +-1 %) and had inflated
 # fps_reg_kernel<8> from 52 to 194 registers.  tests/test_isa_cpu.py keeps the instruction class out.
 set -euo pipefail

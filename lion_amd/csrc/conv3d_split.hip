@@ -59,7 +59,7 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
 //     bytes of scratch around the staging), step 6.84 -> 6.93 ms;
 //   * a plane-fill kernel for empty tiles in front of the convolution: serialises 30-40 us per convolution, step 6.84 -> 7.05 ms
 //     (as queue items inside this kernel it cost the dense layer 37 %).
-// Evidence: profiles/r05a_conv_ab_variants_one_box.txt, r05a_conv_ab_r04_vs_fill_items_in_kernel.txt,
+// Evidence: profiles/archive/r05a_conv_ab_variants_one_box.txt, r05a_conv_ab_r04_vs_fill_items_in_kernel.txt,
 // r05b_conv_epilogue_phases.txt (where a launch's cycles go).  What was adopted instead is below: empty tiles nobody reads are
 // not stored at all (aware levels), and the work queue re-arms itself.
 template <int N> struct IntC { static constexpr int value = N; }; // compile-time count for generic lambdas

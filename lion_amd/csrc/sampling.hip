@@ -160,7 +160,7 @@ static int launch_fps_reg(const float *coords, int B, int N, int M, int32_t *idx
   // History.  Round 2: inside a captured sampling step this kernel ran on a side stream beside the
   // convolutions and returned 300-1800 wrong indices of 2048 per graph replay whenever conv3d_split_kernel workgroups
   // shared its CUs; it was then given a whole CU's LDS so that nothing could share.  Round 3 named the mechanism with
-  // builds that differ in one property each (tools/victims_beside_conv.py, profiles/r03_fps_variants.txt): the SLP
+  // builds that differ in one property each (tools/victims_beside_conv.py, profiles/archive/r03_fps_variants.txt): the SLP
   // vectoriser had turned the distance arithmetic into PACKED fp32 VALU (v_pk_add_f32 / v_pk_mul_f32); any build that
   // contains them -- even a single float2 expression in an otherwise scalar kernel -- fails in 37-40 of 40 replays beside
   // the fp16-MFMA stream, every build without them (52, 200 or 256 registers, with or without s_setprio) is exact in 100+.

@@ -112,7 +112,7 @@ __device__ __forceinline__ void vox_means_and_store(
       // CHANNELS of one voxel (item = voxel * ch + channel), not consecutive voxels of one channel: the lanes of a wave then
       // walk runs of the same length.  With a voxel per lane, the one lane that held a crowded voxel (the chain's latents
       // put ~900 of a cloud's 2048 points into one) kept its wave for 900 dependent adds while 63 lanes waited, once per
-      // channel: 22 of a workgroup's 38 us (profiles/r05b_scatter_units_wallclock_log.txt).  The order of every sum is
+      // channel: 22 of a workgroup's 38 us (profiles/archive/r05b_scatter_units_wallclock_log.txt).  The order of every sum is
       // unchanged -- bit-identical.
       const int items = my_occ * ch;
       for (int it = tid; it < items; it += VT) {
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
   // two slabs of a cloud (up to ~1900 of 2048 points in a single voxel) and leave most of the others without a point, so
   // that workgroup ran four chunks -- each with a ~1900-long chain of ordered adds -- while its neighbours were done after
   // 10 us of zeros: (64, 2048, 32) took 110 us on the chain's clouds against 61 us on Gaussian ones
-  // (profiles/r05b_scatter_units_wallclock_log.txt).  Now the cloud's workgroups whose own slab is EMPTY take over chunks
+  // (profiles/archive/r05b_scatter_units_wallclock_log.txt).  Now the cloud's workgroups whose own slab is EMPTY take over chunks
   // of the crowded slabs (and run them first, then their zeros); a cloud without an empty slab -- nearly every Gaussian
   // one -- keeps the old assignment.  Same arithmetic per (voxel, channel): bit-identical.
   const int c_per = (C + CS - 1) / CS, cg_lo = cs * c_per, cg_hi = min(C, cg_lo + c_per);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(VT) void vox_scatter_kernel(
   // to the least loaded adopter as long as the move lowers the larger of the two; an adopter takes at most five.
   // Clouds of more than 1024 points only (NP >= 2): the 1024-point instantiation runs two workgroups per CU and the
   // registers of this block cost it that -- (128, 1024, 16) on Gaussian clouds 31 -> 38 us with it, for 54 -> 41 us on the
-  // chain's clouds and nothing on the chain's step (profiles/r05b_scatter_adoption_ab.txt).
+  // chain's clouds and nothing on the chain's step (profiles/archive/r05b_scatter_adoption_ab.txt).
   int rem = l_nc, ld2 = (((empt >> (tid & 63)) & 1) != 0) ? 1 : 0x7fffff, taken = 0;
   unsigned long long adopted = 0;   // the chunks this workgroup adopted: 12 bits each, (slab << 8) | chunk
   int n_adopted = 0;

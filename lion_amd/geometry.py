@@ -20,7 +20,7 @@ _SIDE = {}
 # Off by default (round 3): inside a captured step the side stream becomes a parallel graph branch, and hipGraph replays
 # of multi-branch graphs are SLOWER on ROCm 7.2 than the same kernels on one stream -- B = 32 sampling step, same box,
 # `python bench.py --steps 20 --warmup 5`: prefetch + point-branch streams 13.1-13.2 ms, prefetch only 14.7, point branch
-# only 11.1, single stream 10.6 (profiles/r03_streams_and_graph_knobs.txt; DEBUG_CLR_GRAPH_PACKET_CAPTURE, graph queue
+# only 11.1, single stream 10.6 (profiles/archive/r03_streams_and_graph_knobs.txt; DEBUG_CLR_GRAPH_PACKET_CAPTURE, graph queue
 # count and CP-wait knobs do not change it; under rocprofv3 the branches do overlap and the step takes 9.1 ms).  Eager
 # launches gain 0.4 ms from the prefetch (9.2 -> 8.8 ms).  LION_GEOMETRY_PREFETCH=1 turns it on.
 ENABLED = __import__("os").environ.get("LION_GEOMETRY_PREFETCH", "0") != "0"

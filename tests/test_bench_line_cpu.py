@@ -114,7 +114,7 @@ def test_compact_line_is_what_a_line_parser_can_take():
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    full = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_steps20_line.json")).read().strip().splitlines()[-1])
+    full = json.loads(open(os.path.join(ROOT, "profiles", "archive", "r05_bench_steps20_line.json")).read().strip().splitlines()[-1])
     assert len(json.dumps(full)) > 15000 and json.dumps(full).count('"metric"') > 1      # the record that broke the parser
     text = json.dumps(bench.compact_line(full))
     assert len(text) < 8000, len(text)

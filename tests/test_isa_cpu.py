@@ -149,7 +149,7 @@ def test_1024_point_voxelize_kernels_keep_two_workgroups_per_cu(tmp_path_factory
     CU on half the LDS each (voxelize.hip::make_plan, two_per_cu) -- 32 waves per CU = 8 per SIMD, which the register file
     grants only up to 64 VGPRs (and 96 SGPRs) per wave.  The chunk-adoption block of the scatter kernel and a 16-deep
     prefetch of the ordered sums each pushed the NP = 1 instantiation past that ((128, 1024, 16): 31 -> 38 us,
-    profiles/r05b_scatter_adoption_ab.txt); both are compiled for NP >= 2 only.  The compiler's own occupancy figure
+    profiles/archive/r05b_scatter_adoption_ab.txt); both are compiled for NP >= 2 only.  The compiler's own occupancy figure
     of every NP = 1 instantiation must stay 8, and no voxelize kernel may spill."""
     lst = _listing("voxelize.hip", tmp_path_factory)
     seen = 0

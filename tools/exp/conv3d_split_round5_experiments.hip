@@ -53,19 +53,19 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
 template <int N> struct IntC { static constexpr int value = N; }; // compile-time count for generic lambdas
 
 // Compile-time switches of the round-5 sparse-plan experiments.  BOTH ARE OFF in the product: built, bit-exact, measured on
-// one box against the round-4 kernel inside the sampling step (profiles/r05a_conv_ab_variants_one_box.txt) and not adopted:
+// one box against the round-4 kernel inside the sampling step (profiles/archive/r05a_conv_ab_variants_one_box.txt) and not adopted:
 //   LION_SPLIT_COMPACT 1: voxel compaction inside occupied tiles (below).  Sparse launches on the chain's clouds 8-11 %
 //                         faster (r = 32: 195 -> 179 us, r = 16: 160 -> 142 us), dense launches 5-6 % slower (the third copy
 //                         of the K walk costs the register allocation 40 bytes of scratch around the staging); step 6.84 ->
 //                         6.93 ms.  What a sparse item costs is not its MFMAs: on the chain's clouds 40 % of a sparse launch's wave
 //                         cycles are the epilogue (80 % of its items are empty tiles), 15 % the queue pop, 45 % the K loop
-//                         (profiles/r05b_conv_epilogue_phases.txt).
+//                         (profiles/archive/r05b_conv_epilogue_phases.txt).
 //                      0: the round-3 wave masks (a wave skips its 64-voxel block when no point is within the margin).
 //   LION_SPLIT_FILL    1: empty tiles written by split_fill_kernel in front of the convolution (16-byte stores in plane
 //                         order).  As a kernel of its own it serialises 30-40 us per convolution that the empty work items
 //                         overlap with the occupied tiles' MFMAs: step 6.84 -> 7.05 ms.  As queue items inside the convolution
 //                         kernel (even as a non-inlined function) it cost the dense layer 37 %
-//                         (profiles/r05a_conv_ab_r04_vs_fill_items_in_kernel.txt).
+//                         (profiles/archive/r05a_conv_ab_r04_vs_fill_items_in_kernel.txt).
 //                      0: every empty tile is a work item of the convolution (its epilogue writes bias / constant response).
 // tools/build_variant.sh NAME 'conv3d_split:-DLION_SPLIT_COMPACT=1 -DLION_SPLIT_FILL=1' builds the others; the GPU tests
 // run on every variant (tests/test_hip_parity_gpu.py::test_conv3d_voxel_compaction_matches_dense checks outputs, not which
@@ -82,10 +82,10 @@ template <int N> struct IntC { static constexpr int value = N; }; // compile-tim
 // voxels themselves), and the GroupNorm sums of the sample's empty tiles in closed form (voxels per border configuration x
 // value).  Round 5 measured why this is not left to the convolution's work items: with every empty tile an item of its own
 // (64 stores of 4 bytes per lane into 2 x 512-byte runs per channel) the sparse launches spent 46 % of their cycles in the
-// epilogue and 16 % waiting for its stores at the next queue pop (profiles/r05a_conv_phase_times_sparse_*.txt) -- 268 MB of
+// epilogue and 16 % waiting for its stores at the next queue pop (profiles/archive/r05a_conv_phase_times_sparse_*.txt) -- 268 MB of
 // constants leaving at ~1.6 TB/s.  Inside the convolution kernel (as queue items, even as a non-inlined function) the
 // extra code cost the register allocation of the tap loop 37 % of the dense layer's time
-// (profiles/r05a_conv_ab_r04_vs_fill_items_in_kernel.txt); as a kernel of its own it runs at the stores' rate in front of it.
+// (profiles/archive/r05a_conv_ab_r04_vs_fill_items_in_kernel.txt); as a kernel of its own it runs at the stores' rate in front of it.
 template <int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void split_fill_kernel(int FCO, bool fdelta, float *__restrict__ y,
                                                          const float *__restrict__ bias, const float *__restrict__ tconst,

@@ -1,4 +1,4 @@
-"""reader of the per-chunk wall-clock log of the voxelize scatter kernel (tools/vox_chunk_log_build.py): launch span, when the\nworkgroups end, a least-squares fit of every phase against (channels, channels x points), and the chunks of cloud 0 and of\nthe cloud that finishes last.  profiles/r05b_scatter_adoption_ab.txt / r05b_scatter_units_wallclock_log.txt came from this."""
+"""reader of the per-chunk wall-clock log of the voxelize scatter kernel (tools/vox_chunk_log_build.py): launch span, when the\nworkgroups end, a least-squares fit of every phase against (channels, channels x points), and the chunks of cloud 0 and of\nthe cloud that finishes last.  profiles/archive/r05b_scatter_adoption_ab.txt / r05b_scatter_units_wallclock_log.txt came from this."""
 import ctypes, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lion_amd import _lib, fused_ops as fo
