@@ -276,29 +276,9 @@ int lion_conv3d_tile_occupancy(const int32_t *cnt, int B, int r, int Cout, int32
  * lion_conv3d_tile_occupancy) every voxel of y is written, as before. */
 int lion_conv3d_tile_occupancy_aware(const int32_t *cnt, int B, int r, int Cout, int32_t *occ_m1, int32_t *occ_m2,
                                      int consumer_aware, lionStream_t stream);
-/* Round 6 -- the fold in the TAIL of the kernel that produced the tile sums (csrc/fold.h): the *_fold entry points below take
- * a lion_fold_t and, when fold->counters is non-NULL, the workgroup finishing a sample's last work item writes that sample's
- * A / Bs (== lion_groupnorm_fold, or lion_groupnorm_fold_se when w1 / w2 are given) -- no separate fold launch.  stats is still
- * required (the tile sums travel through it).  counters i32[B]: zero before the first launch; every launch leaves them zero.
- * C <= 256.  A NULL fold (or NULL counters) = the plain entry point.  lion_conv3d_k3_split_forward_fold: r = 8 only (few tiles per
- * channel; at r >= 16 the tail costs more than the launch it saves, profiles/r06_fold_in_tail_ab.txt -> LION_EUNSUPPORTED). */
-typedef struct lion_fold_t {
-  int32_t *counters;          /* i32[B] arrival counters */
-  float *A, *Bs;              /* f32[B, C] */
-  const float *gamma, *beta;  /* GroupNorm weight / bias f32[C] */
-  const float *fac, *gbias;   /* AdaGN factor / bias f32[B, ld_fg] (views of the style projection) */
-  const float *w1, *w2;       /* SE3d fc weights f32[H, C], f32[C, H], or NULL */
-  int G, ld_fg, H;
-  int count;                  /* elements per channel (r^3 or L) */
-  float eps;
-} lion_fold_t;
 int lion_groupnorm_fold(const float *stats, int B, int C, int T, int G, int voxels, const float *gamma,
                         const float *beta, const float *fac, const float *gbias, int ld_fg, float eps,
                         float *A, float *Bs, float *chmean, lionStream_t stream);
-int lion_conv3d_k3_split_forward_fold(const float *x, const uint16_t *wp, const float *bias, int B, int Cin, int Cout,
-                                      int r, const float *pro_a, const float *pro_b, const float *pro_bias,
-                                      const float *tconst, float *y, float *stats, int32_t *occ, const lion_fold_t *fold,
-                                      lionStream_t stream);
 /* ---- C3 on the 16-bit matrix pipe at fp32 accuracy (csrc/conv3d_split.hip) -----------------------------------
  * The same convolution and the same modes as lion_conv3d_k3_fused_forward with every fp32 operand cut into two fp16
  * pieces (a = a_h + a_l/2048; main += W_h X_h, corr += W_h X_l + W_l X_h in fp32 accumulators; 3 MFMAs of

@@ -61,7 +61,6 @@ SIGNATURES = {
     "lion_conv3d_split_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_conv3d_split_stat_tiles": (_i, [_i, _i]),
     "lion_conv3d_k3_split_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "lion_conv3d_k3_split_forward_fold": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     "lion_groupnorm_fold_se": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "lion_skinny_packed_floats": (_sz, [_i, _i]),
@@ -113,12 +112,6 @@ SIGNATURES = {
     "lion_three_nn_interpolate_cat_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
 }
 
-
-
-class FoldDesc(C.Structure):
-    """lion_fold_t (include/lion_hip.h): the GroupNorm fold (+ SE gate) a *_fold entry point performs in its tail"""
-    _fields_ = [("counters", _vp), ("A", _vp), ("Bs", _vp), ("gamma", _vp), ("beta", _vp), ("fac", _vp), ("gbias", _vp),
-                ("w1", _vp), ("w2", _vp), ("G", _i), ("ld_fg", _i), ("H", _i), ("count", _i), ("eps", _f)]
 
 
 _ERR = {-1: "LION_EINVAL (bad shape / null pointer)",

@@ -37,8 +37,7 @@ def policy_key() -> tuple:
     from .models import pvcnn2_ada
     return (pvcnn2_ada.SPARSE_CONV1, pvcnn2_ada.FUSE_INFERENCE, pvcnn2_ada.OVERLAP_POINT_BRANCH, geometry.ENABLED,
             geometry.SPLIT_GRAPH, conv_ops.SPLIT, fused_ops.PW_SPLIT, pvcnn2_ada.VOX_PLAN, TEMB_TABLE, fused_ops.MAX_RECOMPUTE,
-            pvcnn2_ada.SKIP_UNREAD, pvcnn2_ada.SKIP_UNREAD_LEVEL2, CHANNEL_MAJOR_EPS, fused_ops.FOLD_IN_PRODUCER,
-            fused_ops.FOLD_MAX_TILES)
+            pvcnn2_ada.SKIP_UNREAD, pvcnn2_ada.SKIP_UNREAD_LEVEL2, CHANNEL_MAJOR_EPS)
 
 
 class GraphedChain:

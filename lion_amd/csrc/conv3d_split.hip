@@ -29,7 +29,6 @@
 // History: tools/exp/split_*.hip (inner product 400 TF fp32-equivalent; whole layer 779 us vs 1973 us of the fp32
 // kernel with statistics at B=32, 64->64, r=32).
 #include "split_ops.h"
-#include "fold.h"
 
 namespace {
 
@@ -59,7 +58,7 @@ __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin
 //     bytes of scratch around the staging), step 6.84 -> 6.93 ms;
 //   * a plane-fill kernel for empty tiles in front of the convolution: serialises 30-40 us per convolution, step 6.84 -> 7.05 ms
 //     (as queue items inside this kernel it cost the dense layer 37 %).
-// Evidence: profiles/archive/r05a_conv_ab_variants_one_box.txt, r05a_conv_ab_r04_vs_fill_items_in_kernel.txt,
+// Evidence: profiles/r05a_conv_ab_variants_one_box.txt, r05a_conv_ab_r04_vs_fill_items_in_kernel.txt,
 // r05b_conv_epilogue_phases.txt (where a launch's cycles go).  What was adopted instead is below: empty tiles nobody reads are
 // not stored at all (aware levels), and the work queue re-arms itself.
 template <int N> struct IntC { static constexpr int value = N; }; // compile-time count for generic lambdas
@@ -608,7 +607,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
                                                                   const float *__restrict__ bias, float *__restrict__ y,
                                                                   int Cin, int Cout, const float *__restrict__ pro_a,
                                                                   const float *__restrict__ pro_b,
-                                                                  float *__restrict__ stats, LionFold fold) {
+                                                                  float *__restrict__ stats) {
   // NW = 4 waves x 2 column blocks or NW = 8 waves x 1 (two waves per SIMD: see the comment above).  Halo row stride HW:
   // 10 for NW = 4 (block rows {h, h+4, h+1, h+5}), 12 for NW = 8 (block rows {h, h+2, h+4, h+6}: 24 / 48 / 72 = 24, 16, 8
   // mod 32 -- the four rows of a 32-lane group fall into four different quarters of the 512-byte LDS window)
@@ -830,10 +829,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) { s1 += sred[(w * COT + tid) * 2]; s2 += sred[(w * COT + tid) * 2 + 1]; }
-      lion_fold_store2(stats + (((size_t)b * Cout + co0 + tid) * (r / TD) + tile) * 2, s1, s2, fold.counters != nullptr);
+      float *o = stats + (((size_t)b * Cout + co0 + tid) * (r / TD) + tile) * 2;
+      o[0] = s1;
+      o[1] = s2;
     }
-    __shared__ int s_fold;
-    lion_fold_arrive(fold, b, stats, &s_fold, smem, true);
   }
   // @phase 7
   // @phase-flush
@@ -841,18 +840,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_split_pipe_kernel(const flo
 
 template <int NW>
 static int launch_split_pipe(const float *x, const u4 *wp, const float *wtail, const float *bias, float *y, int B, int Cin,
-                             int Cout, const float *pa, const float *pb, float *stats, const lion_fold_t *fold_desc,
-                             hipStream_t st) {
+                             int Cout, const float *pa, const float *pb, float *stats, hipStream_t st) {
   constexpr int HP = NW == 8 ? 768 : 640, COT = 32;
   const dim3 grid(B, 2, Cout / COT);
-  const LionFold fold = lion_make_fold(stats ? fold_desc : nullptr, B, Cout, 2, 2 * (Cout / COT));
   const size_t LDS = (size_t)(2 * 4 * HP + 3 * 9 * 4 * COT) * 16 +
                      (size_t)(COT + (pa ? 2 * ((Cin + 63) & ~63) : 0) + NW * COT * 2) * 4;
 #define LION_PIPE_GO(PRO_, ST_)                                                                              \
   {                                                                                                          \
     static LionLdsLimit cfg = {};                                                                            \
     if (int e = lion_dynamic_lds(&conv3d_split_pipe_kernel<PRO_, ST_, NW>, LDS, cfg)) return e;              \
-    conv3d_split_pipe_kernel<PRO_, ST_, NW><<<grid, 64 * NW, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, pa, pb, stats, fold); \
+    conv3d_split_pipe_kernel<PRO_, ST_, NW><<<grid, 64 * NW, LDS, st>>>(x, wp, wtail, bias, y, Cin, Cout, pa, pb, stats); \
   }
   if (pa && stats) LION_PIPE_GO(true, true)
   else if (pa) LION_PIPE_GO(true, false)
@@ -912,21 +909,7 @@ int lion_conv3d_split_stat_tiles(int r, int Cout) {
 int lion_conv3d_k3_split_forward(const float *x, const uint16_t *wp, const float *bias, int B, int Cin, int Cout,
                                  int r, const float *pro_a, const float *pro_b, const float *pro_bias,
                                  const float *tconst, float *y, float *stats, int32_t *occ, lionStream_t stream) {
-  return lion_conv3d_k3_split_forward_fold(x, wp, bias, B, Cin, Cout, r, pro_a, pro_b, pro_bias, tconst, y, stats, occ, nullptr,
-                                           stream);
-}
-
-// the same with the GroupNorm fold (+ SE gate) of the output in the kernel's tail (csrc/fold.h)
-int lion_conv3d_k3_split_forward_fold(const float *x, const uint16_t *wp, const float *bias, int B, int Cin, int Cout,
-                                      int r, const float *pro_a, const float *pro_b, const float *pro_bias,
-                                      const float *tconst, float *y, float *stats, int32_t *occ, const lion_fold_t *fold,
-                                      lionStream_t stream) {
   if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
-  if (fold && fold->counters && !stats) return LION_EINVAL;
-  if (int e = lion_check_fold(fold, Cout)) return e;
-  // the tail fold exists in the r = 8 kernel only: at 16 / 128 tiles per channel it costs the convolution more than the
-  // launch it saves (profiles/r06_fold_in_tail_ab.txt), and the large kernel keeps its round-5 register allocation
-  if (fold && fold->counters && r != 8) return LION_EUNSUPPORTED;
   if ((pro_a == nullptr) != (pro_b == nullptr)) return LION_EINVAL;
   if (tconst && !pro_a) return LION_EINVAL;
   if (occ && pro_a && !tconst) return LION_EINVAL;
@@ -940,7 +923,7 @@ int lion_conv3d_k3_split_forward_fold(const float *x, const uint16_t *wp, const 
   const float *wtail = reinterpret_cast<const float *>(wp + split_piece_halfs(Cout, Cin));
   if (r == 8) {
     if (tconst) return LION_EUNSUPPORTED;
-    return launch_split_pipe<8>(x, w4, wtail, bias, y, B, Cin, Cout, pro_a, pro_b, stats, fold, st);
+    return launch_split_pipe<8>(x, w4, wtail, bias, y, B, Cin, Cout, pro_a, pro_b, stats, st);
   }
 #define LION_SPLIT_TILE(R_, VB_, CB_, TD_, TH_, TW_, OCC_)                                                  \
   if (r == R_ && p.vb == VB_ && p.cb == CB_)                                                                \

@@ -46,37 +46,13 @@ def conv3d_occupancy(counts, r, cout, b, consumer_aware=False):
     return buf[0], buf[1]
 
 
-# Round 6: the GroupNorm fold (+ SE gate) of a layer's output runs in the tail of the kernel that produced the tile sums
-# (csrc/fold.h) instead of as its own launch.  LION_FOLD_IN_PRODUCER=0 restores the separate lion_groupnorm_fold* launches.
-FOLD_IN_PRODUCER = __import__("os").environ.get("LION_FOLD_IN_PRODUCER", "1") != "0"
-# ... where it pays.  Measured per launch inside the step (profiles/r06_fold_in_tail_ab.txt): the separate fold launch costs
-# 5.3 us (7.8 with the SE gate); the tail costs the convolution +3.0 / +6.4 us at 2 tiles per channel (r = 8), +7 us at 16
-# (r = 16) and +16 us at 128 (r = 32: the owner reads 64 KB of tile sums past its L2) -- so only layers with few tiles fold
-# in their tail; the others keep the launch.
-FOLD_MAX_TILES = int(__import__("os").environ.get("LION_FOLD_MAX_TILES", "8"))
-_FOLD_COUNTERS = {}
-
-
-def _fold_counters(owner, b, device):
-    """the arrival counters of one layer: int32 zeros [B], allocated once per (layer, B, device) outside graph capture (a
-    launch leaves them zero again); None while a capture is running and none exist yet -- the caller then takes the
-    separate fold launch."""
-    key = (id(owner), int(b), str(device))
-    hit = _FOLD_COUNTERS.get(key)
-    if hit is not None and hit[0]() is owner:
-        return hit[1]
-    if torch.cuda.is_current_stream_capturing():
-        return None
-    import weakref
-    buf = torch.zeros(int(b), device=device, dtype=torch.int32)
-    _FOLD_COUNTERS[key] = (weakref.ref(owner), buf)
-    return buf
-
-
 class FoldSpec:
     """what groupnorm_fold / groupnorm_fold_se need besides the tile sums: the AdaGN's GroupNorm, the style factor / bias
-    views, the element count per channel and (optionally) the SE3d module -- handed to a producer (conv3d_fused /
-    pwconv_fused) so that its kernel writes (A, Bs) itself."""
+    views, the element count per channel and (optionally) the SE3d module -- handed to a producer (conv3d_fused), which
+    returns (A, Bs) instead of the sums.  (Round 6 built the fold into the producing kernel's tail -- the workgroup finishing
+    a sample's last tile folds it, agent-scope stores + a relaxed arrival counter, no L2 write-back -- bit-identical, 14-28
+    launches per step fewer and NOT faster: the tail costs the convolution what the launch cost the step.  Kept out of the
+    product: tools/exp/fold_in_tail/, profiles/r06_fold_in_tail_ab.txt.)"""
 
     def __init__(self, gn: torch.nn.GroupNorm, fac, gbias, count, se=None):
         self.gn, self.fac, self.gbias, self.count, self.se = gn, fac, gbias, int(count), se
@@ -92,31 +68,6 @@ class FoldSpec:
         a, b_, _ = groupnorm_fold(stats, self.gn, self.fac, self.gbias, self.count)
         return a, b_
 
-    def descriptor(self, owner, b, c, device, tiles):
-        """(ctypes descriptor, A, Bs, keep-alive list) or None when the in-kernel fold does not apply"""
-        if not FOLD_IN_PRODUCER or tiles > FOLD_MAX_TILES or c > 256 or c < 4 or c % self.gn.num_groups:
-            return None
-        w1 = w2 = None
-        h = 0
-        if self.se is not None:
-            w1, w2 = self.se.fc[0].weight.detach(), self.se.fc[2].weight.detach()
-            h = w1.shape[0]
-            if h > 128 or not (w1.is_contiguous() and w2.is_contiguous()):
-                return None
-        cnt = _fold_counters(owner, b, device)
-        if cnt is None:
-            return None
-        fac, gbias = self.fac, self.gbias
-        if not (fac.stride(1) == 1 and gbias.stride(1) == 1 and fac.stride(0) == gbias.stride(0) and fac.stride(0) >= c):
-            fac, gbias = fac.contiguous(), gbias.contiguous()
-        A = torch.empty((b, c), device=device, dtype=torch.float32)
-        Bs = torch.empty_like(A)
-        gw, gb = self.gn.weight.detach(), self.gn.bias.detach()
-        d = _lib.FoldDesc(cnt.data_ptr(), A.data_ptr(), Bs.data_ptr(), gw.data_ptr(), gb.data_ptr(), fac.data_ptr(),
-                          gbias.data_ptr(), None if w1 is None else w1.data_ptr(), None if w2 is None else w2.data_ptr(),
-                          self.gn.num_groups, int(fac.stride(0)), h, self.count, float(self.gn.eps))
-        return d, A, Bs, (fac, gbias, gw, gb, w1, w2, cnt)
-
 
 def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None, split=None, fold=None):
     """x [B,Cin,r,r,r] -> (y [B,Cout,r,r,r], stats [B,Cout,T,2] | None).  pro = (A, Bs) applies
@@ -131,8 +82,7 @@ def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None, s
         2 voxels.
     split (None = conv_ops.SPLIT): run on the split-operand kernel (fp16 x 2 pieces on the 16-bit MFMA pipe, fp32
     accurate, csrc/conv3d_split.hip) where Cin % 16 == 0; same modes, same results within fp32 rounding.
-    fold (a FoldSpec): return (y, (A, Bs)) -- the GroupNorm fold of y (+ SE gate) -- instead of (y, stats); computed in the
-    kernel's tail on the split kernel, by the separate fold launch otherwise."""
+    fold (a FoldSpec): return (y, (A, Bs)) -- the GroupNorm fold of y (+ SE gate) -- instead of (y, stats)."""
     lib = _lib.load()
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = conv.out_channels
@@ -166,16 +116,6 @@ def conv3d_fused(x, conv, pro=None, want_stats=True, occ=None, prev_conv=None, s
         stats = torch.empty((b, cout, tiles, 2), device=x.device, dtype=torch.float32)
     if not sparse:
         occ = None
-    if fold is not None:
-        assert want_stats
-        fd = fold.descriptor(conv, b, cout, x.device, tiles) if use_split and r == 8 else None
-        if fd is not None:
-            import ctypes
-            _lib.check(lib.lion_conv3d_k3_split_forward_fold(
-                _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), b, cin, cout, r, _lib.ptr(pa), _lib.ptr(pb), _lib.ptr(pbias),
-                _lib.ptr(tconst), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(occ), ctypes.byref(fd[0]), st),
-                "conv3d_k3_split_forward_fold")
-            return y, (fd[1], fd[2])
     fwd = lib.lion_conv3d_k3_split_forward if use_split else lib.lion_conv3d_k3_fused_forward
     _lib.check(fwd(
         _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias),

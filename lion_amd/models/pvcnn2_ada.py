@@ -420,8 +420,6 @@ class PVConv(nn.Module):
         occ1 = occ2 = None
         if SPARSE_CONV1 and counts is not None and r >= 16:
             occ1, occ2 = _occupancy(counts, r, conv1.out_channels, grid.shape[0], self._aware_level())
-        # round 6: each convolution's tail folds its own GroupNorm sums (+ the SE gate behind conv2) -- csrc/fold.h; the
-        # separate lion_groupnorm_fold[_se] launches remain for the fp32 kernel and under LION_FOLD_IN_PRODUCER=0
         f1, g1 = gn1.affine(style)
         y1, (a1, b1) = fused_ops.conv3d_fused(grid, conv1, None, True, occ1,   # skips all-zero tiles
                                               fold=fused_ops.FoldSpec(gn1.norm, f1, g1, r ** 3))
