@@ -262,3 +262,40 @@ def test_split_graph_chain_equals_the_single_graph_chain(small_lion):
     finally:
         geometry.SPLIT_GRAPH = saved
 
+
+
+def test_state_hook_graph_equals_eager(small_lion):
+    """run_ddim(state_hook=...) (round 6; bench.py's forced clouds, known-region replacement): the hook overwrites the chain's
+    latent before every model evaluation, in the graphed chain and in the eager loop alike.  With kappa = 0 (no noise enters) the
+    two paths give the same final latent bit for bit, the hook is called once per step with ascending step indices, and the result
+    differs from the un-hooked chain."""
+    lion, d = small_lion, small_lion.diffusion
+    B, S = 2, 4
+    sh = lion.vae.latent_shape()
+    style = lion.vae.global2style(torch.randn([B] + sh[0], device="cuda"))
+    x0 = torch.randn([B] + sh[1], device="cuda")
+    forced = [torch.randn([B] + sh[1], device="cuda") for _ in range(S)]
+    outs = {}
+    for graph in (True, False):
+        seen = []
+
+        def hook(i, x):
+            seen.append(i)
+            x.copy_(forced[i])
+        outs[graph], _ = d.run_ddim(lion.priors[1], B, sh[1], ddim_step=S, kappa=0.0, condition_input=style, x_noisy=x0.clone(),
+                                    is_image=False, graph=graph, state_hook=hook, keep_trajectory=False)
+        assert seen == list(range(S))
+    plain, _ = d.run_ddim(lion.priors[1], B, sh[1], ddim_step=S, kappa=0.0, condition_input=style, x_noisy=x0.clone(),
+                          is_image=False, graph=True, keep_trajectory=False)
+    assert torch.equal(outs[True], outs[False])
+    assert not torch.equal(outs[True], plain)
+
+
+def test_sampler_state_hook_names_the_prior(small_lion):
+    from lion_amd.sampling import generate_samples_vada_2prior
+    lion, d = small_lion, small_lion.diffusion
+    calls = []
+    generate_samples_vada_2prior(lion.vae.latent_shape(), lion.priors, d, lion.vae, 2, ddim_step=3,
+                                 state_hook=lambda prior, i, x: calls.append((prior, i, tuple(x.shape))))
+    assert [c[:2] for c in calls] == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)]
+    assert calls[0][2][0] == 2 and calls[3][2][1] == 2048 * 4
