@@ -149,6 +149,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float *__res
 // one accumulator: 112 accumulator registers, as the fp32 kernel.  A fragment = 8 consecutive voxels of a row (TW % 8 == 0):
 // gy rows at stride 260 floats (16-byte aligned, conflict-free b128 reads), x windows at the column's tap offset (dword reads).
 constexpr int WG_GS = 260;
+// Round 6: the cut moves from the fragment to the STAGING.  A staged element is cut once, when its tile is written to LDS,
+// into one 32-bit word {low half: the fp16 main piece, high half: the fp16 remainder}; a fragment then gathers the main
+// halves of its 8 words into 4 registers and the remainders into 4 more with v_perm_b32 -- 8 VALU per fragment instead of 24.
+// An x element used to be cut once per TAP COLUMN that reads it (27 x per tile), 672 of the 825 vector instructions a thread
+// spent per tile; now 57.5 staged elements x 4 + 7 x 4 x 8 permutes.  Same conversions (v_cvt_pk_f16_f32, round to nearest
+// even), same pieces: the gradient is bit-identical to the round-4 kernel's.
+__device__ __forceinline__ void cut2w(float a, float b, unsigned &wa, unsigned &wb) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const h2_t h = __builtin_convertvector(f2_t{a, b}, h2_t);
+  const h2_t l = __builtin_convertvector(f2_t{a - (float)h[0], b - (float)h[1]}, h2_t);
+  const unsigned hi2 = __builtin_bit_cast(unsigned, h), lo2 = __builtin_bit_cast(unsigned, l);
+  wa = __builtin_amdgcn_perm(lo2, hi2, 0x05040100u);   // {h_a, l_a}
+  wb = __builtin_amdgcn_perm(lo2, hi2, 0x07060302u);   // {h_b, l_b}
+}
+__device__ __forceinline__ unsigned cut1w(float a) {
+  const _Float16 h = (_Float16)a;
+  const _Float16 l = (_Float16)(a - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+// main halves / remainders of two staged words -> one packed operand register each
+__device__ __forceinline__ unsigned mains(unsigned w0, unsigned w1) { return __builtin_amdgcn_perm(w1, w0, 0x05040100u); }
+__device__ __forceinline__ unsigned rests(unsigned w0, unsigned w1) { return __builtin_amdgcn_perm(w1, w0, 0x07060302u); }
 __device__ __forceinline__ void cut2u(float a, float b, unsigned &hi2, unsigned &lo2) { // split_ops.h::cut2 without the 2048
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -202,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
   constexpr int NCOL = CIT * 27, NB = (NCOL + 31) / 32;
   constexpr int GS = WG_GS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *sgy = smem;            // [32][GS]  gy * 2^eg
-  float *sx = sgy + 32 * GS;    // [CIT][HALO]  x * 2^ex
+  unsigned *sgy = reinterpret_cast<unsigned *>(smem);   // [32][GS]  gy * 2^eg, cut: {main, remainder} halves per word
+  unsigned *sx = sgy + 32 * GS;                         // [CIT][HALO]  x * 2^ex, cut
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Workgroup ids go round-robin over the 8 XCDs (private L2s).  A gy tile (32 KiB of the 59 staged per tile) is needed by
   // all Cin / CIT workgroups of a (sample split, output-channel tile) unit: those sit on ONE XCD, next to each other in
@@ -265,15 +288,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
         rx[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, c * r3 * 4, 0));
     }
   };
-  auto store_tile = [&]() { // scaled: the cuts in front of the MFMAs need no multiply
+  auto store_tile = [&]() { // scaled and cut (two channels per conversion)
 #pragma unroll
-    for (int c = 0; c < 32; ++c) sgy[c * GS + tid] = rgy[c] * sgs;
+    for (int c = 0; c < 32; c += 2) {
+      unsigned wa, wb;
+      cut2w(rgy[c] * sgs, rgy[c + 1] * sgs, wa, wb);
+      sgy[c * GS + tid] = wa;
+      sgy[(c + 1) * GS + tid] = wb;
+    }
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const int p = tid + 256 * i;
       if (p < HALO) {
+        static_assert(CIT % 2 == 0, "channel pairs");
 #pragma unroll
-        for (int c = 0; c < CIT; ++c) sx[c * HALO + p] = rx[i][c] * sxs;
+        for (int c = 0; c < CIT; c += 2) {
+          unsigned wa, wb;
+          cut2w(rx[i][c] * sxs, rx[i][c + 1] * sxs, wa, wb);
+          sx[c * HALO + p] = wa;
+          sx[(c + 1) * HALO + p] = wb;
+        }
       }
     }
   };
@@ -289,13 +323,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
       const int v0 = wave * 64 + 16 * s + 8 * kh;
       const int d = v0 / (TH * TW), h = (v0 / TW) % TH, w = v0 % TW;
       const int vb = (d * HH + h) * HW + w;
-      const float4 g0 = *reinterpret_cast<const float4 *>(sgy + cl * GS + v0);
-      const float4 g1 = *reinterpret_cast<const float4 *>(sgy + cl * GS + v0 + 4);
+      const u4 g0 = *reinterpret_cast<const u4 *>(sgy + cl * GS + v0);
+      const u4 g1 = *reinterpret_cast<const u4 *>(sgy + cl * GS + v0 + 4);
       u4 ah, al;
-      { unsigned hh_, ll_; cut2u(g0.x, g0.y, hh_, ll_); ah[0] = hh_; al[0] = ll_;
-        cut2u(g0.z, g0.w, hh_, ll_); ah[1] = hh_; al[1] = ll_;
-        cut2u(g1.x, g1.y, hh_, ll_); ah[2] = hh_; al[2] = ll_;
-        cut2u(g1.z, g1.w, hh_, ll_); ah[3] = hh_; al[3] = ll_; }
+      ah[0] = mains(g0[0], g0[1]); al[0] = rests(g0[0], g0[1]);
+      ah[1] = mains(g0[2], g0[3]); al[1] = rests(g0[2], g0[3]);
+      ah[2] = mains(g1[0], g1[1]); al[2] = rests(g1[0], g1[1]);
+      ah[3] = mains(g1[2], g1[3]); al[3] = rests(g1[2], g1[3]);
       // column blocks in two groups (4 + the rest): the fragments of a group live in registers while its 3 x G MFMAs run,
       // and an accumulator is touched again G MFMAs later
       constexpr int G0 = NB < 4 ? NB : 4;
@@ -305,12 +339,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
 #pragma unroll
         for (int q = 0; q < G0; ++q) {
           const int nb = min(n0 + q, NB - 1);
-          const float *xp = sx + cofs[nb] + vb;
-          float xv[8];
+          const unsigned *xp = sx + cofs[nb] + vb;
+          unsigned xv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) xv[j] = xp[j];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) { unsigned hh_, ll_; cut2u(xv[2 * m], xv[2 * m + 1], hh_, ll_); bh[q][m] = hh_; bl[q][m] = ll_; }
+          for (int m = 0; m < 4; ++m) { bh[q][m] = mains(xv[2 * m], xv[2 * m + 1]); bl[q][m] = rests(xv[2 * m], xv[2 * m + 1]); }
         }
 #pragma unroll
         for (int q = 0; q < G0; ++q) if (n0 + q < NB) acc[n0 + q] = mma(ah, bh[q], acc[n0 + q]);
