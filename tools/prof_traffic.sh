@@ -4,7 +4,7 @@
 # name contains KERNEL_SUBSTR: average duration, raw counters (KiB units) and HBM bytes per launch with the gfx950
 # correction (FETCH_SIZE x 2 for wide coalesced reads).  Output: gpurun_out/traffic/NAME.json (+ the CSVs).
 NAME=$1; SUB=$2; shift 3
-R=$PWD; O=$R/gpurun_out/traffic/$NAME; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$PWD; O=$R/gpurun_out/traffic/$NAME; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp   # (a fresh directory: the summary below reads the first CSV it finds)
 ( cd $R && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- "$@" > /dev/null 2>&1 )
 ( cd $R && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- "$@" > /dev/null 2>&1 )
 ( cd $R && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- "$@" > /dev/null 2>&1 )
