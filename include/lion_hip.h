@@ -310,6 +310,12 @@ int lion_skinny_gemm(const float *pin, int ks_in, const float *bias_in, int act_
                      const float *wp, int nb, int Cin, int Cout, float *pout, lionStream_t stream);
 int lion_skinny_finish(const float *A, int ks_a, const float *bias_a, const float *Bp, int ks_b, const float *resid,
                        int nb, int C, int mode, float *y, lionStream_t stream);
+/* activations of the global denoiser [B, C, 1, 1] <-> the channel-major [ceil(B/32)][C][32] form its layers work on
+ * (models/score_sde/resnet.py:195-218 keeps [B, C, 1, 1]); a / b: two tensors per launch (either may be NULL), row strides
+ * lda / ldb in floats (0 = one row broadcast over the batch: the time embedding of a chain step). */
+int lion_to_channel_major(const float *a, int lda, int Ca, float *oa, const float *b, int ldb, int Cb, float *ob, int B,
+                          lionStream_t stream);
+int lion_from_channel_major(const float *x, int B, int C, float *y, lionStream_t stream);
 /* SE3d (pvcnn2_ada.py:27-41) on the folded scalars: A, Bs f32[B,C] are multiplied in place by
  * sigmoid(W2 relu(W1 (A*chmean + Bs))), w1 f32[H,C], w2 f32[C,H] (C <= 1024, H <= 128). */
 /* lion_groupnorm_fold + lion_se_gate in one launch (C <= 256, H <= 128): the second AdaGN of a PVConv with its SE3d gate

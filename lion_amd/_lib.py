@@ -68,6 +68,8 @@ SIGNATURES = {
     "lion_skinny_splits": (_i, [_i, _i]),
     "lion_skinny_gemm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_skinny_finish": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "lion_to_channel_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "lion_from_channel_major": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_se_gate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lion_trilinear_devoxelize_affine_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_devoxelize_plan_bytes": (_sz, [_i, _i, _i]),

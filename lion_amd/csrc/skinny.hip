@@ -150,6 +150,28 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const float *__restr
   y[i] = a;
 }
 
+// [B][C] (row stride ld floats; ld = 0: one row for the whole batch) -> [nb][C][32] with the batch on the fast axis, zero beyond
+// B; two tensors per launch (the block's input x and the time embedding t), either may be absent.  And back.  (Round 6: these
+// were three ATen transposing copies per step of the global prior's chain.)
+__global__ __launch_bounds__(256) void to_channel_major_kernel(const float *__restrict__ a, int lda, int Ca, float *__restrict__ oa,
+                                                               const float *__restrict__ b, int ldb, int Cb, float *__restrict__ ob,
+                                                               int B, int nb) {
+  const int na = a ? nb * Ca * 32 : 0, nbb = b ? nb * Cb * 32 : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nbb; i += gridDim.x * 256) {
+    const bool second = i >= na;
+    const int j = second ? i - na : i, C = second ? Cb : Ca, ld = second ? ldb : lda;
+    const float *src = second ? b : a;
+    const int col = j & 31, c = (j >> 5) % C, blk = j / (32 * C), row = blk * 32 + col;
+    (second ? ob : oa)[j] = row < B ? src[(size_t)row * ld + c] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void from_channel_major_kernel(const float *__restrict__ x, int B, int C, float *__restrict__ y) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * C) return;
+  const int row = i / C, c = i - row * C;
+  y[i] = x[((size_t)(row >> 5) * C + c) * 32 + (row & 31)];
+}
+
 // element i of wp = [tile][s4][kh][j][e]: channel tile*32 + j, input k = 2*(4*s4 + e) + kh
 __global__ void skinny_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int ksteps4,
                                    float *__restrict__ wp) {
@@ -212,6 +234,23 @@ int lion_skinny_finish(const float *A, int ks_a, const float *bias_a, const floa
   const int n = nb * C * 32;
   skinny_finish_kernel<<<lion_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(A, ks_a, bias_a, Bp, ks_b,
                                                                                         resid, n, C, mode, y);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_to_channel_major(const float *a, int lda, int Ca, float *oa, const float *b, int ldb, int Cb, float *ob, int B,
+                          lionStream_t stream) {
+  if (B <= 0 || (!a && !b) || (a && (!oa || Ca <= 0 || lda < 0)) || (b && (!ob || Cb <= 0 || ldb < 0))) return LION_EINVAL;
+  const int nb = (B + 31) / 32, total = nb * 32 * ((a ? Ca : 0) + (b ? Cb : 0));
+  to_channel_major_kernel<<<lion_cdiv(total, 256) > 64 ? 64 : lion_cdiv(total, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      a, lda, Ca, oa, b, ldb, Cb, ob, B, nb);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_from_channel_major(const float *x, int B, int C, float *y, lionStream_t stream) {
+  if (!x || !y || B <= 0 || C <= 0) return LION_EINVAL;
+  from_channel_major_kernel<<<lion_cdiv(B * C, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(x, B, C, y);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -575,6 +575,34 @@ def three_nn_interpolate_cat(points, centers, cfeat, temb, skip):
     return fn(points, centers, cfeat, rows, ld, skip)[0]
 
 
+def _rows2d(x):
+    """[B, C(, 1, 1)] as (2-D view, row stride in floats) for lion_to_channel_major, or None (not a float32 GPU tensor with
+    unit channel stride)"""
+    b, c = x.shape[0], x.shape[1]
+    v = x.reshape(b, c) if x.dim() != 2 else x
+    if not (v.is_cuda and v.dtype == torch.float32 and (c == 1 or v.stride(1) == 1)):
+        return None
+    return v, (0 if b == 1 else int(v.stride(0)))
+
+
+def to_channel_major_pair(x, t):
+    """(x, t) [B, C, 1, 1] -> their channel-major forms in ONE launch of this library (t may be an expanded single row); the
+    torch formulation when either operand does not qualify"""
+    rx, rt = _rows2d(x), _rows2d(t)
+    if rx is None or rt is None or torch.is_grad_enabled():
+        if t.shape[0] == 1 and x.shape[0] > 1:
+            t = t.expand(x.shape[0], *t.shape[1:])
+        return to_channel_major(x), to_channel_major(t)
+    (vx, ldx), (vt, ldt) = rx, rt
+    b = x.shape[0]
+    nb = (b + 31) // 32
+    ox = torch.empty((nb, vx.shape[1], 32), device=x.device, dtype=torch.float32)
+    ot = torch.empty((nb, vt.shape[1], 32), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().lion_to_channel_major(_lib.ptr(vx), ldx, vx.shape[1], _lib.ptr(ox), _lib.ptr(vt), ldt, vt.shape[1],
+                                                 _lib.ptr(ot), b, _lib.stream_ptr(x.device)), "to_channel_major")
+    return ox, ot
+
+
 def to_channel_major(x):
     """[B, C, 1, 1] (or [B, C]) -> [nb, C, 32] with the batch zero-padded to a multiple of 32."""
     b, c = x.shape[0], x.shape[1]
@@ -587,6 +615,11 @@ def to_channel_major(x):
 
 def from_channel_major(xt, b):
     nb, c, _ = xt.shape
+    if xt.is_cuda and xt.dtype == torch.float32 and xt.is_contiguous() and not torch.is_grad_enabled():
+        y = torch.empty((b, c, 1, 1), device=xt.device, dtype=torch.float32)
+        _lib.check(_lib.load().lion_from_channel_major(_lib.ptr(xt), b, c, _lib.ptr(y), _lib.stream_ptr(xt.device)),
+                   "from_channel_major")
+        return y
     return xt.transpose(1, 2).reshape(nb * 32, c)[:b].reshape(b, c, 1, 1).contiguous()
 
 

@@ -167,11 +167,11 @@ class Prior(nn.Module):
         h1 = relu(conv1(x + t)); h2 = relu(conv2(h1)); s = relu(fc1 h2); x = x + h2 * sigmoid(fc2 s)."""
         from ... import fused_ops as fo
         b = x.shape[0]
-        if temb.shape[0] == 1 and b > 1:
+        if temb.shape[0] != 1 and temb.shape[0] != b:
             temb = temb.expand(b, -1, -1, -1)
-        tt = fo.to_channel_major(temb)
+        xt, tt = fo.to_channel_major_pair(x, temb)      # one launch (a single temb row is broadcast by the kernel)
         bias = lambda conv: conv.bias.detach() if conv.bias is not None else None  # noqa: E731
-        h = fo.skinny_finish(fo.skinny_conv(fo.to_channel_major(x), self.input_layer), bias(self.input_layer))
+        h = fo.skinny_finish(fo.skinny_conv(xt, self.input_layer), bias(self.input_layer))
         for blk in self.all_modules:
             p1 = fo.skinny_conv(h, blk.conv1, add=tt)                               # conv1(x + t)
             p2 = fo.skinny_conv(p1, blk.conv2, bias_in=bias(blk.conv1), act_in=1)   # conv2(relu(. + b1))

@@ -1094,3 +1094,22 @@ def test_chain_update_channel_major_eps_equals_the_transposed_update():
         _lib.check(lib.lion_chain_update_noise_cm(mode, _lib.ptr(x), _lib.ptr(eps_cm), B, N, _lib.ptr(c), _lib.ptr(seed), 0,
                                                   _lib.ptr(o2), _lib.ptr(z2), st), "update_cm")
         assert torch.equal(o1, o2) and torch.equal(z1, z2)
+
+
+@pytest.mark.parametrize("B,C,Ct,bcast", [(32, 128, 2048, True), (5, 128, 64, False), (40, 16, 8, True), (1, 128, 2048, True)])
+def test_channel_major_transposes_equal_the_torch_formulation(B, C, Ct, bcast):
+    """lion_to_channel_major / lion_from_channel_major (round 6: the global prior's step without ATen copies) == the reshape /
+    pad / transpose formulation, incl. a single time-embedding row broadcast over the batch and batches that are not multiples of 32"""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(B + C)
+    x = torch.randn(B, C, 1, 1, device="cuda")
+    t = torch.randn(1 if bcast else B, Ct, 1, 1, device="cuda")
+    with torch.no_grad():
+        ox, ot = fo.to_channel_major_pair(x, t)
+        te = t.expand(B, -1, -1, -1) if bcast else t
+        assert torch.equal(ox, fo.to_channel_major(x)) and torch.equal(ot, fo.to_channel_major(te))
+        back = fo.from_channel_major(ox, B)
+        assert back.shape == x.shape and torch.equal(back, x)
+    with torch.enable_grad():     # the torch formulation under autograd: same values
+        ox2, ot2 = fo.to_channel_major_pair(x, t)
+    assert torch.equal(ox2, ox) and torch.equal(ot2, ot)

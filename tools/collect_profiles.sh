@@ -23,6 +23,8 @@ python bench.py --forced-steps 0 --small-batches "" --detail-file $O/${TAG}_benc
 python tools/kstats.py $O/step_trace 70 > $O/${TAG}_bench_steps20_kernel_stats.txt 2>&1
 python tools/trace_gaps.py $O/step_trace begin_step_kernel --top 45 --last 9 > $O/${TAG}_bench_steps20_timeline.txt 2>&1
 python tools/step_census.py $O/step_trace --json $O/${TAG}_step_census_B32.json > $O/${TAG}_step_census_B32.txt 2>&1
+# the global prior's 20 replayed steps of the same call sit in front of the local prior's 20
+python tools/step_census.py $O/step_trace --slice -39 -21 --json $O/${TAG}_step_census_global_prior_B32.json > $O/${TAG}_step_census_global_prior_B32.txt 2>&1
 cp $O/step_trace/step_kernel_stats.csv $O/${TAG}_bench_steps20_kernel_stats.csv 2>/dev/null
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --output-format csv -d $O/step_trace4 -o step -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --batch 4 --repeats 1 --no-cpu-baseline --no-dense-check --no-full-chain --forced-steps 0 --small-batches "" --detail-file /tmp/_traced_detail.json > /dev/null 2>&1 )
 python tools/step_census.py $O/step_trace4 --json $O/${TAG}_step_census_B4.json > $O/${TAG}_step_census_B4.txt 2>&1

@@ -2,7 +2,7 @@
 kernel between consecutive launches of MARKER (begin_step_kernel: first kernel of a chain step), over the last K intervals (the
 local prior's chain runs last).  ATen kernels (at::native / at::cuda) are listed separately: bench.py reads the JSON this writes
 (profiles/r*_step_census*.json) into config.launches_per_step / config.aten_kernels_in_step.
-usage: step_census.py DIR [--last K] [--json OUT] [--top N] [--marker NAME]"""
+usage: step_census.py DIR [--last K | --first K] [--json OUT] [--top N] [--marker NAME]"""
 import csv, glob, json, re, sys
 from collections import defaultdict
 
@@ -20,7 +20,11 @@ def short(n):
 
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(f))]
 ts = sorted(s for s, e, k in rows if marker in k)
-ts = ts[-(last + 1):]
+first = int(arg("--first", 0))      # --first K: the first K intervals instead (the global prior's chain runs first)
+ts = ts[:first + 1] if first else ts[-(last + 1):]
+if "--slice" in sys.argv:            # --slice A B: markers[A:B] of the whole list (python slice; e.g. -39 -21 = the global prior's
+    i_ = sys.argv.index("--slice")   # replays of a 20-step timed call: the local prior's 20 steps come after them)
+    ts = sorted(s for s, e, k in rows if marker in k)[int(sys.argv[i_ + 1]):int(sys.argv[i_ + 2])]
 lo, hi, n = ts[0], ts[-1], len(ts) - 1
 cnt, tim = defaultdict(int), defaultdict(float)
 for s, e, k in rows:
