@@ -755,9 +755,16 @@ def main():
             for f_ in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_step_census_B%d.json" % B)), reverse=True):
                 try:
                     c_ = json.load(open(f_))
-                    census = {"launches": c_["launches_per_step"], "aten": c_["aten_kernels_per_step"],
+                    census = {"launches_local_prior": c_["launches_per_step"], "aten_local_prior": c_["aten_kernels_per_step"],
+                              "launches": c_["launches_per_step"], "aten": c_["aten_kernels_per_step"],
                               "aten_names": c_.get("aten_names"), "source": os.path.relpath(f_, ROOT),
                               "profile_commit": c_.get("profile_commit")}
+                    fg_ = f_.replace("_step_census_B", "_step_census_global_prior_B")
+                    if os.path.exists(fg_):      # a step = one DDIM step of BOTH priors
+                        g_ = json.load(open(fg_))
+                        census["launches_global_prior"], census["aten_global_prior"] = g_["launches_per_step"], g_["aten_kernels_per_step"]
+                        census["launches"] += g_["launches_per_step"]
+                        census["aten"] += g_["aten_kernels_per_step"]
                     break
                 except Exception:
                     continue
