@@ -450,6 +450,16 @@ int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, c
                               float *S, lionStream_t stream);
 int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
                               const float *R, int rows, int L, int act, float *dx, lionStream_t stream);
+/* Round 6 -- the same op with the set-abstraction pooling behind it (pvcnn2_ada.py:375-377): y f32[rows, M] = max over the U
+ * neighbours of act(A x + Bs), x f32[rows, M, U] (U in {8, 16, 32, 64}).  The activated tensor is never written and its gradient
+ * never materialised: backward = lion_affine_act_max_bwd_stats (S = {sum da, sum da x}, da = gy act'(.) at each group's FIRST
+ * arg-max, 0 elsewhere) -> lion_gn_train_bwd_fold -> lion_affine_act_max_bwd_apply (dx = [arg-max] A da + Q + R x). */
+int lion_affine_act_max(const float *x, const float *A, const float *Bs, int rows, int M, int U, int act, float *y,
+                        lionStream_t stream);
+int lion_affine_act_max_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int M, int U,
+                                  int act, float *S, lionStream_t stream);
+int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                                  const float *R, int rows, int M, int U, int act, float *dx, lionStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,9 @@ SIGNATURES = {
     "lion_affine_act": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lion_affine_act_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_affine_act_max_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "lion_affine_act_max_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_ddim_update": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp, _vp]),
     "lion_ddpm_update": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp, _vp]),
     "lion_chain_begin_step": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),

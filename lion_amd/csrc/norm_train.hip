@@ -129,6 +129,88 @@ __global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *
   }
 }
 
+// ---- round 6: y[row][m] = max_u act(A x[row][m][u] + Bs) -- the set-abstraction pooling behind the last AdaGN + Swish of a
+// grouped SharedMLP (reference models/pvcnn2_ada.py:375-377) as ONE differentiable op.  The activated [B,C,M,U] tensor is never
+// written (forward) and its gradient -- zero except at each group's arg-max -- never materialised (backward): every pass
+// recomputes act(A x + Bs) over the U neighbours of a group from x.  Arg-max = the FIRST maximal neighbour (ball query pads a
+// group with copies of its first hit: which copy receives the gradient does not change the sum grouping's backward forms).
+template <int U4>   // U = 4 * U4 neighbours per group
+__device__ __forceinline__ int group_argmax(const float4 *__restrict__ p, float a, float b, int act, float &vmax, float &xmax) {
+  int best = 0;
+  vmax = -INFINITY; xmax = 0.f;
+#pragma unroll
+  for (int q = 0; q < U4; ++q) {
+    const float4 v = p[q];
+    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float y = act_f(xs[j] * a + b, act);
+      if (y > vmax) { vmax = y; xmax = xs[j]; best = 4 * q + j; }   // strict: the first maximum wins
+    }
+  }
+  return best;
+}
+template <int U4>
+__global__ __launch_bounds__(256) void affine_act_max_kernel(const float *__restrict__ x, const float *__restrict__ A,
+                                                             const float *__restrict__ Bs, int M, int act, float *__restrict__ y) {
+  const int row = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float vmax, xmax;
+  group_argmax<U4>(reinterpret_cast<const float4 *>(x + ((size_t)row * M + m) * (4 * U4)), A[row], Bs[row], act, vmax, xmax);
+  y[(size_t)row * M + m] = vmax;
+}
+// S[row] = {sum da, sum da x} with da = gy[row][m] act'(A x* + Bs) at the group's arg-max x*, 0 elsewhere
+template <int U4>
+__global__ __launch_bounds__(256) void affine_act_max_bwd_stats_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                       const float *__restrict__ A, const float *__restrict__ Bs,
+                                                                       int M, int act, float *__restrict__ S) {
+  __shared__ float r1[4], r2[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float a = A[row], b = Bs[row];
+  float s1 = 0.f, s2 = 0.f;
+  for (int m = tid; m < M; m += 256) {
+    float vmax, xmax;
+    group_argmax<U4>(reinterpret_cast<const float4 *>(x + ((size_t)row * M + m) * (4 * U4)), a, b, act, vmax, xmax);
+    const float da = gy[(size_t)row * M + m] * act_d(xmax * a + b, act);
+    s1 += da;
+    s2 += da * xmax;
+  }
+  s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
+#pragma unroll
+  for (int q = 16; q < 64; q <<= 1) { s1 += __shfl_xor(s1, q, 64); s2 += __shfl_xor(s2, q, 64); }
+  if (lane == 0) { r1[wave] = s1; r2[wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    S[(size_t)row * 2] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    S[(size_t)row * 2 + 1] = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+  }
+}
+// dx[row][m][u] = (u == arg-max ? A da : 0) + Q + R x
+template <int U4>
+__global__ __launch_bounds__(256) void affine_act_max_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                                       const float *__restrict__ A, const float *__restrict__ Bs,
+                                                                       const float *__restrict__ Q, const float *__restrict__ R,
+                                                                       int M, int act, float *__restrict__ dx) {
+  const int row = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float a = A[row], b = Bs[row], qq = Q[row], rr = R[row];
+  const float4 *p = reinterpret_cast<const float4 *>(x + ((size_t)row * M + m) * (4 * U4));
+  float vmax, xmax;
+  const int best = group_argmax<U4>(p, a, b, act, vmax, xmax);
+  const float g = a * (gy[(size_t)row * M + m] * act_d(xmax * a + b, act));
+  float4 *o = reinterpret_cast<float4 *>(dx + ((size_t)row * M + m) * (4 * U4));
+#pragma unroll
+  for (int q = 0; q < U4; ++q) {
+    const float4 v = p[q];
+    float4 d = make_float4(qq + rr * v.x, qq + rr * v.y, qq + rr * v.z, qq + rr * v.w);
+    if (best == 4 * q) d.x += g;
+    if (best == 4 * q + 1) d.y += g;
+    if (best == 4 * q + 2) d.z += g;
+    if (best == 4 * q + 3) d.w += g;
+    o[q] = d;
+  }
+}
+
 // the [B, C] scalar algebra of both directions, one workgroup per sample (C <= 1024 threads), in double
 // forward: stats [B,C,2] (row sums) -> A, Bs, mean, rstd [B,C]
 template <typename ST>
@@ -268,5 +350,45 @@ int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, c
   LION_LAUNCH_CHECK();
   return 0;
 }
+
+// U in {8, 16, 32, 64}; x f32[rows, M, U] 16-byte aligned
+#define LION_AAM_DISPATCH(KERNEL, GRID, ...)                                                       \
+  switch (U) {                                                                                     \
+  case 8:  KERNEL<2><<<GRID, 256, 0, st>>>(__VA_ARGS__); break;                                    \
+  case 16: KERNEL<4><<<GRID, 256, 0, st>>>(__VA_ARGS__); break;                                    \
+  case 32: KERNEL<8><<<GRID, 256, 0, st>>>(__VA_ARGS__); break;                                    \
+  case 64: KERNEL<16><<<GRID, 256, 0, st>>>(__VA_ARGS__); break;                                   \
+  default: return LION_EUNSUPPORTED;                                                               \
+  }
+int lion_affine_act_max(const float *x, const float *A, const float *Bs, int rows, int M, int U, int act, float *y,
+                        lionStream_t stream) {
+  if (!x || !A || !Bs || !y || rows <= 0 || M <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
+  if ((((uintptr_t)x) & 15) != 0 || rows > 65535) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LION_AAM_DISPATCH(affine_act_max_kernel, dim3(lion_cdiv(M, 256), rows), x, A, Bs, M, act, y)
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_affine_act_max_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int M, int U,
+                                  int act, float *S, lionStream_t stream) {
+  if (!x || !gy || !A || !Bs || !S || rows <= 0 || M <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
+  if ((((uintptr_t)x) & 15) != 0) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LION_AAM_DISPATCH(affine_act_max_bwd_stats_kernel, rows, x, gy, A, Bs, M, act, S)
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                                  const float *R, int rows, int M, int U, int act, float *dx, lionStream_t stream) {
+  if (!x || !gy || !A || !Bs || !Q || !R || !dx || rows <= 0 || M <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
+  if (((((uintptr_t)x) | ((uintptr_t)dx)) & 15) != 0 || rows > 65535) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LION_AAM_DISPATCH(affine_act_max_bwd_apply_kernel, dim3(lion_cdiv(M, 256), rows), x, gy, A, Bs, Q, R, M, act, dx)
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+#undef LION_AAM_DISPATCH
 
 } // extern "C"

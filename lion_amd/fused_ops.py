@@ -515,7 +515,7 @@ def adagn_swish(x, adagn, style, reduce_max=False):
     return y
 
 
-# ---- D2: global denoiser on channel-major activations (csrc/skinny.hip) -----------------------------------
+# ---- round 6: layout / concatenation passes of a denoiser forward on this library's kernels (no ATen copy in a captured step) --
 
 def broadcast_rows(temb):
     """a [B, C, N] time embedding that is a per-sample row expanded along N (stride 0) -> ([B-strided, C] view, row stride in
@@ -574,6 +574,8 @@ def three_nn_interpolate_cat(points, centers, cfeat, temb, skip):
     skip = None if skip is None else skip.contiguous()
     return fn(points, centers, cfeat, rows, ld, skip)[0]
 
+
+# ---- D2: global denoiser on channel-major activations (csrc/skinny.hip) -----------------------------------
 
 def _rows2d(x):
     """[B, C(, 1, 1)] as (2-D view, row stride in floats) for lion_to_channel_major, or None (not a float32 GPU tensor with

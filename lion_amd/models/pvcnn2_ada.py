@@ -249,10 +249,12 @@ def route_1x1_convs(module):
     return module
 
 
-def run_layers(layers, x, style, conv):
+def run_layers(layers, x, style, conv, reduce_max=False):
     """the generic (training / non-fused) walk over [conv, AdaGN, Swish, ...] layer lists.  With gradients enabled on the
     GPU an AdaGN (and the Swish behind it, when there is one) is ONE differentiable op on the library's kernels
-    (lion_amd/train_ops.py: two passes forward, three backward, instead of ATen's five and ten)."""
+    (lion_amd/train_ops.py: two passes forward, three backward, instead of ATen's five and ten).
+    reduce_max: additionally the max over the last axis of the result (the SA modules' pooling); when the list ends in
+    AdaGN + Swish on a [B, C, M, U] activation that pooling is part of the same op (train_ops.adagn_act_max, round 6)."""
     from .. import train_ops
     i, n = 0, len(layers)
     while i < n:
@@ -261,6 +263,8 @@ def run_layers(layers, x, style, conv):
             if train_ops.usable(x) and layer.n_channel <= 1024:
                 fused_act = i + 1 < n and isinstance(layers[i + 1], Swish)
                 factor, bias = layer.affine(style)
+                if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x):
+                    return train_ops.adagn_act_max(x, layer.norm, factor, bias, act=fused_act)   # pooled: [B, C, M]
                 x = train_ops.adagn_act(x, layer.norm, factor, bias, act=fused_act)
                 i += 2 if fused_act else 1
                 continue
@@ -272,7 +276,7 @@ def run_layers(layers, x, style, conv):
         else:
             x = layer(x)
         i += 1
-    return x
+    return x.max(dim=-1).values if reduce_max else x
 
 
 class SharedMLP(nn.Module):
@@ -302,8 +306,7 @@ class SharedMLP(nn.Module):
             n = len(self.layers) // 3
             convs, gns = [self.layers[3 * i] for i in range(n)], [self.layers[3 * i + 1] for i in range(n)]
             return fused_ops.shared_mlp(x, convs, gns, style, reduce_max, add=add)
-        x = run_layers(list(self.layers), x, style, conv1x1)
-        x = x.max(dim=-1).values if reduce_max else x
+        x = run_layers(list(self.layers), x, style, conv1x1, reduce_max=reduce_max)
         return x if add is None else x + add
 
     def forward_max(self, x, style):

@@ -118,6 +118,88 @@ class _AdaGNAct(torch.autograd.Function):
         return dx, dgw, dgb, dfac, dbias, None, None, None
 
 
+class _AdaGNActMax(torch.autograd.Function):
+    """max over the last (neighbour) axis of act(GroupNorm(x) * factor + bias) for x [B, C, M, U] -> [B, C, M]: _AdaGNAct with
+    the set-abstraction pooling (reference pvcnn2_ada.py:375-377) folded in.  Forward: row sums + one pass that writes [B, C, M]
+    only; backward: one reduction + one pass writing dx -- the activated [B, C, M, U] tensor and its (one-hot per group) gradient
+    are never materialised (csrc/norm_train.hip, round 6)."""
+
+    @staticmethod
+    def forward(ctx, x, gw, gb, factor, bias, groups, eps, act):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, M, U = x.shape
+        L = M * U
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        stats = torch.empty(B * C, 2, device=dev, dtype=torch.float64)
+        _lib.check(lib.lion_row_stats64(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats64")
+        A, Bs, mean, rstd = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(4))
+        gwc, gbc = gw.detach().float().contiguous(), gb.detach().float().contiguous()
+        f, fs = _rowview(factor.detach(), B, C) if factor is not None else (None, 0)
+        bb, bs = _rowview(bias.detach(), B, C) if bias is not None else (None, 0)
+        _lib.check(lib.lion_gn_train_fold64(_lib.ptr(stats), _lib.ptr(gwc), _lib.ptr(gbc), _lib.ptr(f), fs, _lib.ptr(bb), bs,
+                                            B, C, groups, L, eps, _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(mean), _lib.ptr(rstd),
+                                            st), "gn_train_fold64")
+        y = torch.empty(B, C, M, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_affine_act_max(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), B * C, M, U, int(act), _lib.ptr(y), st),
+                   "affine_act_max")
+        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0))
+        ctx.meta = (groups, int(act), factor is not None, bias is not None, fs,
+                    None if factor is None else factor.shape, None if bias is None else bias.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, A, Bs, mean, rstd, gwc, gbc, f = ctx.saved_tensors
+        groups, act, has_f, has_b, fs, f_shape, b_shape = ctx.meta
+        gy = gy.contiguous()
+        B, C, M, U = x.shape
+        L = M * U
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        S = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_affine_act_max_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, M, U, act,
+                                                     _lib.ptr(S), st), "affine_act_max_bwd_stats")
+        Q, R = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
+        dfac = torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None
+        dbias = torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None
+        pw = torch.empty(B, C, 2, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
+                                              _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
+                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), st), "gn_train_bwd_fold")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.lion_affine_act_max_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
+                                                         _lib.ptr(R), B * C, M, U, act, _lib.ptr(dx), st),
+                       "affine_act_max_bwd_apply")
+        dpw = pw.sum(0)
+        dgw = dpw[:, 0].contiguous() if ctx.needs_input_grad[1] else None
+        dgb = dpw[:, 1].contiguous() if ctx.needs_input_grad[2] else None
+
+        def back(g, shape):
+            shape = tuple(int(d) for d in shape)
+            core = shape
+            while len(core) > 2 and core[-1] == 1:
+                core = core[:-1]
+            return g.sum_to_size(core if core else (1,)).reshape(shape)
+        dfac = back(dfac, f_shape) if has_f and ctx.needs_input_grad[3] else None
+        dbias = back(dbias, b_shape) if has_b and ctx.needs_input_grad[4] else None
+        return dx, dgw, dgb, dfac, dbias, None, None, None
+
+
+def adagn_act_max_usable(x) -> bool:
+    return usable(x) and x.dim() == 4 and x.shape[3] in (8, 16, 32, 64) and x.shape[0] * x.shape[1] <= 65535
+
+
+def adagn_act_max(x, norm, factor=None, bias=None, act=True):
+    """max_u act(GroupNorm(x) * factor + bias) over the last axis of x [B, C, M, U] (see _AdaGNActMax)."""
+    return _AdaGNActMax.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act))
+
+
 def adagn_act(x, norm, factor=None, bias=None, act=True):
     """act(GroupNorm(x) * factor + bias); factor / bias [B, C] (or broadcastable views of it) or None."""
     return _AdaGNAct.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act))

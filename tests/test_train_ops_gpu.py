@@ -307,3 +307,71 @@ def test_training_walk_takes_the_se3d_op():
         with mock.patch.object(train_ops, "se3d", wraps=train_ops.se3d) as spy:
             pvcnn2_ada.run_layers([se], x.detach(), None, None)
         assert spy.call_count == 0
+
+
+@pytest.mark.parametrize("shape,ada,act", [((3, 64, 256, 32), True, True), ((2, 32, 64, 32), True, False), ((2, 128, 16, 32), False, True),
+                                           ((2, 16, 40, 8), True, True)])
+def test_adagn_act_max_matches_float64_autograd(shape, ada, act):
+    """train_ops.adagn_act_max == max over the neighbours of swish(GroupNorm(x) * f + b) in float64 autograd: value, d x, d
+    GroupNorm weight / bias, d factor / bias.  The activated tensor is never written; the gradient reaches each group's first
+    arg-max only."""
+    from lion_amd import train_ops
+    B, C, M, U = shape
+    torch.manual_seed(sum(shape))
+    gn = torch.nn.GroupNorm(8, C).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(shape, device="cuda", requires_grad=True)
+    f = (torch.randn(B, C, device="cuda") * 0.3 + 1.0).requires_grad_(True) if ada else None
+    b = (torch.randn(B, C, device="cuda") * 0.3).requires_grad_(True) if ada else None
+    gy = torch.randn(B, C, M, device="cuda")
+    assert train_ops.adagn_act_max_usable(x)
+    y = train_ops.adagn_act_max(x, gn, f, b, act=act)
+    y.backward(gy)
+    got = [y.detach(), x.grad, gn.weight.grad, gn.bias.grad] + ([f.grad, b.grad] if ada else [])
+    x64 = x.detach().double().requires_grad_(True)
+    gn64 = torch.nn.GroupNorm(8, C).cuda().double()
+    gn64.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+    f64 = f.detach().double().requires_grad_(True) if ada else None
+    b64 = b.detach().double().requires_grad_(True) if ada else None
+    h = gn64(x64)
+    if ada:
+        h = h * f64[:, :, None, None] + b64[:, :, None, None]
+    if act:
+        h = h * torch.sigmoid(h)
+    y64 = h.max(dim=-1).values
+    y64.backward(gy.double())
+    want = [y64.detach(), x64.grad, gn64.weight.grad, gn64.bias.grad] + ([f64.grad, b64.grad] if ada else [])
+    for name, g, w in zip(("y", "dx", "dgw", "dgb", "dfac", "dbias"), got, want):
+        err = (g.double() - w).abs().max().item()
+        assert err <= 5e-5 * max(w.abs().max().item(), 1e-3), (name, err, w.abs().max().item())
+
+
+def test_sa_mlp_training_pools_inside_the_last_activation():
+    """SharedMLP.forward_max in training mode: the last AdaGN + Swish + max over the neighbours is ONE op (no [B, C, M, U]
+    activation stored); same value and gradients as the generic walk followed by .max()"""
+    from unittest import mock
+    from lion_amd import train_ops
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models import pvcnn2_ada as m
+    cfg = released_prior_cfg()
+    torch.manual_seed(4)
+    mlp = m.SharedMLP(19, [32, 64], dim=2, cfg=cfg).cuda().train()
+    x = torch.randn(3, 19, 128, 32, device="cuda", requires_grad=True)
+    sty = torch.randn(3, 128, device="cuda")
+    with mock.patch.object(train_ops, "adagn_act_max", wraps=train_ops.adagn_act_max) as spy:
+        y = mlp.forward_max(x, sty)
+    assert spy.call_count == 1 and tuple(y.shape) == (3, 64, 128)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    gx, gws = x.grad.clone(), [p.grad.clone() for p in mlp.parameters()]
+    x.grad = None
+    mlp.zero_grad()
+    with mock.patch.object(train_ops, "adagn_act_max_usable", return_value=False):
+        y2 = mlp.forward_max(x, sty)
+    y2.backward(gy)
+    assert (y - y2).abs().max().item() <= 2e-6 * y2.abs().max().item()
+    assert (gx - x.grad).abs().max().item() <= 1e-4 * x.grad.abs().max().item()
+    for a, p in zip(gws, mlp.parameters()):
+        assert (a - p.grad).abs().max().item() <= 2e-4 * max(p.grad.abs().max().item(), 1e-6)
