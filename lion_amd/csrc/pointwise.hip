@@ -291,6 +291,7 @@ int lion_concat_broadcast(const float *a, const float *t, int B, int Ca, int Ct,
                           lionStream_t stream) {
   if (!a || !t || !out || B <= 0 || Ca <= 0 || Ct <= 0 || N <= 0 || ld_t < 0) return LION_EINVAL;
   if (N % 4 != 0 || ((((uintptr_t)a) | ((uintptr_t)out)) & 15) != 0) return LION_EUNSUPPORTED;
+  if ((long)B * (Ca + Ct) > 65535) return LION_EUNSUPPORTED;   // one grid row per (sample, channel)
   const int N4 = N / 4;
   concat_broadcast_kernel<<<dim3(lion_cdiv(N4, 256) > 4 ? 4 : lion_cdiv(N4, 256), B * (Ca + Ct)), 256, 0,
                             static_cast<hipStream_t>(stream)>>>(a, t, Ca, Ct, N4, ld_t, reinterpret_cast<float4 *>(out));

@@ -549,8 +549,11 @@ def concat_broadcast(a, temb):
     b, ca, n = a.shape
     ct = rows.shape[1]
     out = torch.empty((b, ca + ct, n), device=a.device, dtype=torch.float32)
-    _lib.check(_lib.load().lion_concat_broadcast(_lib.ptr(a), _lib.ptr(rows), b, ca, ct, n, ld, _lib.ptr(out),
-                                                 _lib.stream_ptr(a.device)), "concat_broadcast")
+    rc = _lib.load().lion_concat_broadcast(_lib.ptr(a), _lib.ptr(rows), b, ca, ct, n, ld, _lib.ptr(out),
+                                           _lib.stream_ptr(a.device))
+    if rc == -2:      # LION_EUNSUPPORTED (more than 65535 (sample, channel) rows): the caller's torch.cat
+        return None
+    _lib.check(rc, "concat_broadcast")
     return out
 
 
