@@ -310,6 +310,12 @@ int lion_skinny_gemm(const float *pin, int ks_in, const float *bias_in, int act_
                      const float *wp, int nb, int Cin, int Cout, float *pout, lionStream_t stream);
 int lion_skinny_finish(const float *A, int ks_a, const float *bias_a, const float *Bp, int ks_b, const float *resid,
                        int nb, int C, int mode, float *y, lionStream_t stream);
+/* Round 6: the second squeeze-excite GEMM of a residual block WITH the block's tail (resnet.py:77-86) in its epilogue:
+ * y = resid + relu(sum_q A[q] + bias_a) * sigmoid(W act_in(sum pin + bias_in)) == lion_skinny_gemm + lion_skinny_finish(mode 1)
+ * bit for bit, one launch.  Needs lion_skinny_splits(Cin, Cout) == 1. */
+int lion_skinny_gemm_se_finish(const float *pin, int ks_in, const float *bias_in, int act_in, const float *wp, int nb, int Cin,
+                               int Cout, const float *A, int ks_a, const float *bias_a, const float *resid, float *y,
+                               lionStream_t stream);
 /* activations of the global denoiser [B, C, 1, 1] <-> the channel-major [ceil(B/32)][C][32] form its layers work on
  * (models/score_sde/resnet.py:195-218 keeps [B, C, 1, 1]); a / b: two tensors per launch (either may be NULL), row strides
  * lda / ldb in floats (0 = one row broadcast over the batch: the time embedding of a chain step). */

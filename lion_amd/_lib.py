@@ -67,6 +67,7 @@ SIGNATURES = {
     "lion_skinny_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_skinny_splits": (_i, [_i, _i]),
     "lion_skinny_gemm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lion_skinny_gemm_se_finish": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "lion_skinny_finish": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "lion_to_channel_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "lion_from_channel_major": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -39,11 +39,17 @@ __device__ __forceinline__ float4 ld_stream(const float4 *p) { // read-once weig
 // with ONE coalesced 16-byte load per lane, partial and chunk, reduces / biases / activates it in registers, parks
 // it in its private 4 KiB of LDS and feeds the MFMAs from there; all weight loads of the wave (<= 4 x 16 B per
 // lane and round) are issued before anything waits.
+// FIN (round 6): the layer is the second squeeze-excite GEMM of a block (one k-split: the tile's sum is complete in this
+// workgroup) and its epilogue IS the block's tail -- y = resid + relu(sum_q A[q] + bias_a) * sigmoid(tile sum), the arithmetic of
+// skinny_finish_kernel mode 1 in the same order -- instead of raw partials followed by that launch (8 launches per step).
+template <bool FIN>
 __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restrict__ pin, int ks_in,
                                                            const float *__restrict__ bias_in, int act_in,
                                                            const float *__restrict__ addT,
                                                            const float *__restrict__ wp, int Cin, int Cout,
-                                                           float *__restrict__ pout) {
+                                                           float *__restrict__ pout, const float *__restrict__ fa, int ks_a,
+                                                           const float *__restrict__ bias_a,
+                                                           const float *__restrict__ resid) {
   extern __shared__ __attribute__((aligned(16))) float smem[]; // [16][1024]: operand slices, then partial tiles
   float(*part)[1024] = reinterpret_cast<float(*)[1024]>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,6 +133,15 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const float *__restri
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < 16; ++w) s += part[w][tid]; // element (o = tid / 32, b = tid % 32), fixed order
+  if (FIN) { // (KS == 1: checked by the launcher)
+    const size_t n = (size_t)NB * Cout * 32, i = ((size_t)nb * Cout + o0 + (tid >> 5)) * 32 + (tid & 31);
+    float a = bias_a ? bias_a[o0 + (tid >> 5)] : 0.f;
+    for (int q = 0; q < ks_a; ++q) a += fa[(size_t)q * n + i];
+    float g = 0.f;
+    g += s;
+    pout[i] = resid[i] + (a > 0.f ? a : 0.f) * (1.0f / (1.0f + expf(-g)));
+    return;
+  }
   pout[((size_t)(ks * NB + nb) * Cout + o0 + (tid >> 5)) * 32 + (tid & 31)] = s;
 }
 
@@ -218,9 +233,27 @@ int lion_skinny_gemm(const float *pin, int ks_in, const float *bias_in, int act_
   if (Cout % 32 != 0) return LION_EUNSUPPORTED;
   const size_t lds = (size_t)16 * 1024 * 4;
   static LionLdsLimit cfg = {};
-  if (int e = lion_dynamic_lds(&skinny_gemm_kernel, lds, cfg)) return e;
-  skinny_gemm_kernel<<<dim3(Cout / 32, lion_skinny_splits(Cin, Cout), nb), 1024, lds, static_cast<hipStream_t>(stream)>>>(
-      pin, ks_in, bias_in, act_in, addT, wp, Cin, Cout, pout);
+  if (int e = lion_dynamic_lds(&skinny_gemm_kernel<false>, lds, cfg)) return e;
+  skinny_gemm_kernel<false><<<dim3(Cout / 32, lion_skinny_splits(Cin, Cout), nb), 1024, lds, static_cast<hipStream_t>(stream)>>>(
+      pin, ks_in, bias_in, act_in, addT, wp, Cin, Cout, pout, nullptr, 0, nullptr, nullptr);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// The block's last GEMM with its tail: y f32[nb][Cout][32] = resid + relu(sum_q A[q] + bias_a) * sigmoid(W act_in(sum pin + bias_in)),
+// A f32[ks_a][nb][Cout][32] (the block's conv2 partials), resid f32[nb][Cout][32].  == lion_skinny_gemm followed by
+// lion_skinny_finish(mode 1), bit for bit, in one launch; needs lion_skinny_splits(Cin, Cout) == 1 (LION_EUNSUPPORTED otherwise).
+int lion_skinny_gemm_se_finish(const float *pin, int ks_in, const float *bias_in, int act_in, const float *wp, int nb, int Cin,
+                               int Cout, const float *A, int ks_a, const float *bias_a, const float *resid, float *y,
+                               lionStream_t stream) {
+  if (!pin || !wp || !A || !resid || !y || nb <= 0 || Cin <= 0 || Cout <= 0 || ks_in < 1 || ks_a < 1 || act_in < 0 || act_in > 1)
+    return LION_EINVAL;
+  if (Cout % 32 != 0 || lion_skinny_splits(Cin, Cout) != 1) return LION_EUNSUPPORTED;
+  const size_t lds = (size_t)16 * 1024 * 4;
+  static LionLdsLimit cfg = {};
+  if (int e = lion_dynamic_lds(&skinny_gemm_kernel<true>, lds, cfg)) return e;
+  skinny_gemm_kernel<true><<<dim3(Cout / 32, 1, nb), 1024, lds, static_cast<hipStream_t>(stream)>>>(
+      pin, ks_in, bias_in, act_in, nullptr, wp, Cin, Cout, y, A, ks_a, bias_a, resid);
   LION_LAUNCH_CHECK();
   return 0;
 }

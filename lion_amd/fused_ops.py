@@ -661,6 +661,24 @@ def skinny_conv(pin, conv, bias_in=None, act_in=0, add=None):
     return out
 
 
+def skinny_conv_se_finish(pin, conv, A, bias_a, resid, act_in=1):
+    """the block's last GEMM (SE fc2) with the block's tail in its epilogue: resid + relu(sum A + bias_a) * sigmoid(conv.weight @
+    act_in(sum pin)) -- skinny_conv + skinny_finish in one launch (lion_skinny_gemm_se_finish); None when the layer needs k-splits."""
+    lib = _lib.load()
+    if pin.dim() == 3:
+        pin = pin.unsqueeze(0)
+    ks_in, nb, cin, _ = pin.shape
+    cout = conv.out_channels
+    if lib.lion_skinny_splits(cin, cout) != 1:
+        return None
+    wp = skinny_packed_weight(conv.weight)
+    y = torch.empty((nb, cout, 32), device=pin.device, dtype=torch.float32)
+    _lib.check(lib.lion_skinny_gemm_se_finish(_lib.ptr(pin), ks_in, None, int(act_in), _lib.ptr(wp), nb, cin, cout, _lib.ptr(A),
+                                              A.shape[0], _lib.ptr(bias_a), _lib.ptr(resid), _lib.ptr(y),
+                                              _lib.stream_ptr(pin.device)), "skinny_gemm_se_finish")
+    return y
+
+
 def skinny_finish(A, bias_a, Bp=None, resid=None):
     """[nb, C, 32] from partials: sum A + bias_a (Bp None) or resid + relu(sum A + bias_a) * sigmoid(sum Bp)."""
     ks_a, nb, c, _ = A.shape

@@ -163,7 +163,7 @@ class Prior(nn.Module):
                 and x.dim() == 4 and x.shape[2] == 1 and x.shape[3] == 1)
 
     def _forward_skinny(self, x, temb):
-        """4 launches per residual block instead of ~15 (channel-major [C, 32] activations throughout):
+        """4 launches per residual block (round 6; 5 before) instead of ~15 (channel-major [C, 32] activations throughout):
         h1 = relu(conv1(x + t)); h2 = relu(conv2(h1)); s = relu(fc1 h2); x = x + h2 * sigmoid(fc2 s)."""
         from ... import fused_ops as fo
         b = x.shape[0]
@@ -176,8 +176,11 @@ class Prior(nn.Module):
             p1 = fo.skinny_conv(h, blk.conv1, add=tt)                               # conv1(x + t)
             p2 = fo.skinny_conv(p1, blk.conv2, bias_in=bias(blk.conv1), act_in=1)   # conv2(relu(. + b1))
             p3 = fo.skinny_conv(p2, blk.SE.fc[0], bias_in=bias(blk.conv2), act_in=1)  # fc1(h2), h2 = relu(. + b2)
-            p4 = fo.skinny_conv(p3, blk.SE.fc[2], act_in=1)                         # fc2(relu(.))
-            h = fo.skinny_finish(p2, bias(blk.conv2), p4, h)                        # x + h2 * sigmoid(.)
+            hn = fo.skinny_conv_se_finish(p3, blk.SE.fc[2], p2, bias(blk.conv2), h)   # fc2(relu(.)) + the tail, one launch
+            if hn is None:
+                p4 = fo.skinny_conv(p3, blk.SE.fc[2], act_in=1)                     # fc2(relu(.))
+                hn = fo.skinny_finish(p2, bias(blk.conv2), p4, h)                   # x + h2 * sigmoid(.)
+            h = hn
         out = fo.skinny_finish(fo.skinny_conv(h, self.output_layer), bias(self.output_layer))
         return fo.from_channel_major(out, b)
 

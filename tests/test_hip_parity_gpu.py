@@ -1113,3 +1113,22 @@ def test_channel_major_transposes_equal_the_torch_formulation(B, C, Ct, bcast):
     with torch.enable_grad():     # the torch formulation under autograd: same values
         ox2, ot2 = fo.to_channel_major_pair(x, t)
     assert torch.equal(ox2, ox) and torch.equal(ot2, ot)
+
+
+@pytest.mark.parametrize("nb_b,C", [(32, 2048), (5, 256)])
+def test_skinny_se_finish_equals_gemm_then_finish(nb_b, C):
+    """lion_skinny_gemm_se_finish (round 6: the block's second squeeze-excite GEMM with the block's tail in its epilogue) ==
+    lion_skinny_gemm + lion_skinny_finish(mode 1), bit for bit"""
+    from lion_amd import fused_ops as fo
+    torch.manual_seed(C + nb_b)
+    H = C // 8
+    fc2 = torch.nn.Conv2d(H, C, 1, bias=False).cuda()
+    nb = (nb_b + 31) // 32
+    p3 = torch.randn(2, nb, H, 32, device="cuda")            # fc1's raw partials (two k-splits)
+    p2 = torch.randn(4, nb, C, 32, device="cuda")            # conv2's raw partials
+    b2 = torch.randn(C, device="cuda")
+    h = torch.randn(nb, C, 32, device="cuda")
+    with torch.no_grad():
+        ref = fo.skinny_finish(p2, b2, fo.skinny_conv(p3, fc2, act_in=1), h)
+        got = fo.skinny_conv_se_finish(p3, fc2, p2, b2, h)
+    assert got is not None and torch.equal(got, ref)
