@@ -140,11 +140,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(const float *__res
 // Forward and data gradient moved to fp16 x 2 split operands in round 2 (csrc/conv3d_split.hip); the weight gradient stayed
 // on v_mfma_f32_32x32x2_f32 (0.67 of the 157 TF fp32 peak: 29 % of a VAE training step).  Here both operands are cut into
 // fp16 pieces IN REGISTERS, from the same fp32 LDS tiles, right in front of v_mfma_f32_32x32x16_f16 (16 voxels per MFMA):
-//   g = g_h + g_l,  x = x_h + x_l  (after one power-of-two scale per TENSOR: max |.| * 2^e in [2^13, 2^14)),
+//   g = g_h + g_l,  x = x_h + x_l  (after a power-of-two block scale: per TENSOR until round 5, a running per-WORKGROUP scale
+//   found inside the kernel since round 6 -- see the kernel),
 //   acc += g_h x_h + g_h x_l + g_l x_h        (the dropped g_l x_l is 2^-22 relative)
 // -- 3 MFMAs of 32 cycles per 16 voxels and column block instead of 8 of 64.  Differences to the forward's split: (i) ONE
-// scale per tensor, not per tile -- the result is a sum over ~10^6 voxels, an element 2^-17 below the tensor's maximum
-// loses low bits that are 2^-39 of the largest term; (ii) the low pieces are NOT scaled up by 2048 (they are normal fp16
+// running scale per workgroup and operand (round 6; one per tensor before), not per tile and chunk -- the result is a sum over
+// ~10^6 voxels, an element 2^-17 below the running maximum loses low bits that are 2^-39 of the largest term; (ii) the low pieces are NOT scaled up by 2048 (they are normal fp16
 // down to 2^-3 of the scaled value, subnormal steps below are 2^-38 of the maximum), so main and correction products share
 // one accumulator: 112 accumulator registers, as the fp32 kernel.  A fragment = 8 consecutive voxels of a row (TW % 8 == 0):
 // gy rows at stride 260 floats (16-byte aligned, conflict-free b128 reads), x windows at the column's tap offset (dword reads).
@@ -181,39 +182,6 @@ __device__ __forceinline__ void cut2u(float a, float b, unsigned &hi2, unsigned 
   lo2 = __builtin_bit_cast(unsigned, l);
 }
 
-// max |v| over a tensor as bits (finite values only), one atomic per workgroup; out must be zeroed
-__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ p, size_t n, unsigned *__restrict__ out) {
-  __shared__ unsigned sm[4];
-  unsigned m = 0u;
-  const size_t n4 = n >> 2;
-  const float4 *p4 = reinterpret_cast<const float4 *>(p);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const float4 v = p4[i];
-    const unsigned a = __float_as_uint(v.x) & 0x7fffffffu, b = __float_as_uint(v.y) & 0x7fffffffu;
-    const unsigned c = __float_as_uint(v.z) & 0x7fffffffu, d = __float_as_uint(v.w) & 0x7fffffffu;
-    m = (a > m && a <= 0x7f7fffffu) ? a : m; m = (b > m && b <= 0x7f7fffffu) ? b : m;
-    m = (c > m && c <= 0x7f7fffffu) ? c : m; m = (d > m && d <= 0x7f7fffffu) ? d : m;
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    const unsigned a = __float_as_uint(p[(n4 << 2) + threadIdx.x]) & 0x7fffffffu;
-    m = (a > m && a <= 0x7f7fffffu) ? a : m;
-  }
-  for (int s = 32; s > 0; s >>= 1) { const unsigned o = __shfl_xor(m, s, 64); m = o > m ? o : m; }
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k) m = sm[k] > m ? sm[k] : m;
-    if (m) atomicMax(out, m);
-  }
-}
-// sc[0..1]: max bits of x, gy  ->  sc[2] = 2^ex, sc[3] = 2^eg, sc[4] = 2^-ex, sc[5] = 2^-eg
-__global__ void wgrad_scales_kernel(float *__restrict__ sc) {
-  const unsigned *u = reinterpret_cast<const unsigned *>(sc);
-  const float mx = __uint_as_float(u[0]), mg = __uint_as_float(u[1]);
-  const int ex = mx > 0.f ? scale_exp(mx) : 0, eg = mg > 0.f ? scale_exp(mg) : 0;
-  sc[2] = pow2f(ex); sc[3] = pow2f(eg); sc[4] = pow2f(-ex); sc[5] = pow2f(-eg);
-}
-
 template <int TD, int TH, int TW, int CIT>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                     int Cin, int Cout, int r, int TS, int units,
@@ -243,7 +211,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
   const int r2 = r * r, r3 = r2 * r;
   const int ntw = r / TW, nth = r / TH, ntiles = (r / TD) * nth * ntw;
   const int cl = lane & 31, kh = lane >> 5;
-  const float sxs = sc[2], sgs = sc[3];
 
   int cofs[NB];
 #pragma unroll
@@ -288,6 +255,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
         rx[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, c * r3 * 4, 0));
     }
   };
+  // Round 6 -- the block scales are found IN the kernel.  Until now two extra passes over x and gy (absmax_kernel, 26 us each
+  // at 268 MB, + a scales kernel and a memset: 3.1 ms of a VAE training step) fixed one power-of-two scale per TENSOR.  A
+  // workgroup now keeps running scales 2^Ex, 2^Eg (max |tile| * 2^E in [2^13, 2^14) when chosen, only ever lowered -- the
+  // forward kernel's monotone scheme): the maxima of the tile in registers are combined through two LDS words in front of the
+  // barrier that was there anyway; when a later tile raises a maximum the accumulators are multiplied by the exact power-of-two
+  // ratio first.  Finer than one scale per tensor (every product carries >= 22 bits relative to the largest operand the
+  // WORKGROUP has seen), deterministic (no cross-workgroup state), and no launch besides the kernel and its reduction.
+  __shared__ unsigned s_m[2][2];   // [parity][x, gy] bits of the tile's max |.| (finite values)
+  int Ex = 127, Eg = 127;          // 127 = not chosen yet (scale 1)
+  float sxs = 1.f, sgs = 1.f;
+  if (tid < 4) s_m[tid >> 1][tid & 1] = 0u;
+  auto tile_max = [&](int par) {   // this thread's staged registers -> s_m[par]
+    // v_max_f32 with the |.| source modifier: one instruction per staged value (max ignores NaN operands; an infinite maximum
+    // is not taken as a scale, below)
+    float fg = 0.f, fx = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) fg = fmaxf(fg, fabsf(rgy[c]));
+#pragma unroll
+    for (int i = 0; i < NXI; ++i)
+#pragma unroll
+      for (int c = 0; c < CIT; ++c) fx = fmaxf(fx, fabsf(rx[i][c]));
+    unsigned mg = __float_as_uint(fg), mx = __float_as_uint(fx);
+    mg = mg <= 0x7f7fffffu ? mg : 0u;
+    mx = mx <= 0x7f7fffffu ? mx : 0u;
+    mg = wave_max_u32_lane63(mg);
+    mx = wave_max_u32_lane63(mx);
+    if (lane == 63) { if (mx) atomicMax(&s_m[par][0], mx); if (mg) atomicMax(&s_m[par][1], mg); }
+  };
   auto store_tile = [&]() { // scaled and cut (two channels per conversion)
 #pragma unroll
     for (int c = 0; c < 32; c += 2) {
@@ -312,9 +307,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
     }
   };
   if (ts < ntiles) load_tile(ts);
-  for (int t = ts; t < ntiles; t += TS) {
-    __syncthreads();
+  __syncthreads();                 // s_m zeroed
+  int par = 0;
+  for (int t = ts; t < ntiles; t += TS, par ^= 1) {
+    tile_max(par);
+    __syncthreads();               // the tile's maxima are complete; the previous tile's LDS reads are done
+    {
+      const unsigned bx = s_m[par][0], bg = s_m[par][1];
+      float f = 1.f;               // what the accumulated sums have to be multiplied by (<= 1, exact)
+      if (bx) { const int e = scale_exp(__uint_as_float(bx)); if (e < Ex) { if (Ex != 127) f *= pow2f(max(e - Ex, -126)); Ex = e; sxs = pow2f(e); } }
+      if (bg) { const int e = scale_exp(__uint_as_float(bg)); if (e < Eg) { if (Eg != 127) f *= pow2f(max(e - Eg, -126)); Eg = e; sgs = pow2f(e); } }
+      if (f != 1.f) {              // (uniform over the workgroup; rare: a later tile raised a maximum)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[nb][i] *= f;
+      }
+    }
     store_tile();
+    if (tid < 2) s_m[par ^ 1][tid] = 0u;   // the other parity: its last readers passed the barrier above
     __syncthreads();
     if (t + TS < ntiles) load_tile(t + TS);
     // 4 k-steps of 16 voxels over this wave's 64 voxels; a lane's fragment = voxels v0 .. v0 + 7 of one row
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
     }
   }
   // waves -> one partial per workgroup, unscaled (two exact power-of-two factors: their product may leave fp32's range)
-  const float ux = sc[4], ug = sc[5];
+  const float ux = Ex == 127 ? 1.f : pow2f(-Ex), ug = Eg == 127 ? 1.f : pow2f(-Eg);
   float *pt = partial + (size_t)part * Cout * Cin * 27;
   float *red = smem; // [4 waves][16][64]
 #pragma unroll
@@ -465,13 +476,7 @@ int lion_conv3d_k3_wgrad_split(const float *x, const float *gy, int B, int Cin, 
   if (((((uintptr_t)x) | ((uintptr_t)gy)) & 15) != 0) return LION_EUNSUPPORTED;
   const int TS = wgrad_splits(B, Cin, Cout, r);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t nparts = (size_t)B * TS * Cout * Cin * 27;
-  float *sc = ws + nparts;
-  if (hipMemsetAsync(sc, 0, 8, st) != hipSuccess) return LION_EINVAL;
-  const size_t nx = (size_t)B * Cin * r * r * r, ng = (size_t)B * Cout * r * r * r;
-  absmax_kernel<<<1024, 256, 0, st>>>(x, nx, reinterpret_cast<unsigned *>(sc));
-  absmax_kernel<<<1024, 256, 0, st>>>(gy, ng, reinterpret_cast<unsigned *>(sc) + 1);
-  wgrad_scales_kernel<<<1, 1, 0, st>>>(sc);
+  const float *sc = nullptr;   // (round 6: the block scales are found inside the kernel; no absmax passes)
   int rc;
   if (r == 32) rc = launch_wgrad_split<2, 4, 32, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
   else if (r == 16) rc = launch_wgrad_split<4, 4, 16, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
