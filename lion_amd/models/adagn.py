@@ -15,12 +15,20 @@ from .. import _wcache
 # layer (75 launches per denoiser step in the released local prior); AdaGN.affine then returns
 # strided views into that result.  Nothing is cached across forward passes.
 _ACTIVE = None  # (style tensor, {id(module): (factor view, bias view)})
+# Round 6 -- the same batching under autograd (training): one cat of the projection weights, ONE Linear and one split per forward
+# instead of a Linear per AdaGN; backward = one cat of the slice gradients + the Linear's two GEMMs + narrow views onto the
+# parameters' gradients, instead of (2 GEMMs + a bias sum + an accumulation into the style gradient) x ~140 layers per VAE step.
+# Only modules that were actually CALLED in an earlier forward of this root are batched (an unused module must keep grad = None,
+# as in the reference): the first training forward runs unbatched and records them.  LION_TRAIN_STYLE_PLAN=0 switches it off.
+TRAIN_BATCHED = __import__("os").environ.get("LION_TRAIN_STYLE_PLAN", "1") != "0"
+_RECORD = None  # set of module ids that called affine() during a recording forward
 
 
 class StylePlan:
     def __init__(self, root):
         self.mods = [m for m in root.modules() if isinstance(m, AdaGN)]
         self._key, self._w, self._b = None, None, None
+        self._used = None      # ids of the modules a training forward of this root calls (recorded by the first one)
 
     def _weights(self):
         key = (_wcache.generation(),) + tuple((m.emd.weight.data_ptr(), m.emd.weight._version, m.emd.bias._version)
@@ -34,10 +42,35 @@ class StylePlan:
     @contextlib.contextmanager
     def projected(self, style):
         """all AdaGN.affine(style) calls inside the block are served from one GEMM."""
-        global _ACTIVE
-        if (not self.mods or torch.is_grad_enabled() or style.dim() != 2
-                or any(m.style_dim != style.shape[1] for m in self.mods)):
+        global _ACTIVE, _RECORD
+        if not self.mods or style.dim() != 2 or any(m.style_dim != style.shape[1] for m in self.mods):
             yield
+            return
+        if torch.is_grad_enabled():
+            if not TRAIN_BATCHED:
+                yield
+                return
+            if self._used is None:          # first training forward: plain per-layer projections, recording who asks
+                prev_r, _RECORD = _RECORD, set()
+                try:
+                    yield
+                finally:
+                    self._used, _RECORD = _RECORD, prev_r
+                return
+            mods = [m for m in self.mods if id(m) in self._used]
+            if not mods:
+                yield
+                return
+            w = torch.cat([m.emd.weight for m in mods], 0)
+            b = torch.cat([m.emd.bias for m in mods], 0)
+            e = torch.nn.functional.linear(style, w, b)
+            parts = torch.split(e, [2 * m.n_channel for m in mods], dim=1)
+            views = {id(m): tuple(p_.chunk(2, 1)) for m, p_ in zip(mods, parts)}
+            prev, _ACTIVE = _ACTIVE, (style, views)
+            try:
+                yield
+            finally:
+                _ACTIVE = prev
             return
         w, b = self._weights()
         from .. import fused_ops
@@ -79,6 +112,8 @@ class AdaGN(nn.Module):
             hit = _ACTIVE[1].get(id(self))
             if hit is not None:
                 return hit
+        if _RECORD is not None:
+            _RECORD.add(id(self))
         return self.emd(style).chunk(2, 1)
 
     def forward(self, image, style):
