@@ -450,6 +450,8 @@ int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, 
 int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
                            const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
                            float *dbias, float *pw, lionStream_t stream);
+/* d GroupNorm weight / bias f32[C] = the per-sample terms pw f32[B,C,2] of lion_gn_train_bwd_fold summed over the batch (ascending b) */
+int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, lionStream_t stream);
 int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
                     lionStream_t stream);
 int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,

@@ -129,6 +129,22 @@ __global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *
   }
 }
 
+// dgw[c] = sum_b pw[b][c][0], dgb[c] = sum_b pw[b][c][1] in ascending b (what pw.sum(0) + two strided copies did in three ATen
+// launches per AdaGN layer and backward)
+__global__ __launch_bounds__(256) void pw_batch_sum_kernel(const float *__restrict__ pw, int B, int C, float *__restrict__ dgw,
+                                                           float *__restrict__ dgb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float2 v = *reinterpret_cast<const float2 *>(pw + ((size_t)b * C + c) * 2);
+    s0 += v.x;
+    s1 += v.y;
+  }
+  dgw[c] = s0;
+  dgb[c] = s1;
+}
+
 // ---- round 6: y[row][m] = max_u act(A x[row][m][u] + Bs) -- the set-abstraction pooling behind the last AdaGN + Swish of a
 // grouped SharedMLP (reference models/pvcnn2_ada.py:375-377) as ONE differentiable op.  The activated [B,C,M,U] tensor is never
 // written (forward) and its gradient -- zero except at each group's arg-max -- never materialised (backward): every pass
@@ -390,5 +406,12 @@ int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *
   return 0;
 }
 #undef LION_AAM_DISPATCH
+
+int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, lionStream_t stream) {
+  if (!pw || !dgw || !dgb || B <= 0 || C <= 0) return LION_EINVAL;
+  pw_batch_sum_kernel<<<lion_cdiv(C, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(pw, B, C, dgw, dgb);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
 
 } // extern "C"

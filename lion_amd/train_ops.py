@@ -53,6 +53,17 @@ def _rowview(t, B, C):
     return t, int(t.stride(0))
 
 
+def _param_grads(pw, want_w, want_b):
+    """pw [B, C, 2] (per-sample terms of the GroupNorm weight / bias gradients) -> (d weight [C], d bias [C]) in one launch"""
+    if not (want_w or want_b):
+        return None, None
+    B, C = pw.shape[:2]
+    dgw, dgb = torch.empty(C, device=pw.device, dtype=torch.float32), torch.empty(C, device=pw.device, dtype=torch.float32)
+    _lib.check(_lib.load().lion_gn_train_param_grads(_lib.ptr(pw), B, C, _lib.ptr(dgw), _lib.ptr(dgb),
+                                                     _lib.stream_ptr(pw.device)), "gn_train_param_grads")
+    return (dgw if want_w else None), (dgb if want_b else None)
+
+
 class _AdaGNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gw, gb, factor, bias, groups, eps, act):
@@ -104,9 +115,7 @@ class _AdaGNAct(torch.autograd.Function):
             dx = torch.empty_like(x)
             _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
                                                      _lib.ptr(R), B * C, L, act, _lib.ptr(dx), st), "affine_act_bwd_apply")
-        dpw = pw.sum(0)                                                       # [C, 2]: d norm.weight, d norm.bias
-        dgw = dpw[:, 0].contiguous() if ctx.needs_input_grad[1] else None
-        dgb = dpw[:, 1].contiguous() if ctx.needs_input_grad[2] else None
+        dgw, dgb = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2])   # d norm.weight, d norm.bias
         def back(g, shape):   # the gradient of a broadcast factor: summed over exactly the dimensions it was spread over
             shape = tuple(int(d) for d in shape)
             core = shape
@@ -176,9 +185,7 @@ class _AdaGNActMax(torch.autograd.Function):
             _lib.check(lib.lion_affine_act_max_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
                                                          _lib.ptr(R), B * C, M, U, act, _lib.ptr(dx), st),
                        "affine_act_max_bwd_apply")
-        dpw = pw.sum(0)
-        dgw = dpw[:, 0].contiguous() if ctx.needs_input_grad[1] else None
-        dgb = dpw[:, 1].contiguous() if ctx.needs_input_grad[2] else None
+        dgw, dgb = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2])   # d norm.weight, d norm.bias
 
         def back(g, shape):
             shape = tuple(int(d) for d in shape)
