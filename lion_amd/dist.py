@@ -5,12 +5,15 @@ The reference flattens ALL gradients into one buffer AFTER backward has finished
 single all-reduce (no overlap, two extra full copies).  On an MI355X node every GPU has 7
 point-to-point xGMI links, and a ring all-reduce of the 354 MB prior gradient is bound by one link
 (~4 ms).  ``BucketedGradAverager`` instead:
-  * packs parameters, in REVERSE registration order (the order backward produces gradients),
-    into ~32 MiB flat buckets whose storage the ``.grad`` tensors alias (no copy in, no copy out);
-  * launches each bucket's all-reduce from a side HIP stream as soon as its last gradient has been
-    accumulated (``register_post_accumulate_grad_hook``), so communication overlaps the rest of the
-    PVCNN backward;
-  * pre-divides by the world size like the reference (:734-738) so the result is the mean.
+  * starts every step with ``grad = None`` (``zero_grad``): autograd then hands each parameter the gradient tensor its
+    backward node produced, as it is -- no zero-fill of the gradients and no ``grad += new`` kernel per parameter (867
+    tiny launches per VAE step, ~4 ms of an 89 ms step, when ``.grad`` pre-exists);
+  * packs parameters, in REVERSE registration order (the order backward produces gradients), into ~32 MiB flat
+    buckets; as soon as the last gradient of a bucket has landed (``register_post_accumulate_grad_hook``) ONE
+    multi-tensor copy moves the bucket's gradients into the flat buffer, ``.grad`` is pointed at the views, and the
+    bucket's all-reduce is launched from a side HIP stream, so communication overlaps the rest of the PVCNN backward;
+  * pre-divides by the world size like the reference (:734-738) so the result is the mean;
+  * at world size 1 has nothing to move: no flat buffers are allocated and ``.grad`` stays what autograd produced.
 ``finish()`` (call before ``optimizer.step``) waits for the outstanding buckets.
 Works with any ``torch.distributed`` backend ('nccl' is RCCL on ROCm; the CPU tests use 'gloo').
 """
@@ -110,11 +113,10 @@ class BucketedGradAverager:
 
     def _make_bucket(self, plist):
         n = sum(p.numel() for p in plist)
-        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device) if self.world > 1 else None
         off = 0
         for p in plist:
-            self._view_of[p] = flat[off:off + p.numel()].view_as(p)
-            p.grad = self._view_of[p]  # .grad aliases the bucket: no pack/unpack copies
+            self._view_of[p] = flat[off:off + p.numel()].view_as(p) if flat is not None else None
             off += p.numel()
             self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(plist)))
@@ -124,6 +126,36 @@ class BucketedGradAverager:
         self._works = []
         self._seen = set()
         self._launched = set()
+
+    def _bind(self, i):
+        """move the gradients bucket i's parameters hold into its flat buffer (one multi-tensor copy) and point ``.grad``
+        at the views; gradients already living there (a caller that kept ``.grad`` and zeroed it in place) are left alone.
+        Parameters without a gradient keep ``grad = None``; their slice of the buffer is reduced with whatever it held
+        and never read."""
+        flat, plist = self.buckets[i]
+        if flat is None:
+            return
+        src, dst, who = [], [], []
+        for p in plist:
+            g, view = p.grad, self._view_of[p]
+            if g is None or g.data_ptr() == view.data_ptr():
+                continue
+            src.append(g.detach())
+            dst.append(view)
+            who.append(p)
+        if not who:
+            return
+        with torch.no_grad():
+            torch._foreach_copy_(dst, src)
+        for p in who:
+            p.grad = self._view_of[p]
+
+    def bind_all(self):
+        """every gradient produced so far into its bucket -- the tail of a captured [forward + backward] graph whose
+        collectives run eagerly behind it (GraphedTrainStep's split mode): a bucket with a parameter that got no gradient
+        never completes inside the hooks"""
+        for i in range(len(self.buckets)):
+            self._bind(i)
 
     def _launch(self, i):
         flat, _ = self.buckets[i]
@@ -140,68 +172,41 @@ class BucketedGradAverager:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         self._works.append(work)
 
-    def _realias(self, p):
-        """`p.grad` must live inside its bucket.  ``zero_grad(set_to_none=True)`` (torch.optim's default) or a
-        ``p.grad = ...`` assignment breaks the aliasing: autograd then accumulates into a fresh tensor while the
-        bucket that gets all-reduced stays zero and the ranks silently diverge.  Heal it: move the gradient into
-        the bucket and point ``.grad`` back at the view."""
-        view = self._view_of[p]
-        g = p.grad
-        if g is None or g.data_ptr() == view.data_ptr():
-            return
-        view.copy_(g)
-        p.grad = view
-
     def _on_grad(self, p):
         i = self._bucket_of[p]
         if p in self._seen:
             raise RuntimeError("BucketedGradAverager: a parameter received a second gradient before finish(); "
                                "two backward passes per step (gradient accumulation) need overlap=False")
         self._seen.add(p)
-        self._realias(p)
         self._pending[i] -= 1
-        if self._pending[i] == 0 and self.launch_in_hooks:
-            self._launch(i)
+        if self._pending[i] == 0:
+            self._bind(i)
+            if self.launch_in_hooks:
+                self._launch(i)
 
     def zero_grad(self):
-        """zero the buckets and (re-)attach every ``.grad`` to its bucket view (parameters that got no gradient
-        in the previous step were detached by ``finish``; a foreign ``zero_grad(set_to_none=True)`` detaches all)."""
-        for flat, _ in self.buckets:
-            flat.zero_()
-        for p, view in self._view_of.items():
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                p.grad = view
+        """``grad = None`` for every parameter: the backward's own gradient tensors are adopted as they are (module
+        docstring) -- nothing to zero, nothing to accumulate into."""
+        for p in self.params:
+            p.grad = None
 
     def finish(self):
         """Wait for (or, without overlap, perform) the averaging of every bucket.  Afterwards parameters that
         received no gradient in this step have ``grad = None``, like in the reference, whose averaging and
-        optimizers skip them (utils/utils.py:725-727): Adam / EMA must not step them with zeros."""
-        if not self.overlap:  # no hooks: find out who got a gradient, heal broken aliasing
-            for p, view in self._view_of.items():
-                g = p.grad
-                if g is None:
-                    continue
-                if g.data_ptr() != view.data_ptr():
-                    self._realias(p)
-                    self._seen.add(p)
-            touched = None    # without hooks "received a gradient" cannot be told from "stayed zero"
-        else:
-            touched = self._seen
+        optimizers skip them (utils/utils.py:725-727): Adam / EMA must not step them with zeros; at world size > 1
+        every other ``.grad`` is a view of its bucket."""
         if self.world > 1:
-            if not self.overlap:
-                for i in range(len(self.buckets)):
+            for i in range(len(self.buckets)):
+                if i not in self._launched:   # no hooks, hooks told not to launch, or a parameter of the bucket got no gradient
+                    self._bind(i)
                     self._launch(i)
-            else:  # parameters that received no gradient this step leave their bucket pending
-                for i in range(len(self.buckets)):
-                    if i not in self._launched:
-                        self._launch(i)
             for w in self._works:
                 w.wait()
             if self._stream is not None:
                 torch.cuda.current_stream().wait_stream(self._stream)
-        if touched is not None:
+        if self.overlap:   # a caller that kept .grad alive across steps (foreign zero_grad(set_to_none=False)): drop the untouched
             for p in self.params:
-                if p not in touched:
+                if p not in self._seen:
                     p.grad = None
         self._reset()
 

@@ -27,7 +27,7 @@ def _zero(optimizer, averager):
     if averager is not None:
         averager.zero_grad()
     else:
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad(set_to_none=True)   # autograd adopts the backward's gradient tensors: no fill, no accumulate kernels
 
 
 def vae_forward_backward(vae, optimizer, x, step=0, averager=None, noisy_input=None, kl_weight=None):
@@ -264,6 +264,8 @@ class GraphedTrainStep:
         def fb():
             loss, aux = self.fb(**self.inputs)
             self.loss, self.aux = loss.detach(), _detached(aux)
+            if self.avg is not None:
+                self.avg.bind_all()   # the copies into the buckets belong to the replayed graph, not to the eager finish() below
         self._side_run(dev, lambda: (fb(), self._update()))
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):

@@ -292,3 +292,71 @@ def test_graphed_train_step_rewinds_module_buffers_too():
     st(x=x)
     torch.cuda.synchronize()
     assert float(net.calls) == 2.0
+
+
+def _w_split_world2(rank, world, port):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lion_amd.dist import BucketedGradAverager, average_gradients
+        from lion_amd.training import GraphedTrainStep
+        torch.cuda.set_device(0)
+
+        def make():
+            torch.manual_seed(3)
+            net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4)).cuda()
+            unused = torch.nn.Parameter(torch.ones(7, device="cuda"))      # its bucket never completes inside the hooks
+            return net, unused, list(net.parameters()) + [unused]
+        gen = torch.Generator(device="cuda").manual_seed(50 + rank)       # every rank its own batches
+        xs = [torch.randn(32, 16, device="cuda", generator=gen) for _ in range(6)]
+        ys = [torch.randn(32, 4, device="cuda", generator=gen) for _ in range(6)]
+        # the reference trainer's step (utils.average_gradients after the backward), eager
+        net_r, _, params_r = make()
+        opt_r = torch.optim.Adam(params_r, lr=1e-2)
+        for i in range(1, 6):
+            opt_r.zero_grad()
+            ((net_r(xs[i]) - ys[i]) ** 2).mean().backward()
+            average_gradients(params_r, True)
+            opt_r.step()
+        # the captured step: [forward + backward + copies into the buckets] graph -> eager gloo all-reduce -> [optimizer] graph
+        net, unused, params = make()
+        opt = torch.optim.Adam(params, lr=1e-2, capturable=True)
+        avg = BucketedGradAverager(params, bucket_bytes=512)
+        assert len(avg.buckets) >= 2 and all(flat is not None for flat, _ in avg.buckets)
+
+        def fb(x, y):
+            avg.zero_grad()
+            loss = ((net(x) - y) ** 2).mean()
+            loss.backward()
+            return loss.detach(), None
+        st = GraphedTrainStep(fb, {"x": xs[0].clone(), "y": ys[0].clone()}, params, opt, avg)
+        assert st.mode == "split" and len(st._graphs) == 2, st.launch
+        for i in range(1, 6):
+            st(x=xs[i], y=ys[i])
+        torch.cuda.synchronize()
+        assert unused.grad is None
+        for p in net.parameters():                                         # after the step .grad is a view of its bucket
+            assert p.grad.data_ptr() == avg._view_of[p].data_ptr()
+        for p, q in zip(net.parameters(), net_r.parameters()):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-6)
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])                               # the ranks stay in lock-step, bit for bit
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graphed_train_step_split_mode_two_ranks_gloo():
+    """world size 2 over gloo, both ranks on this GPU: the copies that move the backward's gradient tensors into the flat
+    buckets must be part of the replayed [forward + backward] graph (lion_amd/dist.py::bind_all), including for a bucket
+    holding a parameter that never receives a gradient; the result equals the reference's average_gradients step."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_w_split_world2, args=(2, port), nprocs=2, join=True)
