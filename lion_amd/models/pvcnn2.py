@@ -13,6 +13,33 @@ from ..conv_ops import conv3d_module
 from .pvcnn2_ada import BallQuery, LinearAttention, SE3d, Swish, Voxelization
 
 
+def run_layers(layers, x, reduce_max=False):
+    """the walk over a [conv, GroupNorm, Swish, Dropout, ..., SE3d] layer list.  With gradients enabled on the GPU a GroupNorm
+    (and the Swish behind it, when there is one) is ONE differentiable op on the library's kernels, as in the adaptive
+    blocks (pvcnn2_ada.run_layers; lion_amd/train_ops.py with factor = bias = None), SE3d is train_ops.se3d, and a list that
+    ends in GroupNorm + Swish on [B, C, M, U] can take the SA modules' max over the neighbours into the same op
+    (reduce_max).  ATen runs each GroupNorm + Swish of the style encoder as 4 launches forward and 9 backward."""
+    from .. import train_ops
+    i, n = 0, len(layers)
+    while i < n:
+        layer = layers[i]
+        if isinstance(layer, nn.GroupNorm) and train_ops.usable(x) and layer.num_channels <= 1024 and layer.affine:
+            fused_act = i + 1 < n and isinstance(layers[i + 1], Swish)
+            if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x):
+                return train_ops.adagn_act_max(x, layer, None, None, act=fused_act)   # pooled: [B, C, M]
+            x = train_ops.adagn_act(x, layer, None, None, act=fused_act)
+            i += 2 if fused_act else 1
+            continue
+        if isinstance(layer, nn.Conv3d):
+            x = conv3d_module(layer, x)
+        elif isinstance(layer, SE3d) and train_ops.se3d_trainable(layer, x):
+            x = train_ops.se3d(layer, x)
+        else:
+            x = layer(x)
+        i += 1
+    return x.max(dim=-1).values if reduce_max else x
+
+
 class SharedMLP(nn.Module):
     def __init__(self, in_channels, out_channels, dim=1):
         super().__init__()
@@ -25,10 +52,10 @@ class SharedMLP(nn.Module):
             in_channels = oc
         self.layers = nn.Sequential(*layers)
 
-    def forward(self, inputs):
+    def forward(self, inputs, reduce_max=False):
         if isinstance(inputs, (list, tuple)):
-            return (self.layers(inputs[0]), *inputs[1:])
-        return self.layers(inputs)
+            return (run_layers(self.layers, inputs[0], reduce_max), *inputs[1:])
+        return run_layers(self.layers, inputs, reduce_max)
 
 
 class PVConv(nn.Module):
@@ -59,8 +86,7 @@ class PVConv(nn.Module):
         assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2]
         assert coords.shape[1] == 3, f'expect coords: B,3,Npoint, get: {coords.shape}'
         grid, voxel_coords = self.voxelization(features, coords)
-        for layer in self.voxel_layers:
-            grid = conv3d_module(layer, grid) if isinstance(layer, nn.Conv3d) else layer(grid)
+        grid = run_layers(self.voxel_layers, grid)
         fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
         if self.add_point_feat:
             fused = fused + self.point_features(features)
@@ -101,7 +127,7 @@ class PointNetSAModule(nn.Module):
         centers_coords = F.furthest_point_sample(coords, self.num_centers)
         if time_emb is not None and type(time_emb) is not dict:
             time_emb = time_emb[:, :, :centers_coords.shape[-1]]
-        pooled = [mlp(grouper(coords, centers_coords, features)).max(dim=-1).values
+        pooled = [mlp(grouper(coords, centers_coords, features), reduce_max=True)   # max over the neighbours (reference :322)
                   for grouper, mlp in zip(self.groupers, self.mlps)]
         return (torch.cat(pooled, dim=1) if len(pooled) > 1 else pooled[0]), centers_coords, time_emb
 

@@ -40,6 +40,12 @@ for e in prof.events():
     for fr in (e.stack or []):
         if "lion_amd/" in fr and "torch/" not in fr:
             site = fr.split("lion_amd/")[-1].strip(); break
+    if site == "?":   # launched by the autograd engine: name the backward node instead
+        par = e.cpu_parent
+        while par is not None:
+            if par.name.startswith("autograd::engine::evaluate_function: "):
+                site = "backward of " + par.name.split(": ", 1)[1]; break
+            par = par.cpu_parent
     k = (site[:70], e.name)
     agg[k][0] += 1; agg[k][1] += dt; tot_n += 1; tot_t += dt
 print(f"aten ops with device time: {tot_n} calls, {tot_t/1e3:.1f} ms")
