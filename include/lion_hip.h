@@ -452,6 +452,16 @@ int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd,
                            float *dbias, float *pw, lionStream_t stream);
 /* d GroupNorm weight / bias f32[C] = the per-sample terms pw f32[B,C,2] of lion_gn_train_bwd_fold summed over the batch (ascending b) */
 int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, lionStream_t stream);
+/* TRAINING, SE3d gate (reference models/pvcnn2_ada.py:27-41: x * sigmoid(W2 relu(W1 mean_voxels(x))), both Linear layers bias-free):
+ * the [B, C] algebra between the row-sum pass (lion_row_stats) and the scaling pass (lion_affine_act with A = g, Bs = zero).
+ * fwd: stats f32[B*C,2] (column 0 = row sums over the L voxels), w1 f32[Cr,C], w2 f32[C,Cr] -> mean f32[B,C], h f32[B,Cr] (after the
+ * ReLU), g f32[B,C] (after the sigmoid), zero f32[B,C] (zeros).  bwd: S f32[B*C,2] (column 1 = sum_voxels gy*x, from
+ * lion_affine_act_bwd_stats) -> dpre2 f32[B,C], dpre1 f32[B,Cr] (scratch outputs), Q f32[B,C] (per-voxel gradient through the mean,
+ * for lion_affine_act_bwd_apply), dw1 f32[Cr,C], dw2 f32[C,Cr] (summed over the batch in ascending order).  C <= 1024, Cr <= 128. */
+int lion_se_gate_fwd(const float *stats, const float *w1, const float *w2, int B, int C, int Cr, int L, float *mean, float *h,
+                     float *g, float *zero, lionStream_t stream);
+int lion_se_gate_bwd(const float *S, const float *g, const float *h, const float *mean, const float *w1, const float *w2, int B,
+                     int C, int Cr, int L, float *dpre2, float *dpre1, float *Q, float *dw1, float *dw2, lionStream_t stream);
 int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
                     lionStream_t stream);
 int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,

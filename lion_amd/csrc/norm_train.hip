@@ -295,6 +295,107 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
 
 } // namespace
 
+// ---- SE3d gate (reference models/pvcnn2_ada.py:27-41: x * sigmoid(W2 relu(W1 mean_voxels(x)))) -- the [B, C] algebra between the
+// row-sum pass and the scaling pass, training form (round 6).  ATen ran it as ~7 tiny launches forward (div, mm, relu, mm,
+// sigmoid, two fills) and ~13 backward per SE layer, 28 layers per VAE step.  One block per sample; C <= 1024, Cr <= 128.
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float *__restrict__ stats, const float *__restrict__ w1,
+                                                          const float *__restrict__ w2, int C, int Cr, float L,
+                                                          float *__restrict__ mean, float *__restrict__ h,
+                                                          float *__restrict__ g, float *__restrict__ zero) {
+  __shared__ float m[1024], hh[128];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) {
+    const float v = stats[((size_t)b * C + c) * 2] / L;
+    m[c] = v;
+    mean[(size_t)b * C + c] = v;
+    zero[(size_t)b * C + c] = 0.f;
+  }
+  __syncthreads();
+  for (int j = wave; j < Cr; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(m[c], w1[(size_t)j * C + c], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const float r = fmaxf(acc, 0.f);
+      hh[j] = r;
+      h[(size_t)b * Cr + j] = r;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < Cr; ++j) acc = fmaf(hh[j], w2[(size_t)c * Cr + j], acc);
+    g[(size_t)b * C + c] = 1.f / (1.f + expf(-acc));
+  }
+}
+
+// backward, per sample: dpre2 = dg g (1 - g) with dg = sum_voxels gy x (S[:, 1] of the reduction pass);
+// dpre1 = (dpre2 W2) [h > 0];  Q = (dpre1 W1) / L (the gradient every voxel of a channel receives through the mean)
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restrict__ S, const float *__restrict__ g,
+                                                          const float *__restrict__ h, const float *__restrict__ w1,
+                                                          const float *__restrict__ w2, int C, int Cr, float L,
+                                                          float *__restrict__ dpre2, float *__restrict__ dpre1,
+                                                          float *__restrict__ Q) {
+  __shared__ float s2[1024], s1[128];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) {
+    const float gg = g[(size_t)b * C + c];
+    const float d = S[((size_t)b * C + c) * 2 + 1] * gg * (1.f - gg);
+    s2[c] = d;
+    dpre2[(size_t)b * C + c] = d;
+  }
+  __syncthreads();
+  for (int j = wave; j < Cr; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(s2[c], w2[(size_t)c * Cr + j], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const float r = h[(size_t)b * Cr + j] > 0.f ? acc : 0.f;
+      s1[j] = r;
+      dpre1[(size_t)b * Cr + j] = r;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < Cr; ++j) acc = fmaf(s1[j], w1[(size_t)j * C + c], acc);
+    Q[(size_t)b * C + c] = acc / L;
+  }
+}
+
+// weight gradients, summed over the batch in ascending order: dW2[c, j] = sum_b dpre2[b, c] h[b, j];  dW1[j, c] = sum_b dpre1[b, j] mean[b, c]
+__global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float *__restrict__ dpre2, const float *__restrict__ dpre1,
+                                                            const float *__restrict__ h, const float *__restrict__ mean, int B,
+                                                            int C, int Cr, float *__restrict__ dw1, float *__restrict__ dw2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * Cr) return;
+  const float *p, *q;   // out[i] = sum_b p[b * ps] * q[b * qs]
+  int ps, qs;
+  if (blockIdx.y == 0) {   // dW2 [C, Cr]
+    const int c = i / Cr, j = i - c * Cr;
+    p = dpre2 + c, ps = C, q = h + j, qs = Cr;
+  } else {                 // dW1 [Cr, C]
+    const int j = i / C, c = i - j * C;
+    p = dpre1 + j, ps = Cr, q = mean + c, qs = C;
+  }
+  float acc = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 8) {   // 16 loads in flight, summed in ascending b
+    float u[8], v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool in = b0 + k < B;
+      u[k] = in ? p[(size_t)(b0 + k) * ps] : 0.f;
+      v[k] = in ? q[(size_t)(b0 + k) * qs] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (b0 + k < B) acc = fmaf(u[k], v[k], acc);
+  }
+  (blockIdx.y == 0 ? dw2 : dw1)[i] = acc;
+}
+
 extern "C" {
 
 int lion_gn_train_fold(const float *stats, const float *gw, const float *gb, const float *fac, int fac_stride,
@@ -414,6 +515,28 @@ int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *
 int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, lionStream_t stream) {
   if (!pw || !dgw || !dgb || B <= 0 || C <= 0) return LION_EINVAL;
   pw_batch_sum_kernel<<<lion_cdiv(C, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(pw, B, C, dgw, dgb);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_se_gate_fwd(const float *stats, const float *w1, const float *w2, int B, int C, int Cr, int L, float *mean, float *h,
+                     float *g, float *zero, lionStream_t stream) {
+  if (!stats || !w1 || !w2 || !mean || !h || !g || !zero || B <= 0 || C <= 0 || Cr <= 0 || L <= 0) return LION_EINVAL;
+  if (C > 1024 || Cr > 128) return LION_EUNSUPPORTED;
+  se_gate_fwd_kernel<<<B, 256, 0, static_cast<hipStream_t>(stream)>>>(stats, w1, w2, C, Cr, (float)L, mean, h, g, zero);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_se_gate_bwd(const float *S, const float *g, const float *h, const float *mean, const float *w1, const float *w2, int B,
+                     int C, int Cr, int L, float *dpre2, float *dpre1, float *Q, float *dw1, float *dw2, lionStream_t stream) {
+  if (!S || !g || !h || !mean || !w1 || !w2 || !dpre2 || !dpre1 || !Q || !dw1 || !dw2 || B <= 0 || C <= 0 || Cr <= 0 || L <= 0)
+    return LION_EINVAL;
+  if (C > 1024 || Cr > 128) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  se_gate_bwd_kernel<<<B, 256, 0, st>>>(S, g, h, w1, w2, C, Cr, (float)L, dpre2, dpre1, Q);
+  LION_LAUNCH_CHECK();
+  se_gate_wgrad_kernel<<<dim3(lion_cdiv(C * Cr, 256), 2), 256, 0, st>>>(dpre2, dpre1, h, mean, B, C, Cr, dw1, dw2);
   LION_LAUNCH_CHECK();
   return 0;
 }

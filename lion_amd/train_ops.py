@@ -215,8 +215,8 @@ def adagn_act(x, norm, factor=None, bias=None, act=True):
 class _SE3d(torch.autograd.Function):
     """y = x * sigmoid(W2 relu(W1 mean_voxels(x))) -- SE3d (reference models/pvcnn2_ada.py:27-41) as ONE differentiable op:
     forward = row sums + one scaling pass; backward = one pass for sum_n gy x (the gate's gradient) + one fused apply
-    dx = gate gy + d mean / L; the [B, C] algebra of the two bias-free Linear layers is written out by hand (a few small
-    launches).  ATen runs the reference expression as three chained mean() reductions, a broadcast multiply, and in backward
+    dx = gate gy + d mean / L; the [B, C] algebra of the two bias-free Linear layers is csrc/norm_train.hip's se_gate kernels
+    (one launch forward, two backward).  ATen runs the reference expression as three chained mean() reductions, a broadcast multiply, and in backward
     two more broadcast multiplies, an expand and three reductions over the 268-MB grid."""
 
     @staticmethod
@@ -224,50 +224,55 @@ class _SE3d(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         B, C = x.shape[:2]
+        Cr = w1.shape[0]
         L = x[0, 0].numel()
         st = _lib.stream_ptr(x.device)
-        stats = torch.empty(B * C, 2, device=x.device, dtype=torch.float32)
+        dev = x.device
+        stats = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
         _lib.check(lib.lion_row_stats(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats")
-        mean = (stats[:, 0] / float(L)).reshape(B, C)
-        h = torch.relu(mean @ w1.t())
-        g = torch.sigmoid(h @ w2.t()).contiguous()
-        zero = torch.zeros_like(g)
+        w1c, w2c = w1.detach().float().contiguous(), w2.detach().float().contiguous()
+        mean, g, zero = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(3))
+        h = torch.empty(B, Cr, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_se_gate_fwd(_lib.ptr(stats), _lib.ptr(w1c), _lib.ptr(w2c), B, C, Cr, L, _lib.ptr(mean), _lib.ptr(h),
+                                        _lib.ptr(g), _lib.ptr(zero), st), "se_gate_fwd")
         y = torch.empty_like(x)
         _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(g), _lib.ptr(zero), B * C, L, 0, _lib.ptr(y), st), "affine_act")
-        ctx.save_for_backward(x, w1, w2, mean, h, g)
+        ctx.save_for_backward(x, w1c, w2c, mean, h, g, zero)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         lib = _lib.load()
-        x, w1, w2, mean, h, g = ctx.saved_tensors
+        x, w1, w2, mean, h, g, zero = ctx.saved_tensors
         gy = gy.contiguous()
         B, C = x.shape[:2]
+        Cr = w1.shape[0]
         L = x[0, 0].numel()
         st = _lib.stream_ptr(x.device)
-        zero = torch.zeros_like(g)
-        S = torch.empty(B * C, 2, device=x.device, dtype=torch.float32)
+        dev = x.device
+        S = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
         _lib.check(lib.lion_affine_act_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(g), _lib.ptr(zero), B * C, L, 0,
-                                                 _lib.ptr(S), st), "affine_act_bwd_stats")
-        dg = S[:, 1].reshape(B, C)                 # sum over the voxels of gy * x
-        dpre2 = dg * g * (1.0 - g)
-        dw2 = dpre2.t() @ h if ctx.needs_input_grad[2] else None
-        dpre1 = (dpre2 @ w2) * (h > 0).to(h.dtype)
-        dw1 = dpre1.t() @ mean if ctx.needs_input_grad[1] else None
+                                                 _lib.ptr(S), st), "affine_act_bwd_stats")   # S[:, 1] = sum over the voxels of gy * x
+        dpre2, Q = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
+        dpre1 = torch.empty(B, Cr, device=dev, dtype=torch.float32)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        _lib.check(lib.lion_se_gate_bwd(_lib.ptr(S), _lib.ptr(g), _lib.ptr(h), _lib.ptr(mean), _lib.ptr(w1), _lib.ptr(w2), B, C, Cr,
+                                        L, _lib.ptr(dpre2), _lib.ptr(dpre1), _lib.ptr(Q), _lib.ptr(dw1), _lib.ptr(dw2), st),
+                   "se_gate_bwd")
         dx = None
-        if ctx.needs_input_grad[0]:
-            Q = ((dpre1 @ w1) / float(L)).contiguous()   # d loss / d x through the mean: the same for every voxel of a channel
+        if ctx.needs_input_grad[0]:   # Q: d loss / d x through the mean, the same for every voxel of a channel
             dx = torch.empty_like(x)
             _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(g), _lib.ptr(zero), _lib.ptr(Q),
                                                      _lib.ptr(zero), B * C, L, 0, _lib.ptr(dx), st), "affine_act_bwd_apply")
-        return dx, dw1, dw2
+        return dx, (dw1 if ctx.needs_input_grad[1] else None), (dw2 if ctx.needs_input_grad[2] else None)
 
 
 def se3d_trainable(se, x) -> bool:
     fc = getattr(se, "fc", None)
     return (usable(x) and fc is not None and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear) and fc[0].bias is None
-            and isinstance(fc[2], torch.nn.Linear) and fc[2].bias is None)
+            and isinstance(fc[2], torch.nn.Linear) and fc[2].bias is None
+            and fc[0].in_features <= 1024 and fc[0].out_features <= 128 and fc[2].weight.dtype == torch.float32)
 
 
 def se3d(se, x):

@@ -268,7 +268,7 @@ def test_adagn_act_broadcast_factors_when_batch_equals_channels(fshape, bshape):
         assert (t.grad.double() - want).abs().max().item() <= 3 * tol(want)
 
 
-@pytest.mark.parametrize("B,C,r", [(3, 64, 16), (2, 128, 8), (2, 32, 32)])
+@pytest.mark.parametrize("B,C,r", [(3, 64, 16), (2, 128, 8), (2, 32, 32), (5, 512, 4), (33, 1024, 2)])
 def test_se3d_training_op_matches_float64_autograd(B, C, r):
     """train_ops.se3d (row sums + one scaling pass forward; one reduction + one fused apply backward) == the module's own
     expression (reference models/pvcnn2_ada.py:27-41) in float64 autograd: output, d x, d fc weights"""
