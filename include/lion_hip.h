@@ -424,10 +424,11 @@ int lion_scatter_csr(const float *gy, const int32_t *idx, const float *w, int B,
 /* ---- weight gradient of the 1x1 convolutions (training): gw[o][i] = sum_b sum_l gy[b][o][l] x[b][i][l] --------------
  * x f32[B,Cin,L], gy f32[B,Cout,L] (16-byte aligned), gw f32[Cout,Cin]; ws from lion_pwconv_wgrad_workspace_bytes.  What
  * autograd's mm([O, B L] x [B L, I]) of models/pvcnn2_ada.py's SharedMLP layers computes, without the transposing copies;
- * exact fp32 products on the MFMA pipe, slices summed in fixed order (csrc/pwconv_wgrad.hip). */
+ * exact fp32 products on the MFMA pipe, slices summed in fixed order (csrc/pwconv_wgrad.hip).  gb f32[Cout] or NULL: the bias
+ * gradient sum_b sum_l gy[b][o][l], taken from the same staged rows of gy (no second pass over it). */
 size_t lion_pwconv_wgrad_workspace_bytes(int B, int Cin, int Cout, int L);
 int lion_pwconv_wgrad(const float *x, const float *gy, int B, int Cin, int Cout, int L, void *ws, size_t ws_bytes,
-                      float *gw, lionStream_t stream);
+                      float *gw, float *gb, lionStream_t stream);
 
 /* ---- training forms of GroupNorm / AdaGN (+ Swish): models/adagn.py:45-65, models/pvcnn2_ada.py:78-84 --------------
  * Per row (b, c) of length L a GroupNorm followed by per-(batch, channel) scalars and an activation is

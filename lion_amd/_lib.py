@@ -96,7 +96,7 @@ SIGNATURES = {
     "lion_scatter_csr_workspace_bytes": (_sz, [_i, _i, _i]),
     "lion_scatter_csr": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "lion_pwconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "lion_pwconv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "lion_pwconv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "lion_gn_train_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "lion_row_stats64": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_gn_train_fold64": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

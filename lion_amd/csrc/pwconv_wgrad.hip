@@ -19,7 +19,7 @@ constexpr int PWG_S = 68;       // LDS row stride in floats
 
 __global__ __launch_bounds__(256, 2) void pwconv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                               int Cin, int Cout, int L, int LK, int spb,
-                                                              float *__restrict__ part) {
+                                                              float *__restrict__ part, float *__restrict__ bpart) {
   __shared__ __attribute__((aligned(16))) float sg[2][PWG_T * PWG_S], sx[2][PWG_T * PWG_S];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slice = blockIdx.x, b = slice / spb, l_begin = (slice % spb) * LK;
@@ -31,6 +31,10 @@ __global__ __launch_bounds__(256, 2) void pwconv_wgrad_kernel(const float *__res
   // staging: thread -> (row r0 + 16 j, 4 consecutive l at c4): 16 lanes cover 256 contiguous bytes of a row
   const int r0 = tid >> 4, c4 = (tid & 15) * 4;
   float4 rg[4], rx[4];
+  // bias gradient (row sums of gy) from the staging registers of the workgroups of the first input-channel tile: the rows
+  // are in flight anyway -- was a separate streaming pass over gy + a batch sum per layer
+  const bool want_b = bpart != nullptr && blockIdx.z == 0;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
   auto load = [&](int l0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void pwconv_wgrad_kernel(const float *__res
       }
       rg[j] = a;
       rx[j] = c;
+      if (want_b) bs[j] += (a.x + a.y) + (a.z + a.w);
     }
   };
   auto store = [&](int buf) {
@@ -93,24 +98,41 @@ __global__ __launch_bounds__(256, 2) void pwconv_wgrad_kernel(const float *__res
     const int o = o0 + wo + (k & 3) + 8 * (k >> 2) + 4 * half, i = i0 + wi + l32;
     if (o < Cout && i < Cin) pt[(size_t)o * Cin + i] = acc[k];
   }
+  if (want_b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = bs[j];
+      v += __shfl_xor(v, 8, 64);   // the 16 lanes that staged one row, fixed order
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 1, 64);
+      const int r = r0 + 16 * j;
+      if ((tid & 15) == 0 && r < orows) bpart[(size_t)slice * Cout + o0 + r] = v;
+    }
+  }
 }
 
 // 16 elements x 16 slice groups per workgroup: the slices of an element are summed by 16 threads (stride 16) and combined
 // through LDS in fixed order -- with one thread per element a 32 x 35 gradient spread over 2048 slices was a 90-us serial loop
+// elements n .. n + nb - 1 are the bias gradient (partials bpart [slices][nb])
 __global__ __launch_bounds__(256) void pwconv_wgrad_reduce_kernel(const float *__restrict__ part, int n, int slices,
-                                                                  float *__restrict__ gw) {
+                                                                  float *__restrict__ gw, const float *__restrict__ bpart,
+                                                                  int nb, float *__restrict__ gb) {
   __shared__ double sh[16][17];
   const int el = threadIdx.x & 15, grp = threadIdx.x >> 4, e = blockIdx.x * 16 + el;
+  const bool is_w = e < n, live = e < n + nb;
+  const float *src = is_w ? part + e : bpart + (e - n);
+  const size_t stride = is_w ? (size_t)n : (size_t)nb;
   double s = 0.0;
-  if (e < n)
-    for (int k = grp; k < slices; k += 16) s += (double)part[(size_t)k * n + e];
+  if (live)
+    for (int k = grp; k < slices; k += 16) s += (double)src[(size_t)k * stride];
   sh[grp][el] = s;
   __syncthreads();
-  if (grp == 0 && e < n) {
+  if (grp == 0 && live) {
     double t = 0.0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += sh[g][el];
-    gw[e] = (float)t;
+    (is_w ? gw + e : gb + (e - n))[0] = (float)t;
   }
 }
 
@@ -138,22 +160,23 @@ extern "C" {
 
 size_t lion_pwconv_wgrad_workspace_bytes(int B, int Cin, int Cout, int L) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0) return 0;
-  return (size_t)pwg_plan(B, Cin, Cout, L).slices * Cout * Cin * sizeof(float);
+  return (size_t)pwg_plan(B, Cin, Cout, L).slices * Cout * (Cin + 1) * sizeof(float);   // + 1: the bias gradient's partials
 }
 
 int lion_pwconv_wgrad(const float *x, const float *gy, int B, int Cin, int Cout, int L, void *ws, size_t ws_bytes,
-                      float *gw, lionStream_t stream) {
+                      float *gw, float *gb, lionStream_t stream) {
   if (!x || !gy || !gw || B <= 0 || Cin <= 0 || Cout <= 0 || L <= 0) return LION_EINVAL;
   const PwgPlan p = pwg_plan(B, Cin, Cout, L);
-  const size_t need = (size_t)p.slices * Cout * Cin * sizeof(float);
+  const size_t need = (size_t)p.slices * Cout * (Cin + 1) * sizeof(float);
   if (!ws || ws_bytes < need) return LION_EWORKSPACE;
   if ((((uintptr_t)x | (uintptr_t)gy) & 15) != 0) return LION_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float *part = static_cast<float *>(ws);
+  float *bpart = gb ? part + (size_t)p.slices * Cout * Cin : nullptr;
   pwconv_wgrad_kernel<<<dim3(p.slices, lion_cdiv(Cout, PWG_T), lion_cdiv(Cin, PWG_T)), 256, 0, st>>>(
-      x, gy, Cin, Cout, L, p.LK, p.spb, part);
-  const int n = Cout * Cin;
-  pwconv_wgrad_reduce_kernel<<<lion_cdiv(n, 16), 256, 0, st>>>(part, n, p.slices, gw);
+      x, gy, Cin, Cout, L, p.LK, p.spb, part, bpart);
+  const int n = Cout * Cin, nb = gb ? Cout : 0;
+  pwconv_wgrad_reduce_kernel<<<lion_cdiv(n + nb, 16), 256, 0, st>>>(part, n, p.slices, gw, bpart, nb, gb);
   LION_LAUNCH_CHECK();
   return 0;
 }

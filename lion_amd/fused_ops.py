@@ -370,8 +370,9 @@ def pwconv_raw(x, w2d, bias=None, cached_param=None):
     return y
 
 
-def pwconv_wgrad(x, gy):
-    """gw [Cout, Cin] = sum_b gy[b] @ x[b]^T for x [B, Cin, *], gy [B, Cout, *] (csrc/pwconv_wgrad.hip)"""
+def pwconv_wgrad(x, gy, want_bias=False):
+    """gw [Cout, Cin] = sum_b gy[b] @ x[b]^T for x [B, Cin, *], gy [B, Cout, *] (csrc/pwconv_wgrad.hip); want_bias: returns
+    (gw, gb) with gb [Cout] = gy summed over batch and positions, from the same launch"""
     lib = _lib.load()
     x, gy = x.contiguous(), gy.contiguous()
     b, cin = x.shape[:2]
@@ -380,9 +381,10 @@ def pwconv_wgrad(x, gy):
     wsb = lib.lion_pwconv_wgrad_workspace_bytes(b, cin, cout, L)
     ws = torch.empty((wsb,), device=x.device, dtype=torch.uint8)
     gw = torch.empty((cout, cin), device=x.device, dtype=torch.float32)
-    _lib.check(lib.lion_pwconv_wgrad(_lib.ptr(x), _lib.ptr(gy), b, cin, cout, L, _lib.ptr(ws), wsb, _lib.ptr(gw),
+    gb = torch.empty((cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    _lib.check(lib.lion_pwconv_wgrad(_lib.ptr(x), _lib.ptr(gy), b, cin, cout, L, _lib.ptr(ws), wsb, _lib.ptr(gw), _lib.ptr(gb),
                                      _lib.stream_ptr(x.device)), "pwconv_wgrad")
-    return gw
+    return (gw, gb) if want_bias else gw
 
 
 def group_points(coords, centers, feat, idx):

@@ -307,9 +307,14 @@ class _PwConv(torch.autograd.Function):
             gx = fused_ops.pwconv_raw(gy, w2d.t().contiguous())
             if gx is None:
                 gx = torch.matmul(w2d.t(), gy.flatten(2)).reshape(x.shape)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = fused_ops.pwconv_wgrad(x, gy).reshape(weight.shape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_b:   # the bias gradient rides on the weight gradient's pass over gy
+                gw, gb = fused_ops.pwconv_wgrad(x, gy, want_bias=True)
+            else:
+                gw = fused_ops.pwconv_wgrad(x, gy)
+            gw = gw.reshape(weight.shape)
+        elif want_b:
             gb = fused_ops.row_stats(gy)[:, 0].reshape(gy.shape[0], gy.shape[1]).sum(0)
         return gx, gw, gb
 
