@@ -380,6 +380,10 @@ int lion_pwconv_forward_max(const float *x, const float *wp, const float *bias, 
  * Any Cout, Cin, L with Cin * L < 2^29. */
 size_t lion_pwconv_split_packed_halfs(int Cout, int Cin);
 int lion_pwconv_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *wp, lionStream_t stream);
+/* TRAINING: the packed form of W^T (the matrix of the data gradient, autograd's mm(W^T, gy)) from W f32[Cout,Cin] as stored and
+ * wp = lion_pwconv_split_pack_weights(W) (its tail carries the tensor's scale, which the transposition does not change):
+ * wpt = lion_pwconv_split_packed_halfs(Cin, Cout) uint16.  One launch; no transposed copy, no second pass for max |w|. */
+int lion_pwconv_split_pack_weights_t(const float *w, int Cout, int Cin, const uint16_t *wp, uint16_t *wpt, lionStream_t stream);
 int lion_pwconv_split_stat_tiles(int Cout, int Cin, int L);
 int lion_pwconv_split_forward(const float *x, const uint16_t *wp, const float *bias, int B, int Cin, int Cout, int L,
                               const float *pro_a, const float *pro_b, float *y, float *stats, lionStream_t stream);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "lion_pwconv_forward_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_pwconv_split_packed_halfs": (_sz, [_i, _i]),
     "lion_pwconv_split_pack_weights": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lion_pwconv_split_pack_weights_t": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "lion_pwconv_split_stat_tiles": (_i, [_i, _i, _i]),
     "lion_pwconv_split_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lion_linear_attention_core": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -33,14 +33,15 @@
 namespace {
 
 // w f32[Cout][Cin][27] -> wp u16[Cin/16][27][piece][k-half][Cout][8]   (ci = chunk*16 + half*8 + j)
-// pack: cuts w * 2^ew (split_ops.h: split_wmax_kernel / split_wscale_kernel fill the tail first).
+// pack: cuts w * 2^ew (split_ops.h: split_wmax_kernel left max |w| in the tail; split_tail_scale completes it).
 __global__ void split_pack_kernel(const float *__restrict__ w, int Cout, int Cin, unsigned short *__restrict__ wp,
-                                  const unsigned *__restrict__ tail) {
+                                  unsigned *__restrict__ tail) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ew = split_tail_scale(tail, i == 0);
   if (i >= Cout * Cin * 27) return;
   const int t = i % 27, c = (i / 27) % Cin, co = i / (27 * Cin), chunk = c / KS, g = (c % KS) / 8, j = c % 8;
   unsigned short hi, lo;
-  cut(w[i] * pow2f((int)tail[1]), hi, lo);
+  cut(w[i] * pow2f(ew), hi, lo);
   const size_t base = ((size_t)chunk * 27 + t) * 4;
   wp[((base + 0 + g) * Cout + co) * 8 + j] = hi;
   wp[((base + 2 + g) * Cout + co) * 8 + j] = lo;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256, OCC) void conv3d_split_kernel(const float *__r
   __shared__ unsigned char s_rowok[256];      // aware level 2, delta launches: this staging thread's halo row has been written
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 5, l32 = lane & 31;
-  const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_wscale_kernel)
+  const float wscale_inv = wtail[2]; // 2^-ew of the packed weights (split_tail_scale)
   const bool queued = occ != nullptr;
   const int ncz = Cout / COT;
   const int n_tile_items = ntiles * B * ncz;
@@ -890,7 +891,6 @@ int lion_conv3d_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *
   const int n = Cout * Cin * 27;
   if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return LION_EINVAL;
   split_wmax_kernel<<<min(lion_cdiv(n, 2048), 128), 256, 0, st>>>(w, n, tail);
-  split_wscale_kernel<<<1, 1, 0, st>>>(tail);
   split_pack_kernel<<<lion_cdiv(n, 256), 256, 0, st>>>(w, Cout, Cin, wp, tail);
   LION_LAUNCH_CHECK();
   return 0;

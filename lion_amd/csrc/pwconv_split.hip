@@ -281,14 +281,25 @@ __global__ __launch_bounds__(256, 2) void pwconv_split_kernel(const float *__res
   PWS_T(101);
 }
 
-// W f32[Cout][Cin] -> pieces u16 [ceil16(Cin)/16][piece][k-half][Cpad][8] (zero beyond Cout / Cin), cut from W * 2^ew
+// W f32[Cout][Cin] -> pieces u16 [ceil16(Cin)/16][piece][k-half][Cpad][8] (zero beyond Cout / Cin), cut from W * 2^ew.
+// TR: the pieces of W^T (the data gradient's matrix) straight from W as stored -- w is then f32[Cin][Cout], read along its
+// rows; its scale is W's (max |w| does not care about the transposition): `tail_src` = the tail of W's own packed form.
+template <bool TR>
 __global__ void pw_split_pack_kernel(const float *__restrict__ w, int Cout, int Cpad, int Cin, int nchunks,
-                                     unsigned short *__restrict__ wp, const unsigned *__restrict__ tail) {
+                                     unsigned short *__restrict__ wp, unsigned *__restrict__ tail,
+                                     const unsigned *__restrict__ tail_src) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int ew;
+  if (TR) {
+    ew = (int)tail_src[1];
+    if (i < 4) tail[i] = tail_src[i];
+  } else {
+    ew = split_tail_scale(tail, i == 0);
+  }
   if (i >= nchunks * KS * Cpad) return;
   const int co = i % Cpad, k = i / Cpad, q = k / KS, g = (k % KS) / 8, j = k % 8;
   unsigned short hi = 0, lo = 0;
-  if (co < Cout && k < Cin) cut(w[(size_t)co * Cin + k] * pow2f((int)tail[1]), hi, lo);
+  if (co < Cout && k < Cin) cut((TR ? w[(size_t)k * Cout + co] : w[(size_t)co * Cin + k]) * pow2f(ew), hi, lo);
   const size_t base = (size_t)q * 4;
   wp[((base + 0 + g) * Cpad + co) * 8 + j] = hi;
   wp[((base + 2 + g) * Cpad + co) * 8 + j] = lo;
@@ -353,8 +364,22 @@ int lion_pwconv_split_pack_weights(const float *w, int Cout, int Cin, uint16_t *
   const int n = Cout * Cin, nchunks = (Cin + KS - 1) / KS, Cpad = pws_pad(Cout);
   if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return LION_EINVAL;
   split_wmax_kernel<<<min(lion_cdiv(n, 2048), 128), 256, 0, st>>>(w, n, tail);
-  split_wscale_kernel<<<1, 1, 0, st>>>(tail);
-  pw_split_pack_kernel<<<lion_cdiv(nchunks * KS * Cpad, 256), 256, 0, st>>>(w, Cout, Cpad, Cin, nchunks, wp, tail);
+  pw_split_pack_kernel<false><<<lion_cdiv(nchunks * KS * Cpad, 256), 256, 0, st>>>(w, Cout, Cpad, Cin, nchunks, wp, tail, nullptr);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// The packed form of W^T f32[Cin][Cout] (what the data gradient multiplies by) from W f32[Cout][Cin] as stored and W's own
+// packed form wp (its tail holds the scale): one launch, no transposed copy, no second maximum.  wpt: lion_pwconv_split_packed_halfs(Cin, Cout).
+int lion_pwconv_split_pack_weights_t(const float *w, int Cout, int Cin, const uint16_t *wp, uint16_t *wpt, lionStream_t stream) {
+  if (!w || !wp || !wpt || Cout <= 0 || Cin <= 0) return LION_EINVAL;
+  if (((((uintptr_t)wp) | ((uintptr_t)wpt)) & 15) != 0) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned *tail_src = reinterpret_cast<const unsigned *>(wp + pws_halfs(Cout, Cin));
+  unsigned *tail = reinterpret_cast<unsigned *>(wpt + pws_halfs(Cin, Cout));
+  // the transposed matrix has Cin rows ("output channels") and Cout columns
+  const int nchunks = (Cout + KS - 1) / KS, Cpad = pws_pad(Cin);
+  pw_split_pack_kernel<true><<<lion_cdiv(nchunks * KS * Cpad, 256), 256, 0, st>>>(w, Cin, Cpad, Cout, nchunks, wpt, tail, tail_src);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -72,13 +72,21 @@ static __global__ void split_wmax_kernel(const float *__restrict__ w, int n, uns
     if (m) atomicMax(tail, m);
   }
 }
-static __global__ void split_wscale_kernel(unsigned *__restrict__ tail) {
+// pass 2 rides on the pack kernels: every thread derives ew from the maximum, the first one records {ew, 2^-ew} for the
+// consumers (was a one-thread launch of its own between the two passes)
+__device__ __forceinline__ int split_tail_scale(unsigned *__restrict__ tail, bool writer) {
   const float m = __uint_as_float(tail[0]);
   const int ew = m > 0.f ? scale_exp(m) : 0;
-  tail[1] = (unsigned)ew;
-  tail[2] = __float_as_uint(pow2f(-ew));
-  tail[3] = 0u;
+  if (writer) {
+    tail[1] = (unsigned)ew;
+    tail[2] = __float_as_uint(pow2f(-ew));
+    tail[3] = 0u;
+  }
+  return ew;
 }
+
+// the former stand-alone pass 2 (tools/exp variants of the kernels still launch it)
+static __global__ void split_wscale_kernel(unsigned *__restrict__ tail) { split_tail_scale(tail, true); }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

@@ -346,19 +346,28 @@ def pwconv_max_recompute(x, conv, gn, style, pro):
     return y
 
 
-def pwconv_raw(x, w2d, bias=None, cached_param=None):
+def pwconv_raw(x, w2d, bias=None, cached_param=None, transposed=False):
     """y[b] = w2d @ x[b] (+ bias) on the library's 1x1-convolution kernels for a plain [Cout, Cin] matrix; None when
     the shape is not supported.  cached_param: the nn.Parameter w2d is a view of (its packed form is cached per
-    version); otherwise -- transposed weights of a backward pass -- the matrix is packed for this call only."""
+    version).  transposed: y[b] = w2d^T @ x[b] -- the data gradient of a layer with weight w2d; on the split kernel the
+    packed W^T comes straight from W and the scale of W's cached packed form (lion_pwconv_split_pack_weights_t)."""
     lib = _lib.load()
     x = x.contiguous()
     b, cin = x.shape[:2]
-    cout = w2d.shape[0]
+    cout = w2d.shape[1] if transposed else w2d.shape[0]
     L = x[0, 0].numel()
     if not (x.is_cuda and x.dtype == torch.float32 and L > 0 and lib.lion_pwconv_stat_tiles(cout, cin, L) > 0):
         return None
     use_split = pw_use_split(None, b, cin, cout, L)
-    if cached_param is not None:
+    if transposed and use_split and cached_param is not None:
+        wf = _PW_SPLIT_CACHE.get(cached_param)
+        wp = torch.empty((lib.lion_pwconv_split_packed_halfs(cout, cin),), device=x.device, dtype=torch.int16)
+        w_c = w2d.detach().contiguous()
+        _lib.check(lib.lion_pwconv_split_pack_weights_t(_lib.ptr(w_c), cin, cout, _lib.ptr(wf), _lib.ptr(wp),
+                                                        _lib.stream_ptr(x.device)), "pwconv_split_pack_weights_t")
+    elif transposed:
+        wp = (_pw_split_pack if use_split else _pw_pack)(w2d.detach().t().contiguous())
+    elif cached_param is not None:
         wp = _PW_SPLIT_CACHE.get(cached_param) if use_split else _PW_CACHE.get(cached_param)
     else:
         wp = (_pw_split_pack if use_split else _pw_pack)(w2d)

@@ -304,7 +304,7 @@ class _PwConv(torch.autograd.Function):
         w2d = weight.detach().reshape(weight.shape[0], -1)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = fused_ops.pwconv_raw(gy, w2d.t().contiguous())
+            gx = fused_ops.pwconv_raw(gy, w2d, cached_param=weight, transposed=True)
             if gx is None:
                 gx = torch.matmul(w2d.t(), gy.flatten(2)).reshape(x.shape)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
