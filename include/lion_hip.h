@@ -473,6 +473,19 @@ int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, c
                               float *S, lionStream_t stream);
 int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
                               const float *R, int rows, int L, int act, float *dx, lionStream_t stream);
+/* TRAINING, round 6: the same three passes with nn.Dropout behind the activation (PVConv's voxel branch: Conv3d -> AdaGN -> Swish ->
+ * Dropout, reference pvcnn2_ada.py:211-222; pvcnn2.py:170-186): y = act(A x + Bs) * m / keep, m ~ Bernoulli(keep) per element.
+ * Element e is kept when word (e & 3) of Philox4x32-10(counter = {e >> 2, 'DROP', 0}, key = *seed) < keep * 2^32; seed: a 64-bit
+ * word in DEVICE memory (drawn per call by the framework's generator, so that a replayed hipGraph draws a fresh mask); the two
+ * backward passes regenerate the mask from the same seed (gy is masked and scaled on the fly) -- no mask tensor exists.
+ * keep in (0, 1]. */
+int lion_affine_act_dropout(const float *x, const float *A, const float *Bs, int rows, int L, int act, const uint64_t *seed,
+                            float keep, float *y, lionStream_t stream);
+int lion_affine_act_dropout_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,
+                                      const uint64_t *seed, float keep, float *S, lionStream_t stream);
+int lion_affine_act_dropout_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                                      const float *R, int rows, int L, int act, const uint64_t *seed, float keep, float *dx,
+                                      lionStream_t stream);
 /* Round 6 -- the same op with the set-abstraction pooling behind it (pvcnn2_ada.py:375-377): y f32[rows, M] = max over the U
  * neighbours of act(A x + Bs), x f32[rows, M, U] (U in {8, 16, 32, 64}).  The activated tensor is never written and its gradient
  * never materialised: backward = lion_affine_act_max_bwd_stats (S = {sum da, sum da x}, da = gy act'(.) at each group's FIRST

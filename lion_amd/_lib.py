@@ -108,6 +108,9 @@ SIGNATURES = {
     "lion_affine_act": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lion_affine_act_dropout": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp]),
+    "lion_affine_act_dropout_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp]),
+    "lion_affine_act_dropout_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp]),
     "lion_affine_act_max": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_max_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_max_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

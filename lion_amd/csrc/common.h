@@ -61,6 +61,19 @@ __device__ __forceinline__ float sqrt_rn(float a) { return sqrtf(a); }
 // csrc/conv3d*.hip needs the constant and the staged activation to come from the same arithmetic.  (Until round 3 this
 // was written __frcp_rn(1 + __expf(-t)), which compiles to the 10-instruction IEEE division sequence: the activation cost
 // 22 VALU issues per value, half the matrix time of a prologue convolution.)
+// Philox4x32-10 (Salmon et al. 2011): counter (c0..c3), key (k0, k1) -> four 32-bit words
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 __device__ __forceinline__ float swish_fast(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
 
 // (a-b)^2 + (c-d)^2 + (e-f)^2 evaluated left to right without contraction.

@@ -55,18 +55,6 @@ __global__ void ddpm_kernel(const float *__restrict__ x, const float *__restrict
 // step, stream id) -- the seed is read from device memory so that a captured graph serves every chain --, four uniforms -> two Box-Muller pairs per float4 -- the reference draws the noise on the CPU
 // and copies it to the device every step (diffusion_pvd.py:465-466).  Algorithmic bytes per step: x, eps in,
 // x out (3*4*numel).
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 __device__ __forceinline__ float u01(uint32_t x) { // (0, 1]: x * 2^-32 + 2^-33, two roundings
   return add_rn(mul_rn((float)x, 2.3283064365386963e-10f), 1.1641532182693481e-10f);
 }

@@ -23,9 +23,31 @@ __device__ __forceinline__ float act_d(float a, int act) {
   return s * (1.0f + a * (1.0f - s));
 }
 
+// Inverted dropout behind the activation (nn.Dropout after Swish in PVConv's voxel branch, reference pvcnn2_ada.py:211-222), DROP
+// variants: element e of the tensor is kept when word (e & 3) of Philox4x32-10(counter = e >> 2, key = the 64-bit seed read from
+// device memory) is below thr = keep * 2^32, and scaled by 1 / keep.  The seed is drawn per call by torch's generator (graph-safe:
+// a replayed step draws a new one), forward and both backward kernels regenerate the same mask from it -- no mask tensor, no
+// extra pass (ATen: fused_dropout reads x, writes y + mask; masked_scale reads gy + mask, writes).
+__device__ __forceinline__ void drop4(const unsigned long long *__restrict__ seed, size_t e, unsigned thr, float scale, float m[4]) {
+  uint32_t r[4];
+  const unsigned long long s = seed[0], quad = (unsigned long long)e >> 2;
+  philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), 0x44524f50u, 0u, (uint32_t)s, (uint32_t)(s >> 32), r);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j] = r[j] < thr ? scale : 0.f;
+}
+__device__ __forceinline__ float drop1(const unsigned long long *__restrict__ seed, size_t e, unsigned thr, float scale) {
+  float m[4];
+  drop4(seed, e, thr, scale, m);
+  const int k = (int)(e & 3);
+  return k == 0 ? m[0] : k == 1 ? m[1] : k == 2 ? m[2] : m[3];
+}
+
+template <bool DROP>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float *__restrict__ x, const float *__restrict__ A,
                                                          const float *__restrict__ Bs, int L, int act,
-                                                         float *__restrict__ y) {
+                                                         float *__restrict__ y,
+                                                         const unsigned long long *__restrict__ seed, unsigned thr,
+                                                         float scale) {
   const int bpr = (((L + 3) >> 2) + 255) >> 8; // workgroups per row: the row index rides on blockIdx.x (B C > 65535 rows exist)
   const int row = blockIdx.x / bpr;
   const float a = A[row], b = Bs[row];
@@ -34,10 +56,16 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float *__restrict
   const int i = ((blockIdx.x - row * bpr) * 256 + threadIdx.x) * 4;
   if (i + 3 < L && (L & 3) == 0) {
     const float4 v = *reinterpret_cast<const float4 *>(p + i);
-    *reinterpret_cast<float4 *>(q + i) = make_float4(act_f(v.x * a + b, act), act_f(v.y * a + b, act),
-                                                     act_f(v.z * a + b, act), act_f(v.w * a + b, act));
+    float4 o = make_float4(act_f(v.x * a + b, act), act_f(v.y * a + b, act), act_f(v.z * a + b, act), act_f(v.w * a + b, act));
+    if (DROP) {
+      float m[4];
+      drop4(seed, (size_t)row * L + i, thr, scale, m);
+      o = make_float4(o.x * m[0], o.y * m[1], o.z * m[2], o.w * m[3]);
+    }
+    *reinterpret_cast<float4 *>(q + i) = o;
   } else {
-    for (int j = i; j < L && j < i + 4; ++j) q[j] = act_f(p[j] * a + b, act);
+    for (int j = i; j < L && j < i + 4; ++j)
+      q[j] = act_f(p[j] * a + b, act) * (DROP ? drop1(seed, (size_t)row * L + j, thr, scale) : 1.0f);
   }
 }
 
@@ -75,10 +103,13 @@ __global__ __launch_bounds__(256) void row_stats64_kernel(const float *__restric
 }
 
 // one workgroup per row: S[row] = {sum da, sum da x}
+template <bool DROP>
 __global__ __launch_bounds__(256) void affine_act_bwd_stats_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                    const float *__restrict__ A,
                                                                    const float *__restrict__ Bs, int L, int act,
-                                                                   float *__restrict__ S) {
+                                                                   float *__restrict__ S,
+                                                                   const unsigned long long *__restrict__ seed, unsigned thr,
+                                                                   float scale) {
   __shared__ float r1[4], r2[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float a = A[row], b = Bs[row];
@@ -86,14 +117,24 @@ __global__ __launch_bounds__(256) void affine_act_bwd_stats_kernel(const float *
   float s1 = 0.f, s2 = 0.f;
   if ((L & 3) == 0) {
     for (int i = tid * 4; i < L; i += 1024) {
-      const float4 v = *reinterpret_cast<const float4 *>(p + i), w = *reinterpret_cast<const float4 *>(g + i);
+      const float4 v = *reinterpret_cast<const float4 *>(p + i);
+      float4 w = *reinterpret_cast<const float4 *>(g + i);
+      if (DROP) {
+        float m[4];
+        drop4(seed, (size_t)row * L + i, thr, scale, m);
+        w = make_float4(w.x * m[0], w.y * m[1], w.z * m[2], w.w * m[3]);
+      }
       const float d0 = w.x * act_d(v.x * a + b, act), d1 = w.y * act_d(v.y * a + b, act);
       const float d2 = w.z * act_d(v.z * a + b, act), d3 = w.w * act_d(v.w * a + b, act);
       s1 += (d0 + d1) + (d2 + d3);
       s2 += (d0 * v.x + d1 * v.y) + (d2 * v.z + d3 * v.w);
     }
   } else {
-    for (int i = tid; i < L; i += 256) { const float d = g[i] * act_d(p[i] * a + b, act); s1 += d; s2 += d * p[i]; }
+    for (int i = tid; i < L; i += 256) {
+      const float d = g[i] * (DROP ? drop1(seed, (size_t)row * L + i, thr, scale) : 1.0f) * act_d(p[i] * a + b, act);
+      s1 += d;
+      s2 += d * p[i];
+    }
   }
   s1 = row16_sum_rn(s1); s2 = row16_sum_rn(s2);
 #pragma unroll
@@ -106,12 +147,15 @@ __global__ __launch_bounds__(256) void affine_act_bwd_stats_kernel(const float *
   }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                    const float *__restrict__ A,
                                                                    const float *__restrict__ Bs,
                                                                    const float *__restrict__ Q,
                                                                    const float *__restrict__ R, int L, int act,
-                                                                   float *__restrict__ dx) {
+                                                                   float *__restrict__ dx,
+                                                                   const unsigned long long *__restrict__ seed, unsigned thr,
+                                                                   float scale) {
   const int bpr = (((L + 3) >> 2) + 255) >> 8;
   const int row = blockIdx.x / bpr;
   const float a = A[row], b = Bs[row], qq = Q[row], rr = R[row];
@@ -119,13 +163,20 @@ __global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *
   float *o = dx + (size_t)row * L;
   const int i = ((blockIdx.x - row * bpr) * 256 + threadIdx.x) * 4;
   if (i + 3 < L && (L & 3) == 0) {
-    const float4 v = *reinterpret_cast<const float4 *>(p + i), w = *reinterpret_cast<const float4 *>(g + i);
+    const float4 v = *reinterpret_cast<const float4 *>(p + i);
+    float4 w = *reinterpret_cast<const float4 *>(g + i);
+    if (DROP) {
+      float m[4];
+      drop4(seed, (size_t)row * L + i, thr, scale, m);
+      w = make_float4(w.x * m[0], w.y * m[1], w.z * m[2], w.w * m[3]);
+    }
     *reinterpret_cast<float4 *>(o + i) = make_float4(a * (w.x * act_d(v.x * a + b, act)) + qq + rr * v.x,
                                                      a * (w.y * act_d(v.y * a + b, act)) + qq + rr * v.y,
                                                      a * (w.z * act_d(v.z * a + b, act)) + qq + rr * v.z,
                                                      a * (w.w * act_d(v.w * a + b, act)) + qq + rr * v.w);
   } else {
-    for (int j = i; j < L && j < i + 4; ++j) o[j] = a * (g[j] * act_d(p[j] * a + b, act)) + qq + rr * p[j];
+    for (int j = i; j < L && j < i + 4; ++j)
+      o[j] = a * (g[j] * (DROP ? drop1(seed, (size_t)row * L + j, thr, scale) : 1.0f) * act_d(p[j] * a + b, act)) + qq + rr * p[j];
   }
 }
 
@@ -444,32 +495,79 @@ int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd,
 }
 
 
-int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
-                    lionStream_t stream) {
+// keep in (0, 1]: thr = keep * 2^32 (saturated), scale = 1 / keep
+static bool drop_args(const void *seed, float keep, unsigned *thr, float *scale) {
+  if (!seed || !(keep > 0.f) || keep > 1.f) return false;
+  const double t = (double)keep * 4294967296.0;
+  *thr = t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+  *scale = 1.0f / keep;
+  return true;
+}
+
+static int affine_act_launch(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
+                             const unsigned long long *seed, unsigned thr, float scale, lionStream_t stream) {
   if (!x || !A || !Bs || !y || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
   if ((long)rows * lion_cdiv(lion_cdiv(L, 4), 256) > 0x7fffffffL) return LION_EUNSUPPORTED;
-  affine_act_kernel<<<(unsigned)(rows * lion_cdiv(lion_cdiv(L, 4), 256)), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      x, A, Bs, L, act, y);
+  const unsigned grid = (unsigned)(rows * lion_cdiv(lion_cdiv(L, 4), 256));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (seed) affine_act_kernel<true><<<grid, 256, 0, st>>>(x, A, Bs, L, act, y, seed, thr, scale);
+  else affine_act_kernel<false><<<grid, 256, 0, st>>>(x, A, Bs, L, act, y, nullptr, 0u, 1.f);
   LION_LAUNCH_CHECK();
   return 0;
 }
-
-int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,
-                              float *S, lionStream_t stream) {
+static int affine_act_bwd_stats_launch(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,
+                                       float *S, const unsigned long long *seed, unsigned thr, float scale, lionStream_t stream) {
   if (!x || !gy || !A || !Bs || !S || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
-  affine_act_bwd_stats_kernel<<<rows, 256, 0, static_cast<hipStream_t>(stream)>>>(x, gy, A, Bs, L, act, S);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (seed) affine_act_bwd_stats_kernel<true><<<rows, 256, 0, st>>>(x, gy, A, Bs, L, act, S, seed, thr, scale);
+  else affine_act_bwd_stats_kernel<false><<<rows, 256, 0, st>>>(x, gy, A, Bs, L, act, S, nullptr, 0u, 1.f);
   LION_LAUNCH_CHECK();
   return 0;
 }
-
-int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
-                              const float *R, int rows, int L, int act, float *dx, lionStream_t stream) {
+static int affine_act_bwd_apply_launch(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                                       const float *R, int rows, int L, int act, float *dx, const unsigned long long *seed,
+                                       unsigned thr, float scale, lionStream_t stream) {
   if (!x || !gy || !A || !Bs || !Q || !R || !dx || rows <= 0 || L <= 0 || (act != 0 && act != 1)) return LION_EINVAL;
   if ((long)rows * lion_cdiv(lion_cdiv(L, 4), 256) > 0x7fffffffL) return LION_EUNSUPPORTED;
-  affine_act_bwd_apply_kernel<<<(unsigned)(rows * lion_cdiv(lion_cdiv(L, 4), 256)), 256, 0,
-                                static_cast<hipStream_t>(stream)>>>(x, gy, A, Bs, Q, R, L, act, dx);
+  const unsigned grid = (unsigned)(rows * lion_cdiv(lion_cdiv(L, 4), 256));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (seed) affine_act_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(x, gy, A, Bs, Q, R, L, act, dx, seed, thr, scale);
+  else affine_act_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(x, gy, A, Bs, Q, R, L, act, dx, nullptr, 0u, 1.f);
   LION_LAUNCH_CHECK();
   return 0;
+}
+
+int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
+                    lionStream_t stream) {
+  return affine_act_launch(x, A, Bs, rows, L, act, y, nullptr, 0u, 1.f, stream);
+}
+int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,
+                              float *S, lionStream_t stream) {
+  return affine_act_bwd_stats_launch(x, gy, A, Bs, rows, L, act, S, nullptr, 0u, 1.f, stream);
+}
+int lion_affine_act_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                              const float *R, int rows, int L, int act, float *dx, lionStream_t stream) {
+  return affine_act_bwd_apply_launch(x, gy, A, Bs, Q, R, rows, L, act, dx, nullptr, 0u, 1.f, stream);
+}
+// the same three passes with inverted dropout (keep probability `keep`, mask from the device-resident 64-bit `seed`) behind the activation
+int lion_affine_act_dropout(const float *x, const float *A, const float *Bs, int rows, int L, int act, const uint64_t *seed,
+                            float keep, float *y, lionStream_t stream) {
+  unsigned thr; float scale;
+  if (!drop_args(seed, keep, &thr, &scale)) return LION_EINVAL;
+  return affine_act_launch(x, A, Bs, rows, L, act, y, reinterpret_cast<const unsigned long long *>(seed), thr, scale, stream);
+}
+int lion_affine_act_dropout_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,
+                                      const uint64_t *seed, float keep, float *S, lionStream_t stream) {
+  unsigned thr; float scale;
+  if (!drop_args(seed, keep, &thr, &scale)) return LION_EINVAL;
+  return affine_act_bwd_stats_launch(x, gy, A, Bs, rows, L, act, S, reinterpret_cast<const unsigned long long *>(seed), thr, scale, stream);
+}
+int lion_affine_act_dropout_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
+                                      const float *R, int rows, int L, int act, const uint64_t *seed, float keep, float *dx,
+                                      lionStream_t stream) {
+  unsigned thr; float scale;
+  if (!drop_args(seed, keep, &thr, &scale)) return LION_EINVAL;
+  return affine_act_bwd_apply_launch(x, gy, A, Bs, Q, R, rows, L, act, dx, reinterpret_cast<const unsigned long long *>(seed), thr, scale, stream);
 }
 
 // U in {8, 16, 32, 64}; x f32[rows, M, U] 16-byte aligned

@@ -27,8 +27,10 @@ def run_layers(layers, x, reduce_max=False):
             fused_act = i + 1 < n and isinstance(layers[i + 1], Swish)
             if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x):
                 return train_ops.adagn_act_max(x, layer, None, None, act=fused_act)   # pooled: [B, C, M]
-            x = train_ops.adagn_act(x, layer, None, None, act=fused_act)
             i += 2 if fused_act else 1
+            drop_p, used = train_ops.fusable_dropout(layers, i) if fused_act else (0.0, 0)
+            x = train_ops.adagn_act(x, layer, None, None, act=fused_act, dropout_p=drop_p)
+            i += used
             continue
         if isinstance(layer, nn.Conv3d):
             x = conv3d_module(layer, x)

@@ -265,8 +265,10 @@ def run_layers(layers, x, style, conv, reduce_max=False):
                 factor, bias = layer.affine(style)
                 if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x):
                     return train_ops.adagn_act_max(x, layer.norm, factor, bias, act=fused_act)   # pooled: [B, C, M]
-                x = train_ops.adagn_act(x, layer.norm, factor, bias, act=fused_act)
                 i += 2 if fused_act else 1
+                drop_p, used = train_ops.fusable_dropout(layers, i) if fused_act else (0.0, 0)   # Swish -> Dropout (PVConv :211-222)
+                x = train_ops.adagn_act(x, layer.norm, factor, bias, act=fused_act, dropout_p=drop_p)
+                i += used
                 continue
             x = layer(x, style)
         elif isinstance(layer, (nn.Conv1d, nn.Conv2d, nn.Conv3d)):

@@ -21,6 +21,7 @@ PWCONV = os.environ.get("LION_TRAIN_PWCONV", "1") != "0"   # 1x1 convolutions of
 # The last number is the global prior's 2048-wide layers on [32, C, 1, 1] activations (32 columns: a weight-streaming skinny
 # GEMM, not what these kernels are tiled for): they stay on the rocBLAS matrix product, everything from 512 columns on is ours.
 PWCONV_MIN_COLS = int(os.environ.get("LION_TRAIN_PWCONV_MIN_COLS", "512"))
+DROPOUT_FUSED = os.environ.get("LION_TRAIN_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind AdaGN + Swish inside the activation pass
 
 
 def usable(x) -> bool:
@@ -66,7 +67,7 @@ def _param_grads(pw, want_w, want_b):
 
 class _AdaGNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gw, gb, factor, bias, groups, eps, act):
+    def forward(ctx, x, gw, gb, factor, bias, groups, eps, act, drop_p=0.0):
         lib = _lib.load()
         x = x.contiguous()
         B, C = x.shape[:2]
@@ -83,26 +84,40 @@ class _AdaGNAct(torch.autograd.Function):
                                           B, C, groups, L, eps, _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(mean), _lib.ptr(rstd),
                                             st), "gn_train_fold64")
         y = torch.empty_like(x)
-        _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), B * C, L, int(act), _lib.ptr(y), st), "affine_act")
-        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0))
+        keep = 1.0 - float(drop_p)
+        if drop_p > 0.0:
+            # nn.Dropout behind the activation, in the same pass: the mask comes from a seed torch's generator draws on the device
+            # (a replayed graph draws a new one) and is regenerated by the backward passes -- it is never stored
+            seed = torch.empty(1, device=dev, dtype=torch.int64).random_()
+            _lib.check(lib.lion_affine_act_dropout(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), B * C, L, int(act), _lib.ptr(seed), keep,
+                                                   _lib.ptr(y), st), "affine_act_dropout")
+        else:
+            seed = x.new_empty(0)
+            _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), B * C, L, int(act), _lib.ptr(y), st), "affine_act")
+        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0), seed)
         ctx.meta = (groups, int(act), factor is not None, bias is not None, fs,
-                    None if factor is None else factor.shape, None if bias is None else bias.shape)
+                    None if factor is None else factor.shape, None if bias is None else bias.shape, keep)
         return y
 
     @staticmethod
     @once_differentiable   # raw kernels: a double backward must raise, not silently treat these gradients as constants
     def backward(ctx, gy):
         lib = _lib.load()
-        x, A, Bs, mean, rstd, gwc, gbc, f = ctx.saved_tensors
-        groups, act, has_f, has_b, fs, f_shape, b_shape = ctx.meta
+        x, A, Bs, mean, rstd, gwc, gbc, f, seed = ctx.saved_tensors
+        groups, act, has_f, has_b, fs, f_shape, b_shape, keep = ctx.meta
+        drop = seed.numel() > 0
         gy = gy.contiguous()
         B, C = x.shape[:2]
         L = x[0, 0].numel()
         st = _lib.stream_ptr(x.device)
         dev = x.device
         S = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
-        _lib.check(lib.lion_affine_act_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, L, act,
-                                                 _lib.ptr(S), st), "affine_act_bwd_stats")
+        if drop:
+            _lib.check(lib.lion_affine_act_dropout_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, L, act,
+                                                             _lib.ptr(seed), keep, _lib.ptr(S), st), "affine_act_dropout_bwd_stats")
+        else:
+            _lib.check(lib.lion_affine_act_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, L, act,
+                                                     _lib.ptr(S), st), "affine_act_bwd_stats")
         Q, R = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
         dfac = torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None
         dbias = torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None
@@ -113,8 +128,13 @@ class _AdaGNAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
-                                                     _lib.ptr(R), B * C, L, act, _lib.ptr(dx), st), "affine_act_bwd_apply")
+            if drop:
+                _lib.check(lib.lion_affine_act_dropout_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
+                                                                 _lib.ptr(R), B * C, L, act, _lib.ptr(seed), keep, _lib.ptr(dx), st),
+                           "affine_act_dropout_bwd_apply")
+            else:
+                _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
+                                                         _lib.ptr(R), B * C, L, act, _lib.ptr(dx), st), "affine_act_bwd_apply")
         dgw, dgb = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2])   # d norm.weight, d norm.bias
         def back(g, shape):   # the gradient of a broadcast factor: summed over exactly the dimensions it was spread over
             shape = tuple(int(d) for d in shape)
@@ -124,7 +144,7 @@ class _AdaGNAct(torch.autograd.Function):
             return g.sum_to_size(core if core else (1,)).reshape(shape)
         dfac = back(dfac, f_shape) if has_f and ctx.needs_input_grad[3] else None
         dbias = back(dbias, b_shape) if has_b and ctx.needs_input_grad[4] else None
-        return dx, dgw, dgb, dfac, dbias, None, None, None
+        return dx, dgw, dgb, dfac, dbias, None, None, None, None
 
 
 class _AdaGNActMax(torch.autograd.Function):
@@ -207,9 +227,22 @@ def adagn_act_max(x, norm, factor=None, bias=None, act=True):
     return _AdaGNActMax.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act))
 
 
-def adagn_act(x, norm, factor=None, bias=None, act=True):
-    """act(GroupNorm(x) * factor + bias); factor / bias [B, C] (or broadcastable views of it) or None."""
-    return _AdaGNAct.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act))
+def adagn_act(x, norm, factor=None, bias=None, act=True, dropout_p=0.0):
+    """dropout(act(GroupNorm(x) * factor + bias), dropout_p); factor / bias [B, C] (or broadcastable views of it) or None."""
+    return _AdaGNAct.apply(x, norm.weight, norm.bias, factor, bias, int(norm.num_groups), float(norm.eps), bool(act),
+                           float(dropout_p))
+
+
+def fusable_dropout(layers, i):
+    """the keep-side probability p of an nn.Dropout at layers[i] that the activation pass in front of it can take over (0.0: there
+    is none / it is the identity now / p = 1, which stays with the module), and how many layers that consumes"""
+    if i < len(layers) and type(layers[i]) is torch.nn.Dropout:
+        d = layers[i]
+        if not d.training or d.p <= 0.0:
+            return 0.0, 1     # identity: skipped
+        if d.p < 1.0 and DROPOUT_FUSED:
+            return float(d.p), 1
+    return 0.0, 0
 
 
 class _SE3d(torch.autograd.Function):

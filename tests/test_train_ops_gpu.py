@@ -375,3 +375,82 @@ def test_sa_mlp_training_pools_inside_the_last_activation():
     assert (gx - x.grad).abs().max().item() <= 1e-4 * x.grad.abs().max().item()
     for a, p in zip(gws, mlp.parameters()):
         assert (a - p.grad).abs().max().item() <= 2e-4 * max(p.grad.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("shape,p", [((4, 32, 16, 16, 16), 0.1), ((3, 16, 1001), 0.35), ((2, 64, 8, 8, 8), 0.5)])
+def test_adagn_act_with_dropout_inside_the_pass(shape, p):
+    """train_ops.adagn_act(..., dropout_p=p) == nn.Dropout(p) behind AdaGN + Swish (reference pvcnn2_ada.py:211-222) with the mask
+    regenerated from a device seed in all three passes (csrc/norm_train.hip drop4): kept elements are the dropout-free output / keep,
+    the keep rate is 1 - p, and every gradient equals autograd through (dropout-free op) * that same mask."""
+    from lion_amd import train_ops
+    torch.manual_seed(11)
+    B, C = shape[:2]
+    norm = torch.nn.GroupNorm(8, C).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.3, 0.3)
+    x = (torch.randn(*shape, device="cuda") * 1.3 + 0.2).requires_grad_(True)
+    factor = (1.0 + 0.3 * torch.randn(B, C, device="cuda")).requires_grad_(True)
+    bias = (0.3 * torch.randn(B, C, device="cuda")).requires_grad_(True)
+    gy = torch.randn(*shape, device="cuda")
+    leaves = (x, norm.weight, norm.bias, factor, bias)
+    y = train_ops.adagn_act(x, norm, factor, bias, act=True, dropout_p=p)
+    got = torch.autograd.grad(y, leaves, gy)
+    y0 = train_ops.adagn_act(x, norm, factor, bias, act=True)
+    keep = 1.0 - p
+    kept = y != 0
+    n = y.numel()
+    rate = kept.float().mean().item()
+    assert abs(rate - keep) < 5.0 * (keep * p / n) ** 0.5 + 1e-4, (rate, keep)       # swish(a) == 0 only at a == 0: negligible
+    assert (y[kept] - y0.detach()[kept] / keep).abs().max().item() <= 1e-6 * y0.abs().max().item()
+    mask = kept.float() / keep
+    want = torch.autograd.grad(y0 * mask, leaves, gy)
+    for name, g, w in zip(("dx", "dgw", "dgb", "dfactor", "dbias"), got, want):
+        assert (g - w).abs().max().item() <= 2e-5 * max(w.abs().max().item(), 1e-3), name
+    # a second call draws another mask; the rows are not copies of each other
+    y2 = train_ops.adagn_act(x, norm, factor, bias, act=True, dropout_p=p)
+    assert ((y2 != 0) != kept).float().mean().item() > 0.5 * 2 * keep * p
+    flat = kept.reshape(B * C, -1)
+    assert (flat[0] != flat[1]).any()
+
+
+def test_dropout_mask_changes_between_graph_replays():
+    """the seed is drawn by torch's generator on the device inside the captured region: every replay of a captured step masks anew"""
+    from lion_amd import train_ops
+    norm = torch.nn.GroupNorm(8, 32).cuda()
+    x = torch.randn(2, 32, 8, 8, 8, device="cuda", requires_grad=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        train_ops.adagn_act(x, norm, None, None, act=True, dropout_p=0.5)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = train_ops.adagn_act(x, norm, None, None, act=True, dropout_p=0.5)
+    g.replay()
+    a = (y != 0).clone()
+    g.replay()
+    b = (y != 0).clone()
+    frac = (a != b).float().mean().item()
+    assert 0.4 < frac < 0.6, frac
+
+
+def test_training_walks_fold_dropout_into_the_activation_pass():
+    """both layer walks (pvcnn2_ada.run_layers, pvcnn2.run_layers) hand [GroupNorm/AdaGN, Swish, Dropout] to ONE op in training and
+    skip the Dropout module in eval mode; nn.Dropout.forward itself never runs"""
+    from unittest import mock
+    from lion_amd import train_ops
+    from lion_amd.models import pvcnn2
+    from lion_amd.models.pvcnn2_ada import Swish
+    layers = torch.nn.ModuleList([torch.nn.GroupNorm(8, 32), Swish(), torch.nn.Dropout(0.25)]).cuda()
+    x = torch.randn(2, 32, 8, 8, 8, device="cuda", requires_grad=True)
+    with mock.patch.object(torch.nn.Dropout, "forward", side_effect=AssertionError("nn.Dropout ran")):
+        layers.train()
+        y = pvcnn2.run_layers(layers, x)
+        rate = (y != 0).float().mean().item()
+        assert abs(rate - 0.75) < 0.02, rate
+        layers.eval()
+        y_eval = pvcnn2.run_layers(layers, x)
+        assert (y_eval != 0).float().mean().item() > 0.999
+    ref = train_ops.adagn_act(x, layers[0], None, None, act=True)
+    assert torch.equal(y_eval, ref)
