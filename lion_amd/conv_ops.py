@@ -179,6 +179,8 @@ class _Conv3dK3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
+        from . import train_ops
+        gb_tagged = train_ops.tagged_channel_sum(gy, weight.shape[0])   # from the AdaGN behind this convolution, if it made gy
         gy = gy.contiguous()
         cout, cin = weight.shape[:2]
         r = x.shape[2]
@@ -205,7 +207,9 @@ class _Conv3dK3(torch.autograd.Function):
                 gw = conv3d_k3_wgrad(xp, gy, (cout, cin + pad, 3, 3, 3))[:, :cin].contiguous()
             else:
                 gw = conv3d_k3_wgrad(x, gy, weight.shape)
-            if want_gb:
+            if want_gb and gb_tagged is not None:
+                gb = gb_tagged   # sum of dx over batch and voxels, a by-product of the AdaGN backward (train_ops.tag_channel_sum)
+            elif want_gb:
                 # one streaming pass (row sums per (b, c), then a [B, C] -> [C] sum) instead of ATen's strided
                 # reduction over dims (0, 2, 3, 4): 240-277 us -> ~60 us at [32, 64, 32^3]
                 from . import fused_ops

@@ -180,24 +180,27 @@ __global__ __launch_bounds__(256) void affine_act_bwd_apply_kernel(const float *
   }
 }
 
-// dgw[c] = sum_b pw[b][c][0], dgb[c] = sum_b pw[b][c][1] in ascending b (what pw.sum(0) + two strided copies did in three ATen
-// launches per AdaGN layer and backward)
+// dgw[c] = sum_b pw[b][c][0], dgb[c] = sum_b pw[b][c][1], dxs[c] = sum_b pw[b][c][2] in ascending b (what pw.sum(0) + strided copies
+// did in three ATen launches per AdaGN layer and backward)
 __global__ __launch_bounds__(256) void pw_batch_sum_kernel(const float *__restrict__ pw, int B, int C, float *__restrict__ dgw,
-                                                           float *__restrict__ dgb) {
+                                                           float *__restrict__ dgb, float *__restrict__ dxs) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int b0 = 0; b0 < B; b0 += 16) {   // 16 loads in flight (one dependent round trip per sample made this a 10-us kernel), summed in order
-    float2 v[16];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 16) {   // 48 loads in flight (one dependent round trip per sample made this a 10-us kernel), summed in order
+    float v[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float *p = pw + ((size_t)min(b0 + k, B - 1) * C + c) * 3;
+      v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2];
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k)
-      v[k] = b0 + k < B ? *reinterpret_cast<const float2 *>(pw + ((size_t)(b0 + k) * C + c) * 2) : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (b0 + k < B) { s0 += v[k].x; s1 += v[k].y; }
+      if (b0 + k < B) { s0 += v[k][0]; s1 += v[k][1]; s2 += v[k][2]; }
   }
   dgw[c] = s0;
   dgb[c] = s1;
+  if (dxs) dxs[c] = s2;
 }
 
 // ---- round 6: y[row][m] = max_u act(A x[row][m][u] + Bs) -- the set-abstraction pooling behind the last AdaGN + Swish of a
@@ -316,7 +319,8 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
                                          const float *__restrict__ rstd, const float *__restrict__ gw,
                                          const float *__restrict__ gb, const float *__restrict__ fac, int fs, int C,
                                          int G, int L, float *__restrict__ Q, float *__restrict__ R,
-                                         float *__restrict__ dfac, float *__restrict__ dbias, float *__restrict__ pw) {
+                                         float *__restrict__ dfac, float *__restrict__ dbias, float *__restrict__ pw,
+                                         const float *__restrict__ A, const double *__restrict__ xstats) {
   extern __shared__ double sh[]; // [2 C]: coef S1, coef T
   const int b = blockIdx.x, c = threadIdx.x, cpg = C / G;
   double s1 = 0.0, T = 0.0, m = 0.0, rs = 0.0, f = 1.0, w = 0.0;
@@ -340,8 +344,13 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
   R[(size_t)b * C + c] = (float)(-rs * rs * m2);
   if (dfac) dfac[(size_t)b * C + c] = (float)(w * T + (double)gb[c] * s1);
   if (dbias) dbias[(size_t)b * C + c] = (float)s1;
-  pw[((size_t)b * C + c) * 2] = (float)(f * T);
-  pw[((size_t)b * C + c) * 2 + 1] = (float)(f * s1);
+  pw[((size_t)b * C + c) * 3] = (float)(f * T);
+  pw[((size_t)b * C + c) * 3 + 1] = (float)(f * s1);
+  // sum over the row of dx = A da + Q + R x (what lion_affine_act_bwd_apply writes): the bias gradient of the convolution that
+  // produced x, per sample -- a [B, C] by-product here, a pass over the 268-MB gradient when taken from dx itself
+  const double q = -rs * m1 + rs * rs * m * m2, r = -rs * rs * m2;
+  pw[((size_t)b * C + c) * 3 + 2] =
+      (A && xstats) ? (float)((double)A[(size_t)b * C + c] * s1 + (double)L * q + r * xstats[((size_t)b * C + c) * 2]) : 0.f;
 }
 
 } // namespace
@@ -484,12 +493,12 @@ int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, 
 
 int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
                            const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
-                           float *dbias, float *pw, lionStream_t stream) {
+                           float *dbias, float *pw, const float *A, const double *xstats, lionStream_t stream) {
   if (!S || !mean || !rstd || !gw || !gb || !Q || !R || !pw || B <= 0 || C <= 0 || G <= 0 || C % G || L <= 0) return LION_EINVAL;
   if (C > 1024) return LION_EUNSUPPORTED;
   const int T = (C + 63) / 64 * 64;
   gn_train_bwd_fold_kernel<<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
-      S, mean, rstd, gw, gb, fac, fac_stride, C, G, L, Q, R, dfac, dbias, pw);
+      S, mean, rstd, gw, gb, fac, fac_stride, C, G, L, Q, R, dfac, dbias, pw, A, xstats);
   LION_LAUNCH_CHECK();
   return 0;
 }
@@ -610,9 +619,9 @@ int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *
 }
 #undef LION_AAM_DISPATCH
 
-int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, lionStream_t stream) {
+int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, float *dxs, lionStream_t stream) {
   if (!pw || !dgw || !dgb || B <= 0 || C <= 0) return LION_EINVAL;
-  pw_batch_sum_kernel<<<lion_cdiv(C, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(pw, B, C, dgw, dgb);
+  pw_batch_sum_kernel<<<lion_cdiv(C, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(pw, B, C, dgw, dgb, dxs);
   LION_LAUNCH_CHECK();
   return 0;
 }

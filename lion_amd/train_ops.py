@@ -54,15 +54,34 @@ def _rowview(t, B, C):
     return t, int(t.stride(0))
 
 
-def _param_grads(pw, want_w, want_b):
-    """pw [B, C, 2] (per-sample terms of the GroupNorm weight / bias gradients) -> (d weight [C], d bias [C]) in one launch"""
-    if not (want_w or want_b):
-        return None, None
+def _param_grads(pw, want_w, want_b, want_dxs=False):
+    """pw [B, C, 3] (per-sample terms of the GroupNorm weight / bias gradients and of the row sums of dx) -> (d weight [C],
+    d bias [C], sum over batch and positions of dx [C] or None) in one launch"""
+    if not (want_w or want_b or want_dxs):
+        return None, None, None
     B, C = pw.shape[:2]
     dgw, dgb = torch.empty(C, device=pw.device, dtype=torch.float32), torch.empty(C, device=pw.device, dtype=torch.float32)
-    _lib.check(_lib.load().lion_gn_train_param_grads(_lib.ptr(pw), B, C, _lib.ptr(dgw), _lib.ptr(dgb),
+    dxs = torch.empty(C, device=pw.device, dtype=torch.float32) if want_dxs else None
+    _lib.check(_lib.load().lion_gn_train_param_grads(_lib.ptr(pw), B, C, _lib.ptr(dgw), _lib.ptr(dgb), _lib.ptr(dxs),
                                                      _lib.stream_ptr(pw.device)), "gn_train_param_grads")
-    return (dgw if want_w else None), (dgb if want_b else None)
+    return (dgw if want_w else None), (dgb if want_b else None), dxs
+
+
+CHANNEL_SUM_TAG = "_lion_channel_sum"
+
+
+def tag_channel_sum(dx, dxs):
+    """hand the consumer of `dx` (the backward of the convolution that produced the normalised tensor) the sum of dx over batch and
+    positions -- its bias gradient -- as an attribute of the gradient tensor, with the tensor's version: an in-place accumulation of
+    another gradient into dx (fan-out of the convolution's output) bumps the version and voids the tag."""
+    setattr(dx, CHANNEL_SUM_TAG, (dxs, dx._version))
+
+
+def tagged_channel_sum(g, channels):
+    tag = getattr(g, CHANNEL_SUM_TAG, None)
+    if tag is None or tag[1] != g._version or tuple(tag[0].shape) != (channels,) or g.shape[1] != channels:
+        return None
+    return tag[0]
 
 
 class _AdaGNAct(torch.autograd.Function):
@@ -94,7 +113,7 @@ class _AdaGNAct(torch.autograd.Function):
         else:
             seed = x.new_empty(0)
             _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(A), _lib.ptr(Bs), B * C, L, int(act), _lib.ptr(y), st), "affine_act")
-        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0), seed)
+        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0), seed, stats)
         ctx.meta = (groups, int(act), factor is not None, bias is not None, fs,
                     None if factor is None else factor.shape, None if bias is None else bias.shape, keep)
         return y
@@ -103,7 +122,7 @@ class _AdaGNAct(torch.autograd.Function):
     @once_differentiable   # raw kernels: a double backward must raise, not silently treat these gradients as constants
     def backward(ctx, gy):
         lib = _lib.load()
-        x, A, Bs, mean, rstd, gwc, gbc, f, seed = ctx.saved_tensors
+        x, A, Bs, mean, rstd, gwc, gbc, f, seed, stats = ctx.saved_tensors
         groups, act, has_f, has_b, fs, f_shape, b_shape, keep = ctx.meta
         drop = seed.numel() > 0
         gy = gy.contiguous()
@@ -121,10 +140,11 @@ class _AdaGNAct(torch.autograd.Function):
         Q, R = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
         dfac = torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None
         dbias = torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None
-        pw = torch.empty(B, C, 2, device=dev, dtype=torch.float32)
+        pw = torch.empty(B, C, 3, device=dev, dtype=torch.float32)
         _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
                                               _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
-                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), st), "gn_train_bwd_fold")
+                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), _lib.ptr(A), _lib.ptr(stats), st),
+                   "gn_train_bwd_fold")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -135,7 +155,10 @@ class _AdaGNAct(torch.autograd.Function):
             else:
                 _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
                                                          _lib.ptr(R), B * C, L, act, _lib.ptr(dx), st), "affine_act_bwd_apply")
-        dgw, dgb = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2])   # d norm.weight, d norm.bias
+        # d norm.weight, d norm.bias; for a voxel grid also the sum of dx per channel = the bias gradient of the Conv3d in front
+        dgw, dgb, dxs = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2], dx is not None and x.dim() == 5)
+        if dxs is not None:
+            tag_channel_sum(dx, dxs)
         def back(g, shape):   # the gradient of a broadcast factor: summed over exactly the dimensions it was spread over
             shape = tuple(int(d) for d in shape)
             core = shape
@@ -195,17 +218,17 @@ class _AdaGNActMax(torch.autograd.Function):
         Q, R = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
         dfac = torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None
         dbias = torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None
-        pw = torch.empty(B, C, 2, device=dev, dtype=torch.float32)
+        pw = torch.empty(B, C, 3, device=dev, dtype=torch.float32)
         _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
                                               _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
-                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), st), "gn_train_bwd_fold")
+                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), None, None, st), "gn_train_bwd_fold")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _lib.check(lib.lion_affine_act_max_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(Q),
                                                          _lib.ptr(R), B * C, M, U, act, _lib.ptr(dx), st),
                        "affine_act_max_bwd_apply")
-        dgw, dgb = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2])   # d norm.weight, d norm.bias
+        dgw, dgb, _ = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2])   # d norm.weight, d norm.bias
 
         def back(g, shape):
             shape = tuple(int(d) for d in shape)

@@ -454,3 +454,40 @@ def test_training_walks_fold_dropout_into_the_activation_pass():
         assert (y_eval != 0).float().mean().item() > 0.999
     ref = train_ops.adagn_act(x, layers[0], None, None, act=True)
     assert torch.equal(y_eval, ref)
+
+
+def test_conv3d_bias_gradient_rides_on_the_adagn_backward():
+    """Conv3d -> AdaGN -> Swish -> Dropout: the convolution's bias gradient (sum of its output gradient over batch and voxels) is a
+    by-product of the AdaGN backward's [B, C] algebra (train_ops.tag_channel_sum), not a pass over the gradient; with a second
+    consumer of the convolution's output autograd accumulates into the tagged tensor and the tag must be ignored."""
+    from unittest import mock
+    from lion_amd import conv_ops, fused_ops, train_ops
+    torch.manual_seed(5)
+    conv = torch.nn.Conv3d(16, 32, 3, padding=1).cuda()
+    norm = torch.nn.GroupNorm(8, 32).cuda()
+    x = torch.randn(3, 16, 8, 8, 8, device="cuda")
+    factor = 1.0 + 0.2 * torch.randn(3, 32, device="cuda")
+    bias = 0.2 * torch.randn(3, 32, device="cuda")
+    gy = torch.randn(3, 32, 8, 8, 8, device="cuda")
+
+    def run(fan_out, p):
+        conv.zero_grad()
+        y = conv_ops.conv3d_module(conv, x)
+        z = train_ops.adagn_act(y, norm, factor, bias, act=True, dropout_p=p)
+        loss = (z * gy).sum() + ((y * y).sum() * 0.01 if fan_out else 0.0)
+        seen = []
+        orig = conv_ops._Conv3dK3.backward
+
+        def spy(ctx, g):
+            seen.append(g.detach().clone())
+            return orig(ctx, g)
+        with mock.patch.object(conv_ops._Conv3dK3, "backward", staticmethod(spy)), \
+                mock.patch.object(fused_ops, "row_stats", wraps=fused_ops.row_stats) as rs:
+            loss.backward()
+        want = seen[0].double().sum((0, 2, 3, 4))
+        err = (conv.bias.grad.double() - want).abs().max().item()
+        assert err <= 2e-5 * max(want.abs().max().item(), 1e-3), (fan_out, p, err)
+        return rs.call_count
+    assert run(False, 0.0) == 0          # taken from the tag: no pass over the gradient
+    assert run(False, 0.3) == 0
+    assert run(True, 0.0) == 1           # accumulated gradient: the tag is void, the streaming pass runs
