@@ -441,7 +441,7 @@ int lion_pwconv_wgrad(const float *x, const float *gy, int B, int Cin, int Cout,
  * into Q, R f32[rows] (group means of the normalisation's gradient) and the parameter gradients;
  * lion_affine_act_bwd_apply writes dx = A da + Q + R x.  (csrc/norm_train.hip, lion_amd/train_ops.py) */
 /* the [B, C] scalar algebra of both directions (double inside).  fac / bias f32[B, *] with row strides (views of the
- * [B, 2C] AdaGN projection) or NULL (plain GroupNorm); dfac / dbias may be NULL; pw f32[B,C,3] = per-sample terms of the
+ * [B, 2C] AdaGN projection) or NULL (plain GroupNorm); dfac / dbias f32[B, *] with row stride d_stride (the halves of one [B, 2C] buffer, or C) may be NULL; pw f32[B,C,3] = per-sample terms of the
  * GroupNorm weight / bias gradients (the caller sums them over the batch). */
 int lion_gn_train_fold(const float *stats, const float *gw, const float *gb, const float *fac, int fac_stride,
                        const float *bias, int bias_stride, int B, int C, int G, int L, float eps, float *A, float *Bs,
@@ -454,7 +454,7 @@ int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, 
                          float *Bs, float *mean, float *rstd, lionStream_t stream);
 int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
                            const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
-                           float *dbias, float *pw, const float *A, const double *xstats, lionStream_t stream);
+                           float *dbias, int d_stride, float *pw, const float *A, const double *xstats, lionStream_t stream);
 /* pw f32[B,C,3]: the per-sample terms of {d GroupNorm weight, d GroupNorm bias, sum over the row of dx}.  The third needs A (of the
  * forward fold) and xstats = the forward's lion_row_stats64 result (column 0 = row sums of x); both NULL: it is written as 0.
  * Summed over the batch it is the BIAS GRADIENT of the convolution that produced x (sum_l dx = A S1 + L Q + R sum_l x): Conv3d layers

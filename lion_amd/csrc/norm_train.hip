@@ -319,7 +319,7 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
                                          const float *__restrict__ rstd, const float *__restrict__ gw,
                                          const float *__restrict__ gb, const float *__restrict__ fac, int fs, int C,
                                          int G, int L, float *__restrict__ Q, float *__restrict__ R,
-                                         float *__restrict__ dfac, float *__restrict__ dbias, float *__restrict__ pw,
+                                         float *__restrict__ dfac, float *__restrict__ dbias, int ds, float *__restrict__ pw,
                                          const float *__restrict__ A, const double *__restrict__ xstats) {
   extern __shared__ double sh[]; // [2 C]: coef S1, coef T
   const int b = blockIdx.x, c = threadIdx.x, cpg = C / G;
@@ -342,8 +342,8 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
   const double cnt = (double)cpg * (double)L, m1 = a1 / cnt, m2 = a2 / cnt;
   Q[(size_t)b * C + c] = (float)(-rs * m1 + rs * rs * m * m2);
   R[(size_t)b * C + c] = (float)(-rs * rs * m2);
-  if (dfac) dfac[(size_t)b * C + c] = (float)(w * T + (double)gb[c] * s1);
-  if (dbias) dbias[(size_t)b * C + c] = (float)s1;
+  if (dfac) dfac[(size_t)b * ds + c] = (float)(w * T + (double)gb[c] * s1);   // ds: row stride (the two may be the halves of one [B, 2C] buffer)
+  if (dbias) dbias[(size_t)b * ds + c] = (float)s1;
   pw[((size_t)b * C + c) * 3] = (float)(f * T);
   pw[((size_t)b * C + c) * 3 + 1] = (float)(f * s1);
   // sum over the row of dx = A da + Q + R x (what lion_affine_act_bwd_apply writes): the bias gradient of the convolution that
@@ -493,12 +493,13 @@ int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, 
 
 int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
                            const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
-                           float *dbias, float *pw, const float *A, const double *xstats, lionStream_t stream) {
+                           float *dbias, int d_stride, float *pw, const float *A, const double *xstats, lionStream_t stream) {
   if (!S || !mean || !rstd || !gw || !gb || !Q || !R || !pw || B <= 0 || C <= 0 || G <= 0 || C % G || L <= 0) return LION_EINVAL;
+  if ((dfac || dbias) && d_stride < C) return LION_EINVAL;
   if (C > 1024) return LION_EUNSUPPORTED;
   const int T = (C + 63) / 64 * 64;
   gn_train_bwd_fold_kernel<<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
-      S, mean, rstd, gw, gb, fac, fac_stride, C, G, L, Q, R, dfac, dbias, pw, A, xstats);
+      S, mean, rstd, gw, gb, fac, fac_stride, C, G, L, Q, R, dfac, dbias, d_stride, pw, A, xstats);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -65,7 +65,8 @@ class StylePlan:
             b = torch.cat([m.emd.bias for m in mods], 0)
             e = torch.nn.functional.linear(style, w, b)
             parts = torch.split(e, [2 * m.n_channel for m in mods], dim=1)
-            views = {id(m): tuple(p_.chunk(2, 1)) for m, p_ in zip(mods, parts)}
+            from .. import train_ops
+            views = {id(m): train_ops.halves(p_) for m, p_ in zip(mods, parts)}   # chunk(2, 1) whose backward needs no cat
             prev, _ACTIVE = _ACTIVE, (style, views)
             try:
                 yield

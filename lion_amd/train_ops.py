@@ -67,6 +67,48 @@ def _param_grads(pw, want_w, want_b, want_dxs=False):
     return (dgw if want_w else None), (dgb if want_b else None), dxs
 
 
+def _affine_grad_buffers(B, C, has_f, has_b, dev):
+    """(d factor, d bias, row stride): with both wanted, the two halves of ONE [B, 2C] buffer -- `halves` below hands that
+    buffer on as the gradient of the [B, 2C] AdaGN projection without a cat"""
+    if has_f and has_b:
+        d = torch.empty(B, 2 * C, device=dev, dtype=torch.float32)
+        return d[:, :C], d[:, C:], 2 * C
+    return (torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None,
+            torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None, C)
+
+
+class _Halves(torch.autograd.Function):
+    """e [B, 2C] -> (e[:, :C], e[:, C:]), as `chunk(2, 1)`; backward: when the two gradients are the halves of one buffer (what
+    the AdaGN ops above produce) that buffer IS the gradient -- chunk's backward cats them (122 launches per VAE step)."""
+
+    @staticmethod
+    def forward(ctx, e):
+        c = e.shape[1] // 2
+        ctx.shape = tuple(e.shape)
+        return e.narrow(1, 0, c), e.narrow(1, c, c)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        B, C2 = ctx.shape
+        C = C2 // 2
+        if (ga is not None and gb is not None and ga.dtype == gb.dtype == torch.float32 and tuple(ga.shape) == tuple(gb.shape) == (B, C)
+                and ga.stride() == gb.stride() == (C2, 1) and gb.data_ptr() == ga.data_ptr() + 4 * C
+                and ga.untyped_storage().data_ptr() == gb.untyped_storage().data_ptr()):
+            return ga.as_strided((B, C2), (C2, 1))
+        if ga is None and gb is None:
+            return None
+        ga = torch.zeros_like(gb) if ga is None else ga
+        gb = torch.zeros_like(ga) if gb is None else gb
+        return torch.cat([ga, gb], 1)
+
+
+def halves(e):
+    """the (factor, bias) halves of an AdaGN projection [B, 2C] (models/adagn.py) for the training ops"""
+    if e.dim() != 2 or e.shape[1] % 2:
+        return tuple(e.chunk(2, 1))
+    return _Halves.apply(e)
+
+
 CHANNEL_SUM_TAG = "_lion_channel_sum"
 
 
@@ -138,13 +180,12 @@ class _AdaGNAct(torch.autograd.Function):
             _lib.check(lib.lion_affine_act_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, L, act,
                                                      _lib.ptr(S), st), "affine_act_bwd_stats")
         Q, R = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
-        dfac = torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None
-        dbias = torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None
+        dfac, dbias, dstride = _affine_grad_buffers(B, C, has_f, has_b, dev)
         pw = torch.empty(B, C, 3, device=dev, dtype=torch.float32)
         _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
                                               _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
-                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), _lib.ptr(A), _lib.ptr(stats), st),
-                   "gn_train_bwd_fold")
+                                              _lib.ptr(dfac), _lib.ptr(dbias), dstride, _lib.ptr(pw), _lib.ptr(A), _lib.ptr(stats),
+                                              st), "gn_train_bwd_fold")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -216,12 +257,12 @@ class _AdaGNActMax(torch.autograd.Function):
         _lib.check(lib.lion_affine_act_max_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, M, U, act,
                                                      _lib.ptr(S), st), "affine_act_max_bwd_stats")
         Q, R = torch.empty(B, C, device=dev, dtype=torch.float32), torch.empty(B, C, device=dev, dtype=torch.float32)
-        dfac = torch.empty(B, C, device=dev, dtype=torch.float32) if has_f else None
-        dbias = torch.empty(B, C, device=dev, dtype=torch.float32) if has_b else None
+        dfac, dbias, dstride = _affine_grad_buffers(B, C, has_f, has_b, dev)
         pw = torch.empty(B, C, 3, device=dev, dtype=torch.float32)
         _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
                                               _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
-                                              _lib.ptr(dfac), _lib.ptr(dbias), _lib.ptr(pw), None, None, st), "gn_train_bwd_fold")
+                                              _lib.ptr(dfac), _lib.ptr(dbias), dstride, _lib.ptr(pw), None, None, st),
+                   "gn_train_bwd_fold")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

@@ -491,3 +491,33 @@ def test_conv3d_bias_gradient_rides_on_the_adagn_backward():
     assert run(False, 0.0) == 0          # taken from the tag: no pass over the gradient
     assert run(False, 0.3) == 0
     assert run(True, 0.0) == 1           # accumulated gradient: the tag is void, the streaming pass runs
+
+
+def test_adagn_projection_halves_backward_needs_no_cat():
+    """train_ops.halves == chunk(2, 1) on the [B, 2C] AdaGN projection; the AdaGN ops write d factor / d bias into the two halves of
+    one buffer and the backward of `halves` passes that buffer on (no aten::cat), with the same numbers as the chunk form"""
+    from unittest import mock
+    from lion_amd import train_ops
+    torch.manual_seed(9)
+    B, C = 4, 64
+    norm = torch.nn.GroupNorm(8, C).cuda()
+    x = torch.randn(B, C, 500, device="cuda", requires_grad=True)
+    gy = torch.randn(B, C, 500, device="cuda")
+    e = torch.randn(B, 3 * 2 * C, device="cuda", requires_grad=True)       # three layers' projections side by side
+    grads = []
+    for split in (train_ops.halves, lambda t: tuple(t.chunk(2, 1))):
+        part = torch.split(e, [2 * C] * 3, dim=1)[1]
+        factor, bias = split(part)
+        y = train_ops.adagn_act(x, norm, factor, bias, act=True)
+        with mock.patch.object(torch, "cat", wraps=torch.cat) as cat:
+            g = torch.autograd.grad(y, (e, x), gy)
+        grads.append(g)
+        assert cat.call_count == 0
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    # one half unused: the general path (zeros + cat) still gives chunk's gradient
+    f2, _ = train_ops.halves(e[:, :2 * C])
+    g1, = torch.autograd.grad((f2 * 2.0).sum(), e)
+    f3, _ = e[:, :2 * C].chunk(2, 1)
+    g2, = torch.autograd.grad((f3 * 2.0).sum(), e)
+    assert torch.equal(g1, g2)

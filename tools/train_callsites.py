@@ -11,6 +11,7 @@ from lion_amd.dist import BucketedGradAverager
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--mode", default="vae"); ap.add_argument("--B", type=int, default=32); ap.add_argument("--rows", type=int, default=60)
+ap.add_argument("--op", default=None, help="list EVERY call of this aten op (e.g. aten::copy_, aten::clone), device time or not: memcpy-backed copies carry none")
 a = ap.parse_args()
 dev = torch.device("cuda"); torch.manual_seed(0)
 x = torch.randn(a.B, 2048, 3, device=dev)
@@ -35,7 +36,10 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 tot_n = tot_t = 0
 for e in prof.events():
     dt = getattr(e, "self_device_time_total", 0) or getattr(e, "self_cuda_time_total", 0)
-    if not e.name.startswith("aten::") or dt <= 0: continue
+    if not e.name.startswith("aten::"): continue
+    if a.op is not None:
+        if e.name != a.op: continue
+    elif dt <= 0: continue
     site = "?"
     for fr in (e.stack or []):
         if "lion_amd/" in fr and "torch/" not in fr:
