@@ -18,14 +18,16 @@ def run_layers(layers, x, reduce_max=False):
     (and the Swish behind it, when there is one) is ONE differentiable op on the library's kernels, as in the adaptive
     blocks (pvcnn2_ada.run_layers; lion_amd/train_ops.py with factor = bias = None), SE3d is train_ops.se3d, and a list that
     ends in GroupNorm + Swish on [B, C, M, U] can take the SA modules' max over the neighbours into the same op
-    (reduce_max).  ATen runs each GroupNorm + Swish of the style encoder as 4 launches forward and 9 backward."""
+    (reduce_max).  ATen runs each GroupNorm + Swish of the style encoder as 4 launches forward and 9 backward.
+    These blocks have no separate fused inference path: without autograd (the frozen VAE's encode inside a prior training
+    step) the same ops run, forward only."""
     from .. import train_ops
     i, n = 0, len(layers)
     while i < n:
         layer = layers[i]
-        if isinstance(layer, nn.GroupNorm) and train_ops.usable(x) and layer.num_channels <= 1024 and layer.affine:
+        if isinstance(layer, nn.GroupNorm) and train_ops.usable(x, False) and layer.num_channels <= 1024 and layer.affine:
             fused_act = i + 1 < n and isinstance(layers[i + 1], Swish)
-            if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x):
+            if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x, False):
                 return train_ops.adagn_act_max(x, layer, None, None, act=fused_act)   # pooled: [B, C, M]
             i += 2 if fused_act else 1
             drop_p, used = train_ops.fusable_dropout(layers, i) if fused_act else (0.0, 0)
@@ -34,7 +36,7 @@ def run_layers(layers, x, reduce_max=False):
             continue
         if isinstance(layer, nn.Conv3d):
             x = conv3d_module(layer, x)
-        elif isinstance(layer, SE3d) and train_ops.se3d_trainable(layer, x):
+        elif isinstance(layer, SE3d) and train_ops.se3d_trainable(layer, x, False):
             x = train_ops.se3d(layer, x)
         else:
             x = layer(x)

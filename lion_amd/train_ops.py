@@ -24,8 +24,10 @@ PWCONV_MIN_COLS = int(os.environ.get("LION_TRAIN_PWCONV_MIN_COLS", "512"))
 DROPOUT_FUSED = os.environ.get("LION_TRAIN_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind AdaGN + Swish inside the activation pass
 
 
-def usable(x) -> bool:
-    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+def usable(x, need_grad=True) -> bool:
+    """need_grad=False: also without autograd (the frozen VAE's style encoder inside a prior training step, an encode at
+    inference) -- for blocks that have no fused inference path of their own (models/pvcnn2.py); the forward kernels are the same"""
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and (torch.is_grad_enabled() or not need_grad)
             and not torch.is_autocast_enabled() and x.dim() >= 3 and x[0, 0].numel() >= 1)
 
 
@@ -282,8 +284,8 @@ class _AdaGNActMax(torch.autograd.Function):
         return dx, dgw, dgb, dfac, dbias, None, None, None
 
 
-def adagn_act_max_usable(x) -> bool:
-    return usable(x) and x.dim() == 4 and x.shape[3] in (8, 16, 32, 64) and x.shape[0] * x.shape[1] <= 65535
+def adagn_act_max_usable(x, need_grad=True) -> bool:
+    return usable(x, need_grad) and x.dim() == 4 and x.shape[3] in (8, 16, 32, 64) and x.shape[0] * x.shape[1] <= 65535
 
 
 def adagn_act_max(x, norm, factor=None, bias=None, act=True):
@@ -365,9 +367,9 @@ class _SE3d(torch.autograd.Function):
         return dx, (dw1 if ctx.needs_input_grad[1] else None), (dw2 if ctx.needs_input_grad[2] else None)
 
 
-def se3d_trainable(se, x) -> bool:
+def se3d_trainable(se, x, need_grad=True) -> bool:
     fc = getattr(se, "fc", None)
-    return (usable(x) and fc is not None and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear) and fc[0].bias is None
+    return (usable(x, need_grad) and fc is not None and len(fc) == 4 and isinstance(fc[0], torch.nn.Linear) and fc[0].bias is None
             and isinstance(fc[2], torch.nn.Linear) and fc[2].bias is None
             and fc[0].in_features <= 1024 and fc[0].out_features <= 128 and fc[2].weight.dtype == torch.float32)
 
