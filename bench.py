@@ -514,10 +514,17 @@ def train_bench(args, rank, world, dev, backend):
                 "configs[3]: train_2prior step (frozen VAE encode + global + local denoiser), car, B=256 over 8 GPUs")
     if world > 1:
         broadcast_params(params)
-    # fused=True: one multi-tensor kernel family for the whole update (same arithmetic as the reference's torch.optim.Adam;
-    # the foreach form with device-resident step counters launches ~1700 tiny bias-correction kernels per step)
-    fused_adam = os.environ.get("LION_BENCH_ADAM_FUSED", "1") != "0"
-    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), capturable=use_graph, fused=fused_adam)
+    # the optimizer of the reference's trainers (utils/utils.py:115-121: optim.Adam): lion_amd.optim.Adam = the same arithmetic with
+    # the whole update in ONE launch through a device pointer table.  LION_BENCH_ADAM=torch: ATen's fused multi-tensor Adam (36
+    # tensors per launch: 25 launches for the VAE's 867 tensors; its foreach form with device-resident step counters launches
+    # ~1700 tiny bias-correction kernels per step)
+    own_adam = os.environ.get("LION_BENCH_ADAM", "own") != "torch"
+    if own_adam:
+        from lion_amd.optim import Adam
+        opt = Adam(params, lr=1e-4, betas=(0.9, 0.99))
+    else:
+        opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), capturable=use_graph,
+                               fused=os.environ.get("LION_BENCH_ADAM_FUSED", "1") != "0")
     averager = BucketedGradAverager(params)
     torch.manual_seed(1234 + rank)
     x = torch.randn(B, 2048, 3, device=dev)
@@ -602,6 +609,7 @@ def train_bench(args, rank, world, dev, backend):
                "dtype": dt, "data": "synthetic",
                "config": {"workload": name, "samples_per_gpu": B, "points": 2048, "launch": launch,
                           "gradient_averaging": f"BucketedGradAverager, {len(averager.buckets)} buckets, world {world}",
+                          "optimizer": ("lion_amd.optim.Adam (one launch)" if own_adam else "torch.optim.Adam (fused multi-tensor)"),
                           "final_loss": loss_v, "strict": _fallback.strict(),
                           "vendor_library_fallbacks_total": sum(gpu_step_fallbacks.values()),
                           "vendor_library_fallbacks": gpu_step_fallbacks,

@@ -501,6 +501,17 @@ int lion_affine_act_max_bwd_stats(const float *x, const float *gy, const float *
 int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *A, const float *Bs, const float *Q,
                                   const float *R, int rows, int M, int U, int act, float *dx, lionStream_t stream);
 
+/* ---- optimizer update (training): torch.optim.Adam with L2 weight decay (reference utils/utils.py:115-121; optimizer.step() of
+ * trainers/hvae_trainer.py:150-154, train_2prior.py:405-410) over EVERY parameter tensor in one launch (csrc/optim.hip).
+ * table u64[T,5]: device addresses {param, grad, exp_avg, exp_avg_sq, step} of T float32 tensors (step: that parameter's f32 step
+ * count, incremented by the call, then used for the bias corrections); numel i32[T]; blockmap i32[blocks,2]: {tensor, chunk} per
+ * workgroup, chunks of lion_adam_chunk() elements (all three in DEVICE memory, written by the caller once per gradient layout);
+ * lr f32[1] (device).
+ * Same arithmetic as torch.optim.Adam's single-tensor path (fp32 op for op, bias corrections in double). */
+int lion_adam_chunk(void);
+int lion_adam_step(const uint64_t *table, const int32_t *numel, const int32_t *blockmap, int blocks, int tensors, const float *lr,
+                   float beta1, float beta2, float eps, float weight_decay, lionStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ VER="$($HIPCC --version 2>/dev/null | head -3)"
 OBJS=()
 PIDS=()
 KEYS=()
-for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise norm_train scatter_csr pwconv pwconv_split pwconv_wgrad skinny attention "$@"; do
+for f in voxelize devoxelize ball_query grouping sampling interpolate chamfer emd diffusion conv3d conv3d_split conv3d_wgrad pointwise norm_train scatter_csr pwconv pwconv_split pwconv_wgrad skinny attention optim "$@"; do
   [ -f "$f.hip" ] || continue
   # shellcheck disable=SC2086
   key="$( { echo "$VER $FLAGS"; cat "$f.hip" $HDRS; } | sha256sum | cut -d' ' -f1)"
