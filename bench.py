@@ -519,12 +519,17 @@ def train_bench(args, rank, world, dev, backend):
     # tensors per launch: 25 launches for the VAE's 867 tensors; its foreach form with device-resident step counters launches
     # ~1700 tiny bias-correction kernels per step)
     own_adam = os.environ.get("LION_BENCH_ADAM", "own") != "torch"
+    # ... each wrapped in the reference's EMA of the weights (utils/utils.py:134-138, common_fun_prior_train.py:47; decay 0.9999):
+    # inside the same launch here, a multiply-add per parameter behind ATen's Adam (LION_BENCH_EMA=0: without, as rounds 1-5 timed it)
+    ema_decay = 0.9999 if os.environ.get("LION_BENCH_EMA", "1") != "0" else 0.0
     if own_adam:
         from lion_amd.optim import Adam
-        opt = Adam(params, lr=1e-4, betas=(0.9, 0.99))
+        opt = Adam(params, lr=1e-4, betas=(0.9, 0.99), ema_decay=ema_decay)
     else:
         opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99), capturable=use_graph,
                                fused=os.environ.get("LION_BENCH_ADAM_FUSED", "1") != "0")
+        if ema_decay > 0.0:
+            opt = training.EMA(opt, ema_decay)
     averager = BucketedGradAverager(params)
     torch.manual_seed(1234 + rank)
     x = torch.randn(B, 2048, 3, device=dev)
@@ -603,13 +608,14 @@ def train_bench(args, rank, world, dev, backend):
                 cpu = train_cpu_baseline(args.mode, cfg)
             except Exception as e:  # the baseline must never take the benchmark down
                 cpu["sample"] = f"unmeasured: {e!r}"
-        out = {"metric": "samples/sec, one data-parallel training step (fwd + bwd + grad averaging + Adam)",
+        out = {"metric": "samples/sec, one data-parallel training step (fwd + bwd + grad averaging + Adam + EMA of the weights)",
                "value": world * B / (ms / 1e3), "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": dt, "data": "synthetic",
                "config": {"workload": name, "samples_per_gpu": B, "points": 2048, "launch": launch,
                           "gradient_averaging": f"BucketedGradAverager, {len(averager.buckets)} buckets, world {world}",
-                          "optimizer": ("lion_amd.optim.Adam (one launch)" if own_adam else "torch.optim.Adam (fused multi-tensor)"),
+                          "optimizer": (("lion_amd.optim.Adam (one launch)" if own_adam else "torch.optim.Adam (fused multi-tensor)")
+                                        + (f" + EMA of the weights, decay {ema_decay}" if ema_decay > 0.0 else "")),
                           "final_loss": loss_v, "strict": _fallback.strict(),
                           "vendor_library_fallbacks_total": sum(gpu_step_fallbacks.values()),
                           "vendor_library_fallbacks": gpu_step_fallbacks,

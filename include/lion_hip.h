@@ -503,14 +503,17 @@ int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *
 
 /* ---- optimizer update (training): torch.optim.Adam with L2 weight decay (reference utils/utils.py:115-121; optimizer.step() of
  * trainers/hvae_trainer.py:150-154, train_2prior.py:405-410) over EVERY parameter tensor in one launch (csrc/optim.hip).
- * table u64[T,5]: device addresses {param, grad, exp_avg, exp_avg_sq, step} of T float32 tensors (step: that parameter's f32 step
- * count, incremented by the call, then used for the bias corrections); numel i32[T]; blockmap i32[blocks,2]: {tensor, chunk} per
+ * table u64[T,lion_adam_row()]: device addresses {param, grad, exp_avg, exp_avg_sq, step, ema} of T float32 tensors (step: that
+ * parameter's f32 step count, incremented by the call, then used for the bias corrections; ema: 0, or the moving average of the
+ * weights the reference's EMA wrapper keeps (utils/ema.py:60-75: ema = ema * ema_decay + (1 - ema_decay) * param after the update,
+ * started from the updated parameter at the parameter's first step)); numel i32[T]; blockmap i32[blocks,2]: {tensor, chunk} per
  * workgroup, chunks of lion_adam_chunk() elements (all three in DEVICE memory, written by the caller once per gradient layout);
  * lr f32[1] (device).
  * Same arithmetic as torch.optim.Adam's single-tensor path (fp32 op for op, bias corrections in double). */
 int lion_adam_chunk(void);
+int lion_adam_row(void);
 int lion_adam_step(const uint64_t *table, const int32_t *numel, const int32_t *blockmap, int blocks, int tensors, const float *lr,
-                   float beta1, float beta2, float eps, float weight_decay, lionStream_t stream);
+                   float beta1, float beta2, float eps, float weight_decay, float ema_decay, lionStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -5,8 +5,12 @@ trainers/hvae_trainer.py:150-154 and train_2prior.py:405-410) with the whole upd
 state_dict moves between the two) and arithmetic (its single-tensor path, fp32 op for op; L2 weight decay; per-parameter step counts;
 parameters without a gradient are skipped).  Differences in form: the step counts and the learning rate live in device memory (so a
 captured step replays: call ``sync_lr()`` after changing ``group['lr']`` when steps are replayed rather than run), and the addresses of
-{param, grad, exp_avg, exp_avg_sq, step} of every tensor sit in a device table that is rewritten only when a gradient moved.  float32
-HIP parameters only -- anything else is an error, not a fallback."""
+{param, grad, exp_avg, exp_avg_sq, step, ema} of every tensor sit in a device table that is rewritten only when a gradient moved.
+``ema_decay > 0``: the moving average of the weights that the reference's ``EMA`` wrapper keeps around every optimizer
+(utils/ema.py:31-89, ``state[p]['ema']``; decay 0.9999 in every released config) is updated by the same launch -- the wrapper's
+form is a stack, a multiply-add and an unstack per parameter shape after the step.  ``lion_amd.training.EMA`` around this optimizer
+hands its decay over and keeps ``swap_parameters_with_ema``.  float32 HIP parameters only -- anything else is an error, not a
+fallback."""
 from __future__ import annotations
 
 import numpy as np
@@ -20,7 +24,10 @@ class _Plan:
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.0):
+        if not 0.0 <= ema_decay <= 1.0:
+            raise ValueError(f"Invalid ema_decay: {ema_decay}")
+        self.ema_decay = float(ema_decay)
         if not 0.0 <= lr:
             raise ValueError(f"Invalid learning rate: {lr}")
         if not 0.0 <= eps:
@@ -33,7 +40,7 @@ class Adam(torch.optim.Optimizer):
         self._plans = {}       # group index -> _Plan
         self._lr_dev = {}      # group index -> (device f32[1], the host value it holds)
         self._captured = []    # plans written inside a stream capture: their pinned tables are the source of the graph's copy nodes
-        self._chunk = None
+        self._chunk = self._row = None
 
     # -- device-resident hyper-parameters ---------------------------------------------------------------------------
     def _lr(self, gi, group, dev):
@@ -57,18 +64,20 @@ class Adam(torch.optim.Optimizer):
 
     # -- the pointer table ------------------------------------------------------------------------------------------------
     def _plan(self, gi, ps, grads, dev):
-        key = tuple((p.data_ptr(), g.data_ptr(), p.numel()) for p, g in zip(ps, grads))
+        ema = self.ema_decay > 0.0
+        key = tuple((p.data_ptr(), g.data_ptr(), p.numel(), self.state[p]["ema"].data_ptr() if ema else 0) for p, g in zip(ps, grads))
         plan = self._plans.get(gi)
         if plan is not None and plan.key == key:
             return plan
         if self._chunk is None:
-            self._chunk = int(_lib.load().lion_adam_chunk())
+            self._chunk, self._row = int(_lib.load().lion_adam_chunk()), int(_lib.load().lion_adam_row())
         T = len(ps)
-        table = np.empty((T, 5), dtype=np.uint64)
+        table = np.empty((T, self._row), dtype=np.uint64)
         numel = np.empty((T,), dtype=np.int32)
         for i, (p, g) in enumerate(zip(ps, grads)):
             st = self.state[p]
-            table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr())
+            table[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
+                        st["ema"].data_ptr() if ema else 0)
             numel[i] = p.numel()
         per = (numel.astype(np.int64) + self._chunk - 1) // self._chunk
         blocks = int(per.sum())
@@ -122,9 +131,14 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 elif not torch.is_tensor(st["step"]) or st["step"].device != dev:   # a state_dict from torch.optim.Adam(capturable=False)
                     st["step"] = torch.full((), float(st["step"]), dtype=torch.float32, device=dev)
+                if self.ema_decay > 0.0 and "ema" not in st:
+                    # the kernel starts the average from the updated parameter at the parameter's FIRST step (utils/ema.py:58-59);
+                    # state that arrives with steps already taken but no average (a plain Adam checkpoint) starts from the
+                    # parameter as it is
+                    st["ema"] = p.detach().clone(memory_format=torch.contiguous_format)
             plan = self._plan(gi, ps, grads, dev)
             b1, b2 = group["betas"]
             _lib.check(lib.lion_adam_step(_lib.ptr(plan.table), _lib.ptr(plan.numel), _lib.ptr(plan.blockmap), plan.blocks,
                                           len(ps), _lib.ptr(self._lr(gi, group, dev)), float(b1), float(b2), float(group["eps"]),
-                                          float(group["weight_decay"]), _lib.stream_ptr(dev)), "adam_step")
+                                          float(group["weight_decay"]), self.ema_decay, _lib.stream_ptr(dev)), "adam_step")
         return loss

@@ -317,10 +317,15 @@ class EMA(torch.optim.Optimizer):
         self.optimizer = opt
         self.state = opt.state
         self.param_groups = opt.param_groups
+        # lion_amd.optim.Adam updates state[p]['ema'] inside its own launch: hand the decay over, keep the swap / state_dict side
+        from .optim import Adam as _OwnAdam
+        self._folded = isinstance(opt, _OwnAdam)
+        if self._folded:
+            opt.ema_decay = float(ema_decay)
 
     def step(self, *args, **kwargs):
         ret = self.optimizer.step(*args, **kwargs)
-        if not self.apply_ema:
+        if not self.apply_ema or self._folded:
             return ret
         for group in self.optimizer.param_groups:
             for p in group['params']:

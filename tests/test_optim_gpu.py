@@ -129,3 +129,40 @@ def test_adam_inside_captured_training_steps():
     assert st_s.mode == "split" and len(st_s._graphs) == 2, st_s.launch
     for a, b, c in zip(p_w, p_s, p_r):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_adam_keeps_the_moving_average_of_the_weights_like_the_reference_wrapper():
+    """ema_decay: state[p]['ema'] == what utils/ema.py:47-78 computes around torch.optim.Adam (started from the updated parameter at a
+    parameter's first step, ema * decay + (1 - decay) * param after every later one; parameters without a gradient untouched);
+    lion_amd.training.EMA around the optimizer hands its decay over and swaps the weights in."""
+    from lion_amd.optim import Adam
+    from lion_amd.training import EMA
+    decay = 0.99
+    pa, pb = _params(3), _params(3)
+    oa = EMA(Adam(pa, lr=3e-3, betas=(0.9, 0.99)), decay)
+    assert oa._folded and oa.optimizer.ema_decay == decay
+    ob = torch.optim.Adam(pb, lr=3e-3, betas=(0.9, 0.99), foreach=False, fused=False)
+    ema_ref = {}
+    for step in range(5):
+        skip = (1, 4) if step == 0 else ()                 # these two take their first step one step later
+        for ps in (pa, pb):
+            for p, g in zip(ps, _grads(ps, step, 11, skip)):
+                p.grad = g
+        oa.step()
+        ob.step()
+        for i, p in enumerate(pb):                          # the reference wrapper's arithmetic
+            if p.grad is None:
+                continue
+            if i not in ema_ref:
+                ema_ref[i] = p.detach().clone()
+            ema_ref[i].mul_(decay).add_(p.detach(), alpha=1.0 - decay)
+    torch.cuda.synchronize()
+    for i, a in enumerate(pa):
+        e = oa.state[a]["ema"]
+        assert (e - ema_ref[i]).abs().max().item() <= 2e-6 * max(ema_ref[i].abs().max().item(), 1e-6), i
+        assert (e - a.detach()).abs().max().item() > 0      # an average, not a copy
+    before = [p.detach().clone() for p in pa]
+    oa.swap_parameters_with_ema(store_params_in_ema=True)
+    for i, a in enumerate(pa):
+        assert (a.detach() - ema_ref[i]).abs().max().item() <= 2e-6 * max(ema_ref[i].abs().max().item(), 1e-6)
+        assert torch.equal(oa.state[a]["ema"], before[i])
