@@ -10,9 +10,13 @@ def ball_query(centers_coords, points_coords, radius, num_neighbors):
     hit = geometry.lookup_ball_query(centers_coords, points_coords, radius, num_neighbors)
     if hit is not None:  # prefetched on the side stream (inference)
         return hit
+    key, hit = geometry.memo_get("bq", (centers_coords, points_coords), float(radius), int(num_neighbors))
+    if hit is not None:  # a second network on the same cloud (geometry.shared)
+        return hit
+    src = (centers_coords, points_coords)
     centers_coords = centers_coords[:, :3].contiguous()
     points_coords = points_coords[:, :3].contiguous()
-    return _bk._backend.ball_query(centers_coords, points_coords, radius, num_neighbors)
+    return geometry.memo_put(key, src, _bk._backend.ball_query(centers_coords, points_coords, radius, num_neighbors))
 
 
 def _ball_query_compute(centers_coords, points_coords, radius, num_neighbors):

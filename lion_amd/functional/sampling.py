@@ -21,12 +21,16 @@ def furthest_point_sample(coords, num_samples, normals=None):
         hit = geometry.lookup_fps(coords, num_samples)  # prefetched on the side stream (inference)
         if hit is not None:
             return hit
+        key, hit = geometry.memo_get("fps", (coords,), int(num_samples))   # a second network on the same cloud (geometry.shared)
+        if hit is not None:
+            return hit
+        src = coords
     coords = coords.contiguous()
     indices = _bk._backend.furthest_point_sampling(coords, num_samples)
     centers_coords = gather(coords, indices)
     if normals is not None:
         return centers_coords, gather(normals, indices)
-    return centers_coords
+    return geometry.memo_put(key, (src,), centers_coords)
 
 
 def _fps_compute(coords, num_samples):

@@ -68,6 +68,16 @@ class Model(nn.Module):
 
     # ---- encoders ----------------------------------------------------------------------------
     def _encode_both(self, x, cls_emb=None):
+        from .. import geometry
+        with geometry.shared():   # both encoders sample / query the same cloud in their first two set abstractions: once
+            return self._encode_both_impl(x, cls_emb)
+
+    def _encode_both_impl(self, x, cls_emb=None):
+        from .. import geometry
+        # one channel-major copy of the cloud for both encoders (each made its own): their first set abstractions then see the
+        # SAME coordinate tensor, which is what geometry.shared() keys on; x stays [B, N, 3] for them, as a view of that copy
+        if x.is_cuda and x.dim() == 3 and geometry.SHARED:
+            x = x.transpose(1, 2).contiguous().transpose(1, 2)
         enc_input = (x, cls_emb) if self.args.data.cond_on_cat else x
         z = self.style_encoder(enc_input)
         g_mu, g_sigma = z['mu_1d'], z['sigma_1d']

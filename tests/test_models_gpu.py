@@ -330,3 +330,34 @@ def test_graph_replay_equals_eager_denoisers():
                 err = (got - want).abs().max().item() / want.abs().max().item()
                 assert err <= 1e-6, err
             assert graphed.eval() is graphed and graphed.mixed_prediction == prior.mixed_prediction
+
+
+def test_vae_encoders_share_the_geometry_of_their_first_two_set_abstractions():
+    """geometry.shared(): the style encoder and the latent-point encoder sample / query the same cloud with the same (1024, 0.1, 32)
+    and (256, 0.2, 32) stages (reference models/vae_adain.py:92-118 runs both chains) -- computed once, same encoding as without"""
+    from unittest import mock
+    import lion_amd.functional.backend as bk
+    from lion_amd import geometry
+    from lion_amd.config import released_prior_cfg
+    from lion_amd.models.vae_adain import Model as VAE
+    torch.manual_seed(0)
+    vae = VAE(released_prior_cfg("chair")).cuda().eval()
+    x = torch.randn(2, 2048, 3, device="cuda")
+    be = bk._backend
+    with torch.no_grad():
+        with mock.patch.object(be, "furthest_point_sampling", wraps=be.furthest_point_sampling) as fps, \
+                mock.patch.object(be, "ball_query", wraps=be.ball_query) as bq:
+            torch.manual_seed(1)
+            shared = vae.encode(x)
+            n_fps, n_bq = fps.call_count, bq.call_count
+        with mock.patch.object(geometry, "memo_get", lambda *a, **k: (None, None)):
+            with mock.patch.object(be, "furthest_point_sampling", wraps=be.furthest_point_sampling) as fps0, \
+                    mock.patch.object(be, "ball_query", wraps=be.ball_query) as bq0:
+                torch.manual_seed(1)
+                plain = vae.encode(x)
+                m_fps, m_bq = fps0.call_count, bq0.call_count
+    assert (m_fps, m_bq) == (6, 6) and (n_fps, n_bq) == (4, 4), (m_fps, m_bq, n_fps, n_bq)
+    for a, b in zip(shared, plain):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)
+    assert geometry._MEMO is None      # nothing outlives the encode
