@@ -312,7 +312,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
   for (int t = ts; t < ntiles; t += TS, par ^= 1) {
     tile_max(par);
     __syncthreads();               // the tile's maxima are complete; the previous tile's LDS reads are done
-    {
+    // A tile whose input window (halo included) is all zero adds nothing: no cut, no LDS stores, no MFMAs -- only its loads,
+    // which were in flight already.  The first convolution of every PVConv reads a freshly voxelized grid (2048 points in 32^3
+    // voxels: most 256-voxel tiles are empty); the tile's maximum is known here anyway.
+    const bool empty = s_m[par][0] == 0u;   // uniform over the workgroup
+    if (!empty) {
       const unsigned bx = s_m[par][0], bg = s_m[par][1];
       float f = 1.f;               // what the accumulated sums have to be multiplied by (<= 1, exact)
       if (bx) { const int e = scale_exp(__uint_as_float(bx)); if (e < Ex) { if (Ex != 127) f *= pow2f(max(e - Ex, -126)); Ex = e; sxs = pow2f(e); } }
@@ -324,13 +328,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
           for (int i = 0; i < 16; ++i) acc[nb][i] *= f;
       }
     }
-    store_tile();
+    if (!empty) store_tile();
     if (tid < 2) s_m[par ^ 1][tid] = 0u;   // the other parity: its last readers passed the barrier above
     __syncthreads();
     if (t + TS < ntiles) load_tile(t + TS);
     // 4 k-steps of 16 voxels over this wave's 64 voxels; a lane's fragment = voxels v0 .. v0 + 7 of one row
 #pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
+    for (int s = empty ? 4 : 0; s < 4; ++s) {
       const int v0 = wave * 64 + 16 * s + 8 * kh;
       const int d = v0 / (TH * TW), h = (v0 / TW) % TH, w = v0 % TW;
       const int vb = (d * HH + h) * HW + w;

@@ -521,3 +521,30 @@ def test_adagn_projection_halves_backward_needs_no_cat():
     f3, _ = e[:, :2 * C].chunk(2, 1)
     g2, = torch.autograd.grad((f3 * 2.0).sum(), e)
     assert torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("cin,cout,r", [(32, 32, 32), (64, 32, 16), (128, 128, 8)])
+def test_conv3d_wgrad_on_a_sparse_grid_skips_empty_tiles_exactly(cin, cout, r):
+    """the weight gradient with an input grid that is zero outside a few voxels (what a voxelized cloud is): tiles whose window is
+    all zero are skipped by the split kernel -- same gradient as float64, and the same as with the zeros replaced by values that
+    are explicitly multiplied by a zero output gradient there (no tile skipped)"""
+    from lion_amd.conv_ops import conv3d_k3_wgrad
+    torch.manual_seed(cin + r)
+    B = 3
+    x = torch.zeros(B, cin, r, r, r, device="cuda")
+    n = r * r * r
+    idx = torch.randint(0, n, (B, max(8, n // 64)), device="cuda")             # ~1.5 % of the voxels occupied, clustered per sample
+    idx = (idx // 7) % n if r > 8 else idx
+    for b in range(B):
+        x[b].view(cin, n)[:, idx[b]] = torch.randn(cin, idx.shape[1], device="cuda")
+    gy = torch.randn(B, cout, r, r, r, device="cuda")
+    w = torch.zeros(cout, cin, 3, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(x.double(), w, None, padding=1).backward(gy.double())
+    got = conv3d_k3_wgrad(x, gy, w.shape, split=True)
+    err = (got.double() - w.grad).abs().max().item() / w.grad.abs().max().item()
+    assert err < 2e-6, err
+    ref32 = conv3d_k3_wgrad(x, gy, w.shape, split=False)                       # the exact-fp32 kernel (never skips)
+    assert (got - ref32).abs().max().item() <= 2e-6 * ref32.abs().max().item()
+    # an all-zero input: the gradient is exactly zero (every tile skipped, the epilogue writes the untouched accumulators)
+    z = conv3d_k3_wgrad(torch.zeros_like(x), gy, w.shape, split=True)
+    assert not bool(z.any())
