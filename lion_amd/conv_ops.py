@@ -72,11 +72,13 @@ def packed_weight(weight):
     return _PACK_CACHE.get(weight)
 
 
-def conv3d_k3(x, weight, bias=None, split=None, packed=None):
+def conv3d_k3(x, weight, bias=None, split=None, packed=None, occ=None):
     """x [B,Cin,r,r,r] fp32 -> [B,Cout,r,r,r]; Cin is zero-padded to a multiple of 4 if needed.
     split: None = the module default (SPLIT), False = the exact-fp32 MFMA kernel, True = split operands if supported.
     packed: callable(kind) -> the packed copy of `weight` for kind in ("split", "f32"), for callers whose `weight` is a
-    derived temporary and who cache its packed forms under the ORIGINAL parameter (the data-gradient path)."""
+    derived temporary and who cache its packed forms under the ORIGINAL parameter (the data-gradient path).
+    occ: the tile occupancy of a freshly voxelised `x` (fused_ops.conv3d_occupancy(counts)[0]): tiles without a point within
+    one voxel skip their K loop (output = bias exactly); split kernel only, ignored otherwise."""
     _lib.require_cuda(x)
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = weight.shape[0]
@@ -87,7 +89,7 @@ def conv3d_k3(x, weight, bias=None, split=None, packed=None):
         wp = packed("split") if packed is not None else split_packed_weight(weight)
         _lib.check(_lib.load().lion_conv3d_k3_split_forward(
             _lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias_c), b, cin, cout, r, None, None, None, None, _lib.ptr(y), None,
-            None, _lib.stream_ptr(x.device)), "conv3d_k3_split_forward")
+            _lib.ptr(occ) if (occ is not None and r >= 16) else None, _lib.stream_ptr(x.device)), "conv3d_k3_split_forward")
         return y
     if cin % 4:
         pad = 4 - cin % 4
@@ -140,6 +142,9 @@ def conv3d_k3_dgrad(gy, weight):
 
 
 # weight gradient on the 16-bit matrix pipe at fp32 accuracy where Cin % 8 == 0 (csrc/conv3d_wgrad.hip, round 4);
+# training: the convolution that reads a freshly voxelised grid skips the tiles without a point within one voxel (forward; the
+# weight gradient skips all-zero input windows by itself).  LION_TRAIN_SPARSE=0: dense.
+TRAIN_SPARSE = os.environ.get("LION_TRAIN_SPARSE", "1") != "0"
 # LION_WGRAD_SPLIT=0: the exact-fp32 MFMA kernel everywhere
 WGRAD_SPLIT = os.environ.get("LION_WGRAD_SPLIT", "1") != "0"
 
@@ -171,10 +176,15 @@ class _Conv3dK3(torch.autograd.Function):
     convolution_backward (MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, counts=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return conv3d_k3(x, weight, bias)
+        occ = None
+        r, cout = x.shape[2], weight.shape[0]
+        if counts is not None and TRAIN_SPARSE and r in (16, 32) and use_split(None, x.shape[1], cout, r):
+            from . import fused_ops
+            occ = fused_ops.conv3d_occupancy(counts, r, cout, x.shape[0])[0]
+        return conv3d_k3(x, weight, bias, occ=occ)
 
     @staticmethod
     def backward(ctx, gy):
@@ -214,7 +224,7 @@ class _Conv3dK3(torch.autograd.Function):
                 # reduction over dims (0, 2, 3, 4): 240-277 us -> ~60 us at [32, 64, 32^3]
                 from . import fused_ops
                 gb = fused_ops.row_stats(gy)[:, 0].reshape(gy.shape[0], gy.shape[1]).sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def conv3d_module(conv: torch.nn.Conv3d, x):
@@ -234,5 +244,9 @@ def conv3d_module(conv: torch.nn.Conv3d, x):
         # always the module's own weight tensor: the packed / mirrored copies are cached per (storage, version),
         # a padded temporary would miss every step and pin dead copies in HBM (odd Cin is padded inside
         # conv3d_k3 / backward instead)
-        return _Conv3dK3.apply(x, conv.weight, conv.bias)
+        # a grid straight from the voxelisation carries its point counts (functional/voxelization.py): the empty tiles of THIS
+        # convolution follow from them (the version check voids the tag after an in-place write to the grid)
+        tag = getattr(x, "_lion_voxel_counts", None)
+        counts = tag[0] if (tag is not None and tag[1] == x._version and tag[0].shape[0] == x.shape[0]) else None
+        return _Conv3dK3.apply(x, conv.weight, conv.bias, counts)
     return conv3d_k3(x, conv.weight, conv.bias)

@@ -48,12 +48,12 @@ class _VoxelizePoints(Function):
         out, norm, indices, counts = _bk._backend.voxelize_points_forward(
             features, coords, resolution, normalize, eps)
         ctx.save_for_backward(indices, counts)
-        ctx.mark_non_differentiable(norm)
-        return out.view(b, c, resolution, resolution, resolution), norm
+        ctx.mark_non_differentiable(norm, counts)
+        return out.view(b, c, resolution, resolution, resolution), norm, counts
 
     @staticmethod
     @custom_bwd(device_type="cuda")
-    def backward(ctx, grad_output, _grad_norm):
+    def backward(ctx, grad_output, _grad_norm, _grad_counts=None):
         b, c = grad_output.shape[:2]
         indices, counts = ctx.saved_tensors
         grad_features = _bk._backend.avg_voxelize_backward(
@@ -61,6 +61,13 @@ class _VoxelizePoints(Function):
         return grad_features, None, None, None, None
 
 
+VOXEL_COUNTS_TAG = "_lion_voxel_counts"
+
+
 def voxelize_points(features, coords, resolution, normalize=True, eps=0.0):
-    return _VoxelizePoints.apply(features, coords.detach(), int(resolution), bool(normalize),
-                                 float(eps))
+    grid, norm, counts = _VoxelizePoints.apply(features, coords.detach(), int(resolution), bool(normalize),
+                                               float(eps))
+    # the per-voxel point counts ride on the grid tensor: the convolution that reads it (conv_ops.conv3d_module, training)
+    # derives its empty tiles from them, as the fused inference branch does from Voxelization(return_counts=True)
+    setattr(grid, VOXEL_COUNTS_TAG, (counts, grid._version))
+    return grid, norm

@@ -548,3 +548,49 @@ def test_conv3d_wgrad_on_a_sparse_grid_skips_empty_tiles_exactly(cin, cout, r):
     # an all-zero input: the gradient is exactly zero (every tile skipped, the epilogue writes the untouched accumulators)
     z = conv3d_k3_wgrad(torch.zeros_like(x), gy, w.shape, split=True)
     assert not bool(z.any())
+
+
+def test_training_conv_on_a_voxelised_grid_skips_empty_tiles_exactly(monkeypatch):
+    """training: the Conv3d that reads a freshly voxelised grid takes the point counts that ride on the grid tensor and evaluates
+    sparsely (tiles without a point within one voxel: output = bias) -- output and every gradient identical to the dense run"""
+    from lion_amd import conv_ops
+    from lion_amd.models.pvcnn2_ada import Voxelization
+    torch.manual_seed(2)
+    B, C, N, r = 4, 32, 2048, 32
+    feat = torch.randn(B, C, N, device="cuda", requires_grad=True)
+    coords = torch.randn(B, 3, N, device="cuda") * torch.tensor([1.0, 0.2, 0.6], device="cuda")[None, :, None]   # a flat cloud
+    conv = torch.nn.Conv3d(C, 64, 3, padding=1).cuda()
+    vox = Voxelization(r)
+    gy = torch.randn(B, 64, r, r, r, device="cuda")
+    outs = []
+    for sparse in (True, False):
+        monkeypatch.setattr(conv_ops, "TRAIN_SPARSE", sparse)
+        conv.zero_grad()
+        feat.grad = None
+        grid, _ = vox(feat, coords)
+        assert hasattr(grid, "_lion_voxel_counts")
+        seen = []
+        orig = conv_ops.conv3d_k3
+
+        def spy(*a, **k):
+            seen.append(k.get("occ") is not None)
+            return orig(*a, **k)
+        monkeypatch.setattr(conv_ops, "conv3d_k3", spy)
+        y = conv_ops.conv3d_module(conv, grid)
+        monkeypatch.setattr(conv_ops, "conv3d_k3", orig)
+        assert seen[0] == sparse
+        y.backward(gy)
+        outs.append((y.detach().clone(), feat.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    for name, a, b in zip(("y", "dfeat", "dw", "db"), outs[0], outs[1]):
+        assert torch.equal(a, b), name
+    empty = (outs[0][0] == conv.bias.detach()[None, :, None, None, None]).all(1).float().mean().item()
+    assert empty > 0.3, empty          # a good part of the grid is bias-only: the case is not vacuous
+    # a grid written in place after the voxelisation loses the tag (version check)
+    grid, _ = vox(feat.detach(), coords)
+    grid.add_(1.0)
+    monkeypatch.setattr(conv_ops, "TRAIN_SPARSE", True)
+    seen.clear()
+    monkeypatch.setattr(conv_ops, "conv3d_k3", spy)
+    with torch.enable_grad():
+        conv_ops.conv3d_module(conv, grid.requires_grad_(True))
+    assert seen == [False]
