@@ -133,11 +133,18 @@ _DGRAD_SPLIT_CACHE = WeightCache(lambda w: _split_pack(dgrad_weight(w)))
 _DGRAD_PACK_CACHE = WeightCache(lambda w: _pack(dgrad_weight(w)))
 
 
-def conv3d_k3_dgrad(gy, weight):
+def conv3d_k3_dgrad(gy, weight, counts=None):
     """grad_x (with Cin padded to a multiple of 32, callers slice) = conv3d_k3(gy, mirror(weight)); every derived tensor
-    is cached under `weight` (storage, version, generation) and replaced in place when the parameter changes."""
+    is cached under `weight` (storage, version, generation) and replaced in place when the parameter changes.
+    counts: the point counts of the voxelised grid x was (int32 [B, r^3]): its gradient is read by the voxelisation's backward
+    at voxels that hold a point only, so tiles without a point within one voxel are not computed (they hold zeros)."""
     wt = dgrad_weight(weight)
-    return conv3d_k3(gy, wt, None,
+    occ = None
+    r = gy.shape[2]
+    if counts is not None and TRAIN_SPARSE and r in (16, 32) and use_split(None, gy.shape[1], wt.shape[0], r):
+        from . import fused_ops
+        occ = fused_ops.conv3d_occupancy(counts, r, wt.shape[0], gy.shape[0])[0]
+    return conv3d_k3(gy, wt, None, occ=occ,
                      packed=lambda kind: (_DGRAD_SPLIT_CACHE if kind == "split" else _DGRAD_PACK_CACHE).get(weight))
 
 
@@ -179,6 +186,7 @@ class _Conv3dK3(torch.autograd.Function):
     def forward(ctx, x, weight, bias, counts=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.counts = counts      # (not a differentiable input; kept for the data gradient's empty tiles)
         occ = None
         r, cout = x.shape[2], weight.shape[0]
         if counts is not None and TRAIN_SPARSE and r in (16, 32) and use_split(None, x.shape[1], cout, r):
@@ -207,7 +215,7 @@ class _Conv3dK3(torch.autograd.Function):
                 gy, x, weight, [weight.shape[0]] if ctx.has_bias else None,
                 [1, 1, 1], [1, 1, 1], [1, 1, 1], False, [0, 0, 0], 1, lib_mask)
         if own_dgrad:
-            gx = conv3d_k3_dgrad(gy, weight)
+            gx = conv3d_k3_dgrad(gy, weight, ctx.counts)
             if gx.shape[1] != cin:
                 gx = gx[:, :cin].contiguous()
         if own_wgrad:
