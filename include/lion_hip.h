@@ -234,6 +234,14 @@ int lion_conv3d_k3_wgrad(const float *x, const float *gy, int B, int Cin, int Co
  * workspace as lion_conv3d_k3_wgrad; Cin % 8 == 0, x / gy 16-byte aligned (LION_EUNSUPPORTED otherwise). */
 int lion_conv3d_k3_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
                                size_t ws_floats, lionStream_t stream);
+/* TRAINING, round 6: the same gradient when x is a freshly voxelised grid (the first Conv3d of a PVConv, models/pvcnn2_ada.py:211):
+ * cnt i32[B, r^3] = the voxelisation's per-voxel point counts (16-byte aligned).  Tiles without a point within one voxel add nothing
+ * and are neither loaded nor multiplied (a one-workgroup-per-sample kernel derives the tile map first).  Without counts the split
+ * kernel still skips the arithmetic of a tile whose staged window turns out to be all zero.  Workspace:
+ * lion_conv3d_wgrad_sparse_workspace_floats (the dense size + the tile map). */
+size_t lion_conv3d_wgrad_sparse_workspace_floats(int B, int Cin, int Cout, int r);
+int lion_conv3d_k3_wgrad_split_sparse(const float *x, const float *gy, const int32_t *cnt, int B, int Cin, int Cout, int r,
+                                      float *gw, float *ws, size_t ws_floats, lionStream_t stream);
 
 /* ---- P2+P3+P4 folded into C3 / K4 (inference): PVConv.forward voxel branch, pvcnn2_ada.py:211-226 ----
  * conv -> AdaGN -> Swish -> conv -> AdaGN -> SE3d -> devoxelize without a single stand-alone pass over

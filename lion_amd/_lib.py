@@ -51,6 +51,8 @@ SIGNATURES = {
     "lion_conv3d_wgrad_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "lion_conv3d_k3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lion_conv3d_k3_wgrad_split": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lion_conv3d_wgrad_sparse_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "lion_conv3d_k3_wgrad_split_sparse": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lion_conv3d_stat_tiles": (_i, [_i, _i, _i, _i]),
     "lion_conv3d_k3_fused_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_conv3d_const_response": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -156,17 +156,26 @@ TRAIN_SPARSE = os.environ.get("LION_TRAIN_SPARSE", "1") != "0"
 WGRAD_SPLIT = os.environ.get("LION_WGRAD_SPLIT", "1") != "0"
 
 
-def conv3d_k3_wgrad(x, gy, weight_shape, split=None):
+def conv3d_k3_wgrad(x, gy, weight_shape, split=None, counts=None):
     """weight gradient [Cout,Cin,3,3,3] of the 3x3x3 / pad 1 conv on the MFMA kernels (x [B,Cin,r,r,r], Cin % 4 == 0).
-    split: None = WGRAD_SPLIT, True / False = the split-operand kernel where it applies / the exact-fp32 kernel."""
+    split: None = WGRAD_SPLIT, True / False = the split-operand kernel where it applies / the exact-fp32 kernel.
+    counts: x is a freshly voxelised grid with these point counts (int32 [B, r^3]): its empty tiles are not loaded."""
     lib = _lib.load()
     b, cin, r = x.shape[0], x.shape[1], x.shape[2]
     cout = gy.shape[1]
     gw = torch.empty(tuple(weight_shape), device=x.device, dtype=torch.float32)
-    n = lib.lion_conv3d_wgrad_workspace_floats(b, cin, cout, r)
+    sparse = counts is not None and TRAIN_SPARSE and (WGRAD_SPLIT if split is None else split) and cin % 8 == 0
+    n = (lib.lion_conv3d_wgrad_sparse_workspace_floats if sparse else lib.lion_conv3d_wgrad_workspace_floats)(b, cin, cout, r)
     ws = torch.empty((n,), device=x.device, dtype=torch.float32)
     x_c, gy_c = x.contiguous(), gy.contiguous()
     st = _lib.stream_ptr(x.device)
+    if sparse:
+        cnt_c = counts.contiguous()
+        rc = lib.lion_conv3d_k3_wgrad_split_sparse(_lib.ptr(x_c), _lib.ptr(gy_c), _lib.ptr(cnt_c), b, cin, cout, r, _lib.ptr(gw),
+                                                   _lib.ptr(ws), n, st)
+        if rc != -2:
+            _lib.check(rc, "conv3d_k3_wgrad_split_sparse")
+            return gw
     if (WGRAD_SPLIT if split is None else split) and cin % 8 == 0:
         rc = lib.lion_conv3d_k3_wgrad_split(_lib.ptr(x_c), _lib.ptr(gy_c), b, cin, cout, r, _lib.ptr(gw), _lib.ptr(ws), n, st)
         if rc != -2:   # LION_EUNSUPPORTED (alignment): the fp32 kernel below
@@ -224,7 +233,7 @@ class _Conv3dK3(torch.autograd.Function):
                 xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 0, 0, pad))
                 gw = conv3d_k3_wgrad(xp, gy, (cout, cin + pad, 3, 3, 3))[:, :cin].contiguous()
             else:
-                gw = conv3d_k3_wgrad(x, gy, weight.shape)
+                gw = conv3d_k3_wgrad(x, gy, weight.shape, counts=ctx.counts)
             if want_gb and gb_tagged is not None:
                 gb = gb_tagged   # sum of dx over batch and voxels, a by-product of the AdaGN backward (train_ops.tag_channel_sum)
             elif want_gb:

@@ -185,7 +185,7 @@ __device__ __forceinline__ void cut2u(float a, float b, unsigned &hi2, unsigned 
 template <int TD, int TH, int TW, int CIT>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                                     int Cin, int Cout, int r, int TS, int units,
-                                                                    const float *__restrict__ sc,
+                                                                    const unsigned char *__restrict__ skip,
                                                                     float *__restrict__ partial) {
   constexpr int TV = TD * TH * TW; // 256 voxels per tile
   static_assert(TV == 256 && TW % 8 == 0, "4 waves x 64 voxels; fragments of 8 voxels stay inside a row");
@@ -306,10 +306,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
       }
     }
   };
-  if (ts < ntiles) load_tile(ts);
+  // skip (or NULL): u8 [B][ntiles], 1 = no point within one voxel of the tile (wgrad_tile_skip_kernel, from the voxelisation's
+  // counts): such a tile is not even loaded; without the map an all-zero window is still detected below, after its loads
+  const unsigned char *skb = skip ? skip + (size_t)b * ntiles : nullptr;
+  auto next_tile = [&](int t) {
+    if (skb) while (t < ntiles && skb[t]) t += TS;
+    return t;
+  };
+  int t = next_tile(ts);
+  if (t < ntiles) load_tile(t);
   __syncthreads();                 // s_m zeroed
   int par = 0;
-  for (int t = ts; t < ntiles; t += TS, par ^= 1) {
+  for (int tn; t < ntiles; t = tn, par ^= 1) {
+    tn = next_tile(t + TS);
     tile_max(par);
     __syncthreads();               // the tile's maxima are complete; the previous tile's LDS reads are done
     // A tile whose input window (halo included) is all zero adds nothing: no cut, no LDS stores, no MFMAs -- only its loads,
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
     if (!empty) store_tile();
     if (tid < 2) s_m[par ^ 1][tid] = 0u;   // the other parity: its last readers passed the barrier above
     __syncthreads();
-    if (t + TS < ntiles) load_tile(t + TS);
+    if (tn < ntiles) load_tile(tn);
     // 4 k-steps of 16 voxels over this wave's 64 voxels; a lane's fragment = voxels v0 .. v0 + 7 of one row
 #pragma unroll 1
     for (int s = empty ? 4 : 0; s < 4; ++s) {
@@ -393,6 +402,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_split_kernel(const float 
   }
 }
 
+// skip[b][t] = 1 when no voxel within one step of tile t (tiles of TD x TH x r voxels: they span the w axis) holds a point.
+// cnt i32[B][r^3] from the voxelisation.  One workgroup per sample: row occupancy bits, then one thread per tile.
+__global__ __launch_bounds__(256) void wgrad_tile_skip_kernel(const int32_t *__restrict__ cnt, int r, int TD, int TH,
+                                                              unsigned char *__restrict__ skip) {
+  __shared__ unsigned rowany[32 * 32];   // (d, h) row holds a point
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < r * r; i += 256) rowany[i] = 0u;
+  __syncthreads();
+  const int4 *c4 = reinterpret_cast<const int4 *>(cnt + (size_t)b * r * r * r);
+  for (int i = tid; i < (r * r * r) >> 2; i += 256) {
+    const int4 v = c4[i];
+    if (v.x | v.y | v.z | v.w) rowany[(i << 2) / r] = 1u;   // (benign race: every writer stores 1)
+  }
+  __syncthreads();
+  const int nth = r / TH, ntiles = (r / TD) * nth;
+  for (int t = tid; t < ntiles; t += 256) {
+    const int d0 = (t / nth) * TD, h0 = (t % nth) * TH;
+    unsigned any = 0u;
+    for (int d = max(d0 - 1, 0); d <= min(d0 + TD, r - 1); ++d)
+      for (int h = max(h0 - 1, 0); h <= min(h0 + TH, r - 1); ++h) any |= rowany[d * r + h];
+    skip[(size_t)b * ntiles + t] = any ? 0 : 1;
+  }
+}
+
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float *__restrict__ partial, int nparts,
                                                                   size_t n, float *__restrict__ gw) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -416,8 +449,8 @@ static int launch_wgrad(const float *x, const float *gy, int B, int Cin, int Cou
 }
 
 template <int TD, int TH, int TW, int CIT>
-static int launch_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, int TS, const float *sc,
-                              float *partial, hipStream_t st) {
+static int launch_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, int TS,
+                              const unsigned char *skip, float *partial, hipStream_t st) {
   constexpr int HALO = (TD + 2) * (TH + 2) * (TW + 2);
   size_t lds = (size_t)(32 * WG_GS + CIT * HALO) * 4;
   if (lds < (size_t)4 * 16 * 64 * 4) lds = (size_t)4 * 16 * 64 * 4; // the epilogue's [4][16][64] reduction buffer
@@ -425,7 +458,7 @@ static int launch_wgrad_split(const float *x, const float *gy, int B, int Cin, i
   if (int e = lion_dynamic_lds(&conv3d_wgrad_split_kernel<TD, TH, TW, CIT>, lds, cfg)) return e;
   const int units = B * TS * (Cout / 32), nci = Cin / CIT;
   conv3d_wgrad_split_kernel<TD, TH, TW, CIT><<<dim3((unsigned)(((units + 7) / 8) * 8 * nci)), 256, lds, st>>>(
-      x, gy, Cin, Cout, r, TS, units, sc, partial);
+      x, gy, Cin, Cout, r, TS, units, skip, partial);
   LION_LAUNCH_CHECK();
   return 0;
 }
@@ -472,24 +505,50 @@ int lion_conv3d_k3_wgrad(const float *x, const float *gy, int B, int Cin, int Co
 
 // The same gradient on the 16-bit matrix pipe at fp32 accuracy (conv3d_wgrad_split_kernel above): same arguments and
 // workspace; Cin % 8 == 0 (LION_EUNSUPPORTED otherwise: the caller uses lion_conv3d_k3_wgrad).
-int lion_conv3d_k3_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
-                               size_t ws_floats, lionStream_t stream) {
+static int wgrad_split_impl(const float *x, const float *gy, const int32_t *cnt, int B, int Cin, int Cout, int r, float *gw,
+                            float *ws, size_t ws_floats, lionStream_t stream) {
   if (!x || !gy || !gw || B <= 0 || Cin <= 0 || Cout <= 0) return LION_EINVAL;
   if (Cin % 8 != 0 || Cout % 32 != 0 || (r != 8 && r != 16 && r != 32)) return LION_EUNSUPPORTED;
   if (!ws || ws_floats < lion_conv3d_wgrad_workspace_floats(B, Cin, Cout, r)) return LION_EWORKSPACE;
-  if (((((uintptr_t)x) | ((uintptr_t)gy)) & 15) != 0) return LION_EUNSUPPORTED;
+  if (((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)cnt)) & 15) != 0) return LION_EUNSUPPORTED;
   const int TS = wgrad_splits(B, Cin, Cout, r);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const float *sc = nullptr;   // (round 6: the block scales are found inside the kernel; no absmax passes)
-  int rc;
-  if (r == 32) rc = launch_wgrad_split<2, 4, 32, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
-  else if (r == 16) rc = launch_wgrad_split<4, 4, 16, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
-  else rc = launch_wgrad_split<4, 8, 8, 8>(x, gy, B, Cin, Cout, r, TS, sc, ws, st);
-  if (rc) return rc;
+  // (round 6: the block scales are found inside the kernel; no absmax passes)
   const size_t n = (size_t)Cout * Cin * 27;
+  unsigned char *skip = nullptr;
+  if (cnt) {   // the tile map lives behind the partials (the workspace's 64 spare floats are not enough: B * ntiles bytes)
+    const int td = r == 32 ? 2 : 4, th = r == 8 ? 8 : 4, ntiles = (r / td) * (r / th);
+    const size_t used = (size_t)B * TS * n;
+    if (ws_floats < used + ((size_t)B * ntiles + 3) / 4) return LION_EWORKSPACE;
+    skip = reinterpret_cast<unsigned char *>(ws + used);
+    wgrad_tile_skip_kernel<<<B, 256, 0, st>>>(cnt, r, td, th, skip);
+  }
+  int rc;
+  if (r == 32) rc = launch_wgrad_split<2, 4, 32, 8>(x, gy, B, Cin, Cout, r, TS, skip, ws, st);
+  else if (r == 16) rc = launch_wgrad_split<4, 4, 16, 8>(x, gy, B, Cin, Cout, r, TS, skip, ws, st);
+  else rc = launch_wgrad_split<4, 8, 8, 8>(x, gy, B, Cin, Cout, r, TS, skip, ws, st);
+  if (rc) return rc;
   conv3d_wgrad_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ws, B * TS, n, gw);
   LION_LAUNCH_CHECK();
   return 0;
+}
+
+int lion_conv3d_k3_wgrad_split(const float *x, const float *gy, int B, int Cin, int Cout, int r, float *gw, float *ws,
+                               size_t ws_floats, lionStream_t stream) {
+  return wgrad_split_impl(x, gy, nullptr, B, Cin, Cout, r, gw, ws, ws_floats, stream);
+}
+
+// x is a freshly voxelised grid and cnt i32[B, r^3] its per-voxel point counts (16-byte aligned): tiles without a point within one
+// voxel add nothing to the gradient and are not loaded.  Workspace: lion_conv3d_wgrad_sparse_workspace_floats.
+size_t lion_conv3d_wgrad_sparse_workspace_floats(int B, int Cin, int Cout, int r) {
+  const size_t base = lion_conv3d_wgrad_workspace_floats(B, Cin, Cout, r);
+  return base ? base + ((size_t)B * 256 + 3) / 4 : 0;   // <= 256 tiles per sample
+}
+
+int lion_conv3d_k3_wgrad_split_sparse(const float *x, const float *gy, const int32_t *cnt, int B, int Cin, int Cout, int r,
+                                      float *gw, float *ws, size_t ws_floats, lionStream_t stream) {
+  if (!cnt) return LION_EINVAL;
+  return wgrad_split_impl(x, gy, cnt, B, Cin, Cout, r, gw, ws, ws_floats, stream);
 }
 
 } // extern "C"
