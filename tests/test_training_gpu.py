@@ -322,7 +322,8 @@ def _w_split_world2(rank, world, port):
             opt_r.step()
         # the captured step: [forward + backward + copies into the buckets] graph -> eager gloo all-reduce -> [optimizer] graph
         net, unused, params = make()
-        opt = torch.optim.Adam(params, lr=1e-2, capturable=True)
+        from lion_amd.optim import Adam
+        opt = Adam(params, lr=1e-2, ema_decay=0.99)   # the one-launch optimizer (its pointer table: gradients = bucket views here)
         avg = BucketedGradAverager(params, bucket_bytes=512)
         assert len(avg.buckets) >= 2 and all(flat is not None for flat, _ in avg.buckets)
 
@@ -341,6 +342,7 @@ def _w_split_world2(rank, world, port):
             assert p.grad.data_ptr() == avg._view_of[p].data_ptr()
         for p, q in zip(net.parameters(), net_r.parameters()):
             torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-5, atol=1e-6)
+            assert opt.state[p]["ema"].data_ptr() != p.data_ptr() and float(opt.state[p]["step"]) == 5.0
         flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()
         both = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
