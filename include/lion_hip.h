@@ -462,11 +462,15 @@ int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, 
                          float *Bs, float *mean, float *rstd, lionStream_t stream);
 int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
                            const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
-                           float *dbias, int d_stride, float *pw, const float *A, const double *xstats, lionStream_t stream);
+                           float *dbias, int d_stride, float *pw, const float *A, const double *xstats, const float *gate,
+                           const float *qse, float *Aout, lionStream_t stream);
 /* pw f32[B,C,3]: the per-sample terms of {d GroupNorm weight, d GroupNorm bias, sum over the row of dx}.  The third needs A (of the
  * forward fold) and xstats = the forward's lion_row_stats64 result (column 0 = row sums of x); both NULL: it is written as 0.
  * Summed over the batch it is the BIAS GRADIENT of the convolution that produced x (sum_l dx = A S1 + L Q + R sum_l x): Conv3d layers
  * in front of an AdaGN take it from here instead of a pass over dx (lion_amd/conv_ops.py).
+ * gate / qse f32[B,C] (both or neither; with them A and Aout are required): an SE3d gate sits directly behind this AdaGN and the two
+ * run as one op (lion_gn_se_gate_fwd / _bwd below) -- the upstream gradient was du = g gy + qse, S holds ITS row sums, and the apply
+ * pass gets Aout = A g and Q = A qse + Q_gn: dx = Aout gy + Q + R x.
  * lion_gn_train_param_grads: dgw / dgb / dxs (or NULL) f32[C] = pw summed over the batch (ascending b). */
 int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, float *dxs, lionStream_t stream);
 /* TRAINING, SE3d gate (reference models/pvcnn2_ada.py:27-41: x * sigmoid(W2 relu(W1 mean_voxels(x))), both Linear layers bias-free):
@@ -479,6 +483,18 @@ int lion_se_gate_fwd(const float *stats, const float *w1, const float *w2, int B
                      float *g, float *zero, lionStream_t stream);
 int lion_se_gate_bwd(const float *S, const float *g, const float *h, const float *mean, const float *w1, const float *w2, int B,
                      int C, int Cr, int L, float *dpre2, float *dpre1, float *Q, float *dw1, float *dw2, lionStream_t stream);
+/* The tail of every PVConv's voxel branch is Conv3d -> AdaGN -> SE3d with NO activation between the last two (reference
+ * pvcnn2_ada.py:211-226): both are affine per (sample, channel), so they run as ONE op -- u = A x + Bs is never written.
+ * fwd: xstats f64[B*C,2] (lion_row_stats64 of x), A / Bs (lion_gn_train_fold64) -> mean f32[B,C] (channel means of u), h, g, and
+ * A2 = g A, B2 = g Bs for one lion_affine_act pass (act 0) over x.  bwd: S f32[B*C,2] = {sum gy, sum gy x} (one
+ * lion_affine_act_bwd_stats pass, act 0) -> Qse f32[B,C], Sp f32[B*C,2] (the row sums of du = g gy + Qse that
+ * lion_gn_train_bwd_fold takes, with gate = g, qse = Qse), dpre2 / dpre1 (scratch), dw1, dw2; then one lion_affine_act_bwd_apply
+ * pass with (Aout, Q, R).  3 passes over the grid forward and 5 backward instead of 6 and 10. */
+int lion_gn_se_gate_fwd(const double *xstats, const float *A, const float *Bs, const float *w1, const float *w2, int B, int C, int Cr,
+                        int L, float *mean, float *h, float *g, float *A2, float *B2, lionStream_t stream);
+int lion_gn_se_gate_bwd(const float *S, const double *xstats, const float *A, const float *Bs, const float *g, const float *h,
+                        const float *mean, const float *w1, const float *w2, int B, int C, int Cr, int L, float *Sp, float *dpre2,
+                        float *dpre1, float *Qse, float *dw1, float *dw2, lionStream_t stream);
 int lion_affine_act(const float *x, const float *A, const float *Bs, int rows, int L, int act, float *y,
                     lionStream_t stream);
 int lion_affine_act_bwd_stats(const float *x, const float *gy, const float *A, const float *Bs, int rows, int L, int act,

@@ -103,13 +103,16 @@ SIGNATURES = {
     "lion_gn_train_fold": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "lion_row_stats64": (_i, [_vp, _i, _i, _vp, _vp]),
     "lion_gn_train_fold64": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
-    "lion_gn_train_bwd_fold": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "lion_gn_train_bwd_fold": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp]),
     "lion_gn_train_param_grads": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "lion_adam_chunk": (_i, []),
     "lion_adam_row": (_i, []),
     "lion_adam_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _f, _f, _f, _f, _f, _vp]),
     "lion_se_gate_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lion_se_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lion_gn_se_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lion_gn_se_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_affine_act": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "lion_affine_act_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

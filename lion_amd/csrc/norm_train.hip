@@ -320,7 +320,9 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
                                          const float *__restrict__ gb, const float *__restrict__ fac, int fs, int C,
                                          int G, int L, float *__restrict__ Q, float *__restrict__ R,
                                          float *__restrict__ dfac, float *__restrict__ dbias, int ds, float *__restrict__ pw,
-                                         const float *__restrict__ A, const double *__restrict__ xstats) {
+                                         const float *__restrict__ A, const double *__restrict__ xstats,
+                                         const float *__restrict__ gate, const float *__restrict__ qse,
+                                         float *__restrict__ Aout) {
   extern __shared__ double sh[]; // [2 C]: coef S1, coef T
   const int b = blockIdx.x, c = threadIdx.x, cpg = C / G;
   double s1 = 0.0, T = 0.0, m = 0.0, rs = 0.0, f = 1.0, w = 0.0;
@@ -340,8 +342,11 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
   double a1 = 0.0, a2 = 0.0;
   for (int k = 0; k < cpg; ++k) { a1 += sh[g0 + k]; a2 += sh[C + g0 + k]; }
   const double cnt = (double)cpg * (double)L, m1 = a1 / cnt, m2 = a2 / cnt;
-  Q[(size_t)b * C + c] = (float)(-rs * m1 + rs * rs * m * m2);
+  // gate / qse (an SE3d gate behind this AdaGN, folded into one op): upstream was du = g gy + qse, so dx = (A g) gy + (A qse + Q) + R x
+  const double a_row = A ? (double)A[(size_t)b * C + c] : 0.0;
+  Q[(size_t)b * C + c] = (float)(-rs * m1 + rs * rs * m * m2 + (gate ? a_row * (double)qse[(size_t)b * C + c] : 0.0));
   R[(size_t)b * C + c] = (float)(-rs * rs * m2);
+  if (gate) Aout[(size_t)b * C + c] = (float)(a_row * (double)gate[(size_t)b * C + c]);
   if (dfac) dfac[(size_t)b * ds + c] = (float)(w * T + (double)gb[c] * s1);   // ds: row stride (the two may be the halves of one [B, 2C] buffer)
   if (dbias) dbias[(size_t)b * ds + c] = (float)s1;
   pw[((size_t)b * C + c) * 3] = (float)(f * T);
@@ -358,17 +363,25 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
 // ---- SE3d gate (reference models/pvcnn2_ada.py:27-41: x * sigmoid(W2 relu(W1 mean_voxels(x)))) -- the [B, C] algebra between the
 // row-sum pass and the scaling pass, training form (round 6).  ATen ran it as ~7 tiny launches forward (div, mm, relu, mm,
 // sigmoid, two fills) and ~13 backward per SE layer, 28 layers per VAE step.  One block per sample; C <= 1024, Cr <= 128.
+// GN: the gate sits directly behind an AdaGN WITHOUT activation (the tail of every PVConv's voxel branch: Conv3d -> AdaGN -> SE3d,
+// reference pvcnn2_ada.py:211-226) -- both are affine per (sample, channel), so u = A x + Bs never has to exist: its channel
+// mean is A mean(x) + Bs (xstats = the row sums of x in double), and the gated result is (g A) x + (g Bs): A2 / B2 out.
+template <bool GN>
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float *__restrict__ stats, const float *__restrict__ w1,
                                                           const float *__restrict__ w2, int C, int Cr, float L,
                                                           float *__restrict__ mean, float *__restrict__ h,
-                                                          float *__restrict__ g, float *__restrict__ zero) {
+                                                          float *__restrict__ g, float *__restrict__ zero,
+                                                          const double *__restrict__ xstats, const float *__restrict__ A,
+                                                          const float *__restrict__ Bs, float *__restrict__ A2,
+                                                          float *__restrict__ B2) {
   __shared__ float m[1024], hh[128];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < C; c += 256) {
-    const float v = stats[((size_t)b * C + c) * 2] / L;
+    const size_t row = (size_t)b * C + c;
+    const float v = GN ? (float)((double)A[row] * (xstats[row * 2] / (double)L) + (double)Bs[row]) : stats[row * 2] / L;
     m[c] = v;
-    mean[(size_t)b * C + c] = v;
-    zero[(size_t)b * C + c] = 0.f;
+    mean[row] = v;
+    if (!GN) zero[row] = 0.f;
   }
   __syncthreads();
   for (int j = wave; j < Cr; j += 4) {
@@ -386,22 +399,34 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float *__restric
   for (int c = tid; c < C; c += 256) {
     float acc = 0.f;
     for (int j = 0; j < Cr; ++j) acc = fmaf(hh[j], w2[(size_t)c * Cr + j], acc);
-    g[(size_t)b * C + c] = 1.f / (1.f + expf(-acc));
+    const float gg = 1.f / (1.f + expf(-acc));
+    g[(size_t)b * C + c] = gg;
+    if (GN) {
+      A2[(size_t)b * C + c] = gg * A[(size_t)b * C + c];
+      B2[(size_t)b * C + c] = gg * Bs[(size_t)b * C + c];
+    }
   }
 }
 
 // backward, per sample: dpre2 = dg g (1 - g) with dg = sum_voxels gy x (S[:, 1] of the reduction pass);
 // dpre1 = (dpre2 W2) [h > 0];  Q = (dpre1 W1) / L (the gradient every voxel of a channel receives through the mean)
+// GN (see se_gate_fwd_kernel): S = {sum gy, sum gy x} over the row; the gate's gradient is sum gy u = A S2 + Bs S1, and the row sums
+// the AdaGN backward needs of du = g gy + Qse follow without another pass: S'1 = g S1 + L Qse, S'2 = g S2 + Qse sum x  (Sp out).
+template <bool GN>
 __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restrict__ S, const float *__restrict__ g,
                                                           const float *__restrict__ h, const float *__restrict__ w1,
                                                           const float *__restrict__ w2, int C, int Cr, float L,
                                                           float *__restrict__ dpre2, float *__restrict__ dpre1,
-                                                          float *__restrict__ Q) {
+                                                          float *__restrict__ Q, const double *__restrict__ xstats,
+                                                          const float *__restrict__ A, const float *__restrict__ Bs,
+                                                          float *__restrict__ Sp) {
   __shared__ float s2[1024], s1[128];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; c < C; c += 256) {
-    const float gg = g[(size_t)b * C + c];
-    const float d = S[((size_t)b * C + c) * 2 + 1] * gg * (1.f - gg);
+    const size_t row = (size_t)b * C + c;
+    const float gg = g[row];
+    const float dg = GN ? (float)((double)A[row] * (double)S[row * 2 + 1] + (double)Bs[row] * (double)S[row * 2]) : S[row * 2 + 1];
+    const float d = dg * gg * (1.f - gg);
     s2[c] = d;
     dpre2[(size_t)b * C + c] = d;
   }
@@ -421,7 +446,14 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restric
   for (int c = tid; c < C; c += 256) {
     float acc = 0.f;
     for (int j = 0; j < Cr; ++j) acc = fmaf(s1[j], w1[(size_t)j * C + c], acc);
-    Q[(size_t)b * C + c] = acc / L;
+    const float q = acc / L;
+    Q[(size_t)b * C + c] = q;
+    if (GN) {
+      const size_t row = (size_t)b * C + c;
+      const double gg = (double)g[row];
+      Sp[row * 2] = (float)(gg * (double)S[row * 2] + (double)L * (double)q);
+      Sp[row * 2 + 1] = (float)(gg * (double)S[row * 2 + 1] + (double)q * xstats[row * 2]);
+    }
   }
 }
 
@@ -493,13 +525,15 @@ int lion_gn_train_fold64(const double *stats, const float *gw, const float *gb, 
 
 int lion_gn_train_bwd_fold(const float *S, const float *mean, const float *rstd, const float *gw, const float *gb,
                            const float *fac, int fac_stride, int B, int C, int G, int L, float *Q, float *R, float *dfac,
-                           float *dbias, int d_stride, float *pw, const float *A, const double *xstats, lionStream_t stream) {
+                           float *dbias, int d_stride, float *pw, const float *A, const double *xstats, const float *gate,
+                           const float *qse, float *Aout, lionStream_t stream) {
   if (!S || !mean || !rstd || !gw || !gb || !Q || !R || !pw || B <= 0 || C <= 0 || G <= 0 || C % G || L <= 0) return LION_EINVAL;
   if ((dfac || dbias) && d_stride < C) return LION_EINVAL;
+  if ((gate != nullptr) != (qse != nullptr) || (gate && (!A || !Aout))) return LION_EINVAL;
   if (C > 1024) return LION_EUNSUPPORTED;
   const int T = (C + 63) / 64 * 64;
   gn_train_bwd_fold_kernel<<<B, T, (size_t)2 * C * sizeof(double), static_cast<hipStream_t>(stream)>>>(
-      S, mean, rstd, gw, gb, fac, fac_stride, C, G, L, Q, R, dfac, dbias, d_stride, pw, A, xstats);
+      S, mean, rstd, gw, gb, fac, fac_stride, C, G, L, Q, R, dfac, dbias, d_stride, pw, A, xstats, gate, qse, Aout);
   LION_LAUNCH_CHECK();
   return 0;
 }
@@ -631,7 +665,19 @@ int lion_se_gate_fwd(const float *stats, const float *w1, const float *w2, int B
                      float *g, float *zero, lionStream_t stream) {
   if (!stats || !w1 || !w2 || !mean || !h || !g || !zero || B <= 0 || C <= 0 || Cr <= 0 || L <= 0) return LION_EINVAL;
   if (C > 1024 || Cr > 128) return LION_EUNSUPPORTED;
-  se_gate_fwd_kernel<<<B, 256, 0, static_cast<hipStream_t>(stream)>>>(stats, w1, w2, C, Cr, (float)L, mean, h, g, zero);
+  se_gate_fwd_kernel<false><<<B, 256, 0, static_cast<hipStream_t>(stream)>>>(stats, w1, w2, C, Cr, (float)L, mean, h, g, zero,
+                                                                             nullptr, nullptr, nullptr, nullptr, nullptr);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+// the gate directly behind an AdaGN without activation (see se_gate_fwd_kernel<true>): xstats f64[B*C,2] (lion_row_stats64 of x),
+// A / Bs f32[B,C] of the AdaGN fold -> mean (of u = A x + Bs), h, g, and A2 = g A, B2 = g Bs for ONE lion_affine_act pass over x
+int lion_gn_se_gate_fwd(const double *xstats, const float *A, const float *Bs, const float *w1, const float *w2, int B, int C, int Cr,
+                        int L, float *mean, float *h, float *g, float *A2, float *B2, lionStream_t stream) {
+  if (!xstats || !A || !Bs || !w1 || !w2 || !mean || !h || !g || !A2 || !B2 || B <= 0 || C <= 0 || Cr <= 0 || L <= 0) return LION_EINVAL;
+  if (C > 1024 || Cr > 128) return LION_EUNSUPPORTED;
+  se_gate_fwd_kernel<true><<<B, 256, 0, static_cast<hipStream_t>(stream)>>>(nullptr, w1, w2, C, Cr, (float)L, mean, h, g, nullptr,
+                                                                            xstats, A, Bs, A2, B2);
   LION_LAUNCH_CHECK();
   return 0;
 }
@@ -642,7 +688,23 @@ int lion_se_gate_bwd(const float *S, const float *g, const float *h, const float
     return LION_EINVAL;
   if (C > 1024 || Cr > 128) return LION_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  se_gate_bwd_kernel<<<B, 256, 0, st>>>(S, g, h, w1, w2, C, Cr, (float)L, dpre2, dpre1, Q);
+  se_gate_bwd_kernel<false><<<B, 256, 0, st>>>(S, g, h, w1, w2, C, Cr, (float)L, dpre2, dpre1, Q, nullptr, nullptr, nullptr, nullptr);
+  LION_LAUNCH_CHECK();
+  se_gate_wgrad_kernel<<<dim3(lion_cdiv(C * Cr, 256), 2), 256, 0, st>>>(dpre2, dpre1, h, mean, B, C, Cr, dw1, dw2);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+// backward of the same pair: S f32[B*C,2] = {sum gy, sum gy x} (lion_affine_act_bwd_stats with act = 0) -> Qse (the gate's
+// contribution to du, per row), Sp f32[B*C,2] = the row sums {sum du, sum du x} lion_gn_train_bwd_fold needs, dw1 / dw2
+int lion_gn_se_gate_bwd(const float *S, const double *xstats, const float *A, const float *Bs, const float *g, const float *h,
+                        const float *mean, const float *w1, const float *w2, int B, int C, int Cr, int L, float *Sp, float *dpre2,
+                        float *dpre1, float *Qse, float *dw1, float *dw2, lionStream_t stream) {
+  if (!S || !xstats || !A || !Bs || !g || !h || !mean || !w1 || !w2 || !Sp || !dpre2 || !dpre1 || !Qse || !dw1 || !dw2 || B <= 0 ||
+      C <= 0 || Cr <= 0 || L <= 0)
+    return LION_EINVAL;
+  if (C > 1024 || Cr > 128) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  se_gate_bwd_kernel<true><<<B, 256, 0, st>>>(S, g, h, w1, w2, C, Cr, (float)L, dpre2, dpre1, Qse, xstats, A, Bs, Sp);
   LION_LAUNCH_CHECK();
   se_gate_wgrad_kernel<<<dim3(lion_cdiv(C * Cr, 256), 2), 256, 0, st>>>(dpre2, dpre1, h, mean, B, C, Cr, dw1, dw2);
   LION_LAUNCH_CHECK();

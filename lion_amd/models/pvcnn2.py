@@ -27,6 +27,11 @@ def run_layers(layers, x, reduce_max=False):
         layer = layers[i]
         if isinstance(layer, nn.GroupNorm) and train_ops.usable(x, False) and layer.num_channels <= 1024 and layer.affine:
             fused_act = i + 1 < n and isinstance(layers[i + 1], Swish)
+            if (not fused_act and i + 1 < n and isinstance(layers[i + 1], SE3d) and x.dim() == 5
+                    and train_ops.se3d_trainable(layers[i + 1], x, False)):
+                x = train_ops.adagn_se(x, layer, None, None, layers[i + 1])   # GroupNorm -> SE3d, nothing between: one op
+                i += 2
+                continue
             if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x, False):
                 return train_ops.adagn_act_max(x, layer, None, None, act=fused_act)   # pooled: [B, C, M]
             i += 2 if fused_act else 1

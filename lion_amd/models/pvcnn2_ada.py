@@ -263,6 +263,11 @@ def run_layers(layers, x, style, conv, reduce_max=False):
             if train_ops.usable(x) and layer.n_channel <= 1024:
                 fused_act = i + 1 < n and isinstance(layers[i + 1], Swish)
                 factor, bias = layer.affine(style)
+                if (not fused_act and i + 1 < n and isinstance(layers[i + 1], SE3d) and x.dim() == 5
+                        and train_ops.se3d_trainable(layers[i + 1], x)):
+                    x = train_ops.adagn_se(x, layer.norm, factor, bias, layers[i + 1])   # AdaGN -> SE3d, nothing between: one op
+                    i += 2
+                    continue
                 if reduce_max and i + (2 if fused_act else 1) == n and train_ops.adagn_act_max_usable(x):
                     return train_ops.adagn_act_max(x, layer.norm, factor, bias, act=fused_act)   # pooled: [B, C, M]
                 i += 2 if fused_act else 1

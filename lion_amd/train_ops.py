@@ -187,7 +187,7 @@ class _AdaGNAct(torch.autograd.Function):
         _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
                                               _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
                                               _lib.ptr(dfac), _lib.ptr(dbias), dstride, _lib.ptr(pw), _lib.ptr(A), _lib.ptr(stats),
-                                              st), "gn_train_bwd_fold")
+                                              None, None, None, st), "gn_train_bwd_fold")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -263,8 +263,8 @@ class _AdaGNActMax(torch.autograd.Function):
         pw = torch.empty(B, C, 3, device=dev, dtype=torch.float32)
         _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(S), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
                                               _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
-                                              _lib.ptr(dfac), _lib.ptr(dbias), dstride, _lib.ptr(pw), None, None, st),
-                   "gn_train_bwd_fold")
+                                              _lib.ptr(dfac), _lib.ptr(dbias), dstride, _lib.ptr(pw), None, None, None, None, None,
+                                              st), "gn_train_bwd_fold")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -309,6 +309,100 @@ def fusable_dropout(layers, i):
         if d.p < 1.0 and DROPOUT_FUSED:
             return float(d.p), 1
     return 0.0, 0
+
+
+class _AdaGNSE(torch.autograd.Function):
+    """SE3d(AdaGN(x)) with no activation between the two -- the tail of every PVConv's voxel branch (reference pvcnn2_ada.py:211-226:
+    Conv3d -> AdaGN -> SE3d) -- as ONE differentiable op.  u = A x + Bs (the AdaGN) and y = g u (the gate, g from the channel means
+    of u) are both affine per (sample, channel): forward = row sums of x, the [B, C] algebra (GroupNorm fold, mean(u) = A mean(x) + Bs,
+    the gate), ONE pass y = (g A) x + g Bs; backward = ONE reduction {sum gy, sum gy x}, the [B, C] algebra (the gate's gradient is
+    A S2 + Bs S1; du = g gy + Qse and its row sums follow in closed form; GroupNorm backward), ONE pass dx = (A g) gy + Q + R x.
+    The two separate ops (adagn_act(act=False) -> se3d) make 6 passes over the grid forward and 10 backward."""
+
+    @staticmethod
+    def forward(ctx, x, gw, gb, factor, bias, w1, w2, groups, eps):
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        Cr = w1.shape[0]
+        L = x[0, 0].numel()
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        stats = torch.empty(B * C, 2, device=dev, dtype=torch.float64)
+        _lib.check(lib.lion_row_stats64(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats64")
+        A, Bs, mean, rstd = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(4))
+        gwc, gbc = gw.detach().float().contiguous(), gb.detach().float().contiguous()
+        f, fs = _rowview(factor.detach(), B, C) if factor is not None else (None, 0)
+        bb, bs = _rowview(bias.detach(), B, C) if bias is not None else (None, 0)
+        _lib.check(lib.lion_gn_train_fold64(_lib.ptr(stats), _lib.ptr(gwc), _lib.ptr(gbc), _lib.ptr(f), fs, _lib.ptr(bb), bs,
+                                            B, C, groups, L, eps, _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(mean), _lib.ptr(rstd),
+                                            st), "gn_train_fold64")
+        w1c, w2c = w1.detach().float().contiguous(), w2.detach().float().contiguous()
+        um, g, A2, B2 = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(4))
+        h = torch.empty(B, Cr, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_gn_se_gate_fwd(_lib.ptr(stats), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(w1c), _lib.ptr(w2c), B, C, Cr, L,
+                                           _lib.ptr(um), _lib.ptr(h), _lib.ptr(g), _lib.ptr(A2), _lib.ptr(B2), st), "gn_se_gate_fwd")
+        y = torch.empty_like(x)
+        _lib.check(lib.lion_affine_act(_lib.ptr(x), _lib.ptr(A2), _lib.ptr(B2), B * C, L, 0, _lib.ptr(y), st), "affine_act")
+        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0), stats, um, h, g, w1c, w2c)
+        ctx.meta = (groups, factor is not None, bias is not None, fs,
+                    None if factor is None else factor.shape, None if bias is None else bias.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, A, Bs, mean, rstd, gwc, gbc, f, stats, um, h, g, w1, w2 = ctx.saved_tensors
+        groups, has_f, has_b, fs, f_shape, b_shape = ctx.meta
+        gy = gy.contiguous()
+        B, C = x.shape[:2]
+        Cr = w1.shape[0]
+        L = x[0, 0].numel()
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        S = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_affine_act_bwd_stats(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(A), _lib.ptr(Bs), B * C, L, 0, _lib.ptr(S), st),
+                   "affine_act_bwd_stats")                      # act 0: S = {sum gy, sum gy x}
+        Sp = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
+        dpre2, Qse, Q, R, Aout = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(5))
+        dpre1 = torch.empty(B, Cr, device=dev, dtype=torch.float32)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        _lib.check(lib.lion_gn_se_gate_bwd(_lib.ptr(S), _lib.ptr(stats), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(g), _lib.ptr(h),
+                                           _lib.ptr(um), _lib.ptr(w1), _lib.ptr(w2), B, C, Cr, L, _lib.ptr(Sp), _lib.ptr(dpre2),
+                                           _lib.ptr(dpre1), _lib.ptr(Qse), _lib.ptr(dw1), _lib.ptr(dw2), st), "gn_se_gate_bwd")
+        dfac, dbias, dstride = _affine_grad_buffers(B, C, has_f, has_b, dev)
+        pw = torch.empty(B, C, 3, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(Sp), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
+                                              _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
+                                              _lib.ptr(dfac), _lib.ptr(dbias), dstride, _lib.ptr(pw), _lib.ptr(A), _lib.ptr(stats),
+                                              _lib.ptr(g), _lib.ptr(Qse), _lib.ptr(Aout), st), "gn_train_bwd_fold")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # (act 0: the kernel's Bs argument does not enter)
+            _lib.check(lib.lion_affine_act_bwd_apply(_lib.ptr(x), _lib.ptr(gy), _lib.ptr(Aout), _lib.ptr(Bs), _lib.ptr(Q),
+                                                     _lib.ptr(R), B * C, L, 0, _lib.ptr(dx), st), "affine_act_bwd_apply")
+        dgw, dgb, dxs = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2], dx is not None and x.dim() == 5)
+        if dxs is not None:
+            tag_channel_sum(dx, dxs)
+
+        def back(g_, shape):
+            shape = tuple(int(d) for d in shape)
+            core = shape
+            while len(core) > 2 and core[-1] == 1:
+                core = core[:-1]
+            return g_.sum_to_size(core if core else (1,)).reshape(shape)
+        dfac = back(dfac, f_shape) if has_f and ctx.needs_input_grad[3] else None
+        dbias = back(dbias, b_shape) if has_b and ctx.needs_input_grad[4] else None
+        return (dx, dgw, dgb, dfac, dbias, (dw1 if ctx.needs_input_grad[5] else None), (dw2 if ctx.needs_input_grad[6] else None),
+                None, None)
+
+
+def adagn_se(x, norm, factor, bias, se):
+    """SE3d(GroupNorm(x) * factor + bias) as one op (see _AdaGNSE); `se` passes se3d_trainable."""
+    return _AdaGNSE.apply(x, norm.weight, norm.bias, factor, bias, se.fc[0].weight, se.fc[2].weight, int(norm.num_groups),
+                          float(norm.eps))
 
 
 class _SE3d(torch.autograd.Function):

@@ -594,3 +594,56 @@ def test_training_conv_on_a_voxelised_grid_skips_empty_tiles_exactly(monkeypatch
     with torch.enable_grad():
         conv_ops.conv3d_module(conv, grid.requires_grad_(True))
     assert seen == [False]
+
+
+@pytest.mark.parametrize("B,C,r,ada", [(3, 64, 16, True), (2, 32, 32, True), (4, 128, 8, False), (2, 256, 4, True)])
+def test_adagn_se_as_one_op_matches_the_two_ops_and_float64(B, C, r, ada):
+    """train_ops.adagn_se == se3d(adagn_act(x, act=False)) (the tail of a PVConv's voxel branch, reference pvcnn2_ada.py:211-226) ==
+    the modules' own expressions in float64 autograd: output and all seven gradients"""
+    from lion_amd import train_ops
+    from lion_amd.models.pvcnn2_ada import SE3d
+    torch.manual_seed(B * C + r)
+    norm = torch.nn.GroupNorm(8, C).cuda()
+    se = SE3d(C).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(B, C, r, r, r, device="cuda") * 1.5 + 0.7).requires_grad_(True)
+    factor = (1.0 + 0.3 * torch.randn(B, C, device="cuda")).requires_grad_(True) if ada else None
+    bias = (0.3 * torch.randn(B, C, device="cuda")).requires_grad_(True) if ada else None
+    gy = torch.randn(B, C, r, r, r, device="cuda")
+    leaves = [x, norm.weight, norm.bias, se.fc[0].weight, se.fc[2].weight] + ([factor, bias] if ada else [])
+    y1 = train_ops.adagn_se(x, norm, factor, bias, se)
+    g1 = torch.autograd.grad(y1, leaves, gy)
+    y2 = train_ops.se3d(se, train_ops.adagn_act(x, norm, factor, bias, act=False))
+    g2 = torch.autograd.grad(y2, leaves, gy)
+    # float64 reference of the modules' own arithmetic
+    l64 = [t.detach().double().requires_grad_(True) for t in leaves]
+    u = torch.nn.functional.group_norm(l64[0], 8, l64[1], l64[2], norm.eps)
+    if ada:
+        u = u * l64[5][:, :, None, None, None] + l64[6][:, :, None, None, None]
+    gate = torch.sigmoid(torch.relu(u.mean((2, 3, 4)) @ l64[3].t()) @ l64[4].t())
+    y3 = u * gate[:, :, None, None, None]
+    g3 = torch.autograd.grad(y3, l64, gy.double())
+    names = ["dx", "dgw", "dgb", "dw1", "dw2", "dfactor", "dbias"]
+    tol = lambda ref: 3e-5 * max(ref.abs().max().item(), 1e-3)
+    assert (y1.double() - y3).abs().max().item() <= tol(y3)
+    assert (y1 - y2).abs().max().item() <= 2e-6 * y2.abs().max().item()
+    for n_, a, b_, c in zip(names, g1, g2, g3):
+        assert (a.double() - c).abs().max().item() <= tol(c), ("vs float64", n_)
+        assert (a - b_).abs().max().item() <= 3e-5 * max(b_.abs().max().item(), 1e-3), ("vs the two ops", n_)
+
+
+def test_training_walks_take_the_adagn_se_op():
+    from unittest import mock
+    from lion_amd import train_ops
+    from lion_amd.models import pvcnn2
+    from lion_amd.models.pvcnn2_ada import SE3d
+    layers = torch.nn.ModuleList([torch.nn.GroupNorm(8, 32), SE3d(32)]).cuda()
+    x = torch.randn(2, 32, 8, 8, 8, device="cuda", requires_grad=True)
+    with mock.patch.object(train_ops, "adagn_se", wraps=train_ops.adagn_se) as fused, \
+            mock.patch.object(train_ops, "se3d", wraps=train_ops.se3d) as plain:
+        y = pvcnn2.run_layers(layers, x)
+    assert fused.call_count == 1 and plain.call_count == 0
+    want = layers[1](layers[0](x))
+    assert (y - want).abs().max().item() <= 2e-5 * want.abs().max().item()
