@@ -490,6 +490,17 @@ int lion_se_gate_bwd(const float *S, const float *g, const float *h, const float
  * lion_affine_act_bwd_stats pass, act 0) -> Qse f32[B,C], Sp f32[B*C,2] (the row sums of du = g gy + Qse that
  * lion_gn_train_bwd_fold takes, with gate = g, qse = Qse), dpre2 / dpre1 (scratch), dw1, dw2; then one lion_affine_act_bwd_apply
  * pass with (Aout, Q, R).  3 passes over the grid forward and 5 backward instead of 6 and 10. */
+/* ... and with the devoxelisation behind them (AdaGN -> SE3d -> trilinear_devoxelize, pvcnn2_ada.py:211-233: all linear): the gated
+ * grid is never written either.  Forward: devoxelise x itself, apply (A2, B2) to the [B,C,N] result.  Backward, from the gradient g
+ * f32[B,C,N] of that result: lion_rows_dot2 -> S f32[B*C,2] = {sum_p g ws, sum_p g v} (ws f32[B,N] = each point's 8 corner weights
+ * summed, v = the devoxelised x saved by the forward) = the row sums {sum gy, sum gy x} of the scatter without a pass over the grid;
+ * lion_gn_se_gate_bwd + lion_gn_train_bwd_fold as above; lion_trilinear_devoxelize_backward_affine writes
+ * dx = A' scatter(g) + Q + R x in one pass (slab = Q + R x, corner contributions added in LDS; x 16-byte aligned, r3 * 4 <= 128 KiB,
+ * r3 % 8 == 0).  Dense passes over the grid per PVConv tail: 1 forward (the row sums) and 2 backward -- were 6 + 10 as separate ops. */
+int lion_rows_dot2(const float *g, const float *v, const float *ws, int B, int C, int N, float *S, lionStream_t stream);
+int lion_trilinear_devoxelize_backward_affine(const float *gy, const int32_t *inds, const float *wgts, const float *x,
+                                              const float *Ap, const float *Q, const float *R, int B, int C, int N, int r3,
+                                              float *dx, lionStream_t stream);
 int lion_gn_se_gate_fwd(const double *xstats, const float *A, const float *Bs, const float *w1, const float *w2, int B, int C, int Cr,
                         int L, float *mean, float *h, float *g, float *A2, float *B2, lionStream_t stream);
 int lion_gn_se_gate_bwd(const float *S, const double *xstats, const float *A, const float *Bs, const float *g, const float *h,

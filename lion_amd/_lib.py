@@ -111,6 +111,8 @@ SIGNATURES = {
     "lion_adam_step": (_i, [_vp, _vp, _vp, _i, _i, _vp, _f, _f, _f, _f, _f, _vp]),
     "lion_se_gate_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lion_se_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lion_rows_dot2": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "lion_trilinear_devoxelize_backward_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "lion_gn_se_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_gn_se_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lion_affine_act": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -649,6 +649,47 @@ __global__ __launch_bounds__(1024) void devox_bwd_lds_kernel(const float *__rest
     *reinterpret_cast<float4 *>(o + v) = *reinterpret_cast<const float4 *>(slab + v);
 }
 
+// The same scatter with the AdaGN(+SE) backward's elementwise pass folded in (training, round 6): the voxel branch of a PVConv ends
+// AdaGN -> SE3d -> devoxelize, all linear, so the gradient of the AdaGN's INPUT x is
+//     dx = A' scatter(gy) + Q + R x        (A', Q, R f32[B, C] from lion_gn_train_bwd_fold with the gate)
+// and the dense gradient of the devoxelisation never has to exist: the slab starts as Q + R x (one read of x) instead of zeros,
+// the corner contributions are added scaled by A', the slab is stored (one write of dx).  Was: store the scatter, read it twice
+// with x (reduction + apply), store dx.
+__global__ __launch_bounds__(1024) void devox_bwd_affine_kernel(const float *__restrict__ gy, const int32_t *__restrict__ inds,
+                                                                const float *__restrict__ wgts, const float *__restrict__ x,
+                                                                const float *__restrict__ Ap, const float *__restrict__ Q,
+                                                                const float *__restrict__ R, int C, int N, int r3,
+                                                                float *__restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *slab = reinterpret_cast<float *>(smem);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int part = r3 / gridDim.z, lo = blockIdx.z * part;
+  const size_t row = (size_t)b * C + c;
+  const float a = Ap[row], q = Q[row], rr = R[row];
+  const float *xr = x + row * r3 + lo;
+  for (int v = tid * 4; v < part; v += nt * 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(xr + v);
+    *reinterpret_cast<float4 *>(slab + v) = make_float4(q + rr * t.x, q + rr * t.y, q + rr * t.z, q + rr * t.w);
+  }
+  __syncthreads();
+  const float *g = gy + row * N;
+  const int32_t *id = inds + (size_t)b * 8 * N;
+  const float *wg = wgts + (size_t)b * 8 * N;
+  for (int i = tid; i < N; i += nt) {
+    const float gv = a * g[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ix = min(max(id[(size_t)k * N + i], 0), r3 - 1) - lo;
+      if (ix >= 0 && ix < part) atomicAdd(slab + ix, mul_rn(wg[(size_t)k * N + i], gv)); // ds_add_f32
+    }
+  }
+  __syncthreads();
+  float *o = dx + row * r3 + lo;
+  for (int v = tid * 4; v < part; v += nt * 4)
+    *reinterpret_cast<float4 *>(o + v) = *reinterpret_cast<const float4 *>(slab + v);
+}
+
 // Fallback for slabs that do not fit LDS (r^3 * 4 > 128 KiB or r^3 % 4 != 0).
 __global__ void devox_bwd_atomic_kernel(const float *__restrict__ gy,
                                         const int32_t *__restrict__ inds,
@@ -848,6 +889,23 @@ int lion_trilinear_devoxelize_backward(const float *gy, const int32_t *inds, con
   const int CT = 8;
   devox_bwd_atomic_kernel<<<dim3(lion_cdiv(N, 256), lion_cdiv(C, CT), B), 256, 0, st>>>(
       gy, inds, wgts, C, N, r3, CT, gx);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+// dx f32[B,C,r3] = A' scatter(gy) + Q + R x  (see devox_bwd_affine_kernel); x f32[B,C,r3] 16-byte aligned, r3 * 4 <= 128 KiB, r3 % 8 == 0
+int lion_trilinear_devoxelize_backward_affine(const float *gy, const int32_t *inds, const float *wgts, const float *x,
+                                              const float *Ap, const float *Q, const float *R, int B, int C, int N, int r3,
+                                              float *dx, lionStream_t stream) {
+  if (!gy || !inds || !wgts || !x || !Ap || !Q || !R || !dx || B <= 0 || C <= 0 || N <= 0 || r3 <= 0) return LION_EINVAL;
+  if ((size_t)r3 * 4 > 128 * 1024 || (r3 % 8) != 0 || (((uintptr_t)x | (uintptr_t)dx) & 15) != 0) return LION_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int parts = (size_t)r3 * 4 > 64 * 1024 ? 2 : 1;
+  const size_t lds = (size_t)(r3 / parts) * 4;
+  static LionLdsLimit configured = {};
+  if (int e = lion_dynamic_lds(&devox_bwd_affine_kernel, lds, configured)) return e;
+  const int nt = r3 >= 16384 ? 1024 : 256;
+  devox_bwd_affine_kernel<<<dim3(C, B, parts), nt, lds, st>>>(gy, inds, wgts, x, Ap, Q, R, C, N, r3, dx);
   LION_LAUNCH_CHECK();
   return 0;
 }

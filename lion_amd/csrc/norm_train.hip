@@ -360,6 +360,26 @@ __global__ void gn_train_bwd_fold_kernel(const float *__restrict__ S, const floa
 
 } // namespace
 
+// S[row] = {sum_p g[row][p] ws[b][p], sum_p g[row][p] v[row][p]}: the two row sums of the AdaGN(+SE) backward when the upstream
+// gradient is a devoxelisation's scatter of g (ws = the 8 corner weights of point p summed, v = the devoxelised input): one wave
+// per row of N points instead of a pass over the r^3 grid (lion_amd/train_ops.py::adagn_se_devox)
+__global__ __launch_bounds__(256) void rows_dot2_kernel(const float *__restrict__ g, const float *__restrict__ v,
+                                                        const float *__restrict__ ws, int rows, int C, int N,
+                                                        float *__restrict__ S) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float *gr = g + (size_t)row * N, *vr = v + (size_t)row * N, *wr = ws + (size_t)(row / C) * N;
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = lane; p < N; p += 64) {
+    const float t = gr[p];
+    s1 = fmaf(t, wr[p], s1);
+    s2 = fmaf(t, vr[p], s2);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (lane == 0) { S[(size_t)row * 2] = s1; S[(size_t)row * 2 + 1] = s2; }
+}
+
 // ---- SE3d gate (reference models/pvcnn2_ada.py:27-41: x * sigmoid(W2 relu(W1 mean_voxels(x)))) -- the [B, C] algebra between the
 // row-sum pass and the scaling pass, training form (round 6).  ATen ran it as ~7 tiny launches forward (div, mm, relu, mm,
 // sigmoid, two fills) and ~13 backward per SE layer, 28 layers per VAE step.  One block per sample; C <= 1024, Cr <= 128.
@@ -657,6 +677,14 @@ int lion_affine_act_max_bwd_apply(const float *x, const float *gy, const float *
 int lion_gn_train_param_grads(const float *pw, int B, int C, float *dgw, float *dgb, float *dxs, lionStream_t stream) {
   if (!pw || !dgw || !dgb || B <= 0 || C <= 0) return LION_EINVAL;
   pw_batch_sum_kernel<<<lion_cdiv(C, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(pw, B, C, dgw, dgb, dxs);
+  LION_LAUNCH_CHECK();
+  return 0;
+}
+
+int lion_rows_dot2(const float *g, const float *v, const float *ws, int B, int C, int N, float *S, lionStream_t stream) {
+  if (!g || !v || !ws || !S || B <= 0 || C <= 0 || N <= 0) return LION_EINVAL;
+  const int rows = B * C;
+  rows_dot2_kernel<<<lion_cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(g, v, ws, rows, C, N, S);
   LION_LAUNCH_CHECK();
   return 0;
 }

@@ -95,8 +95,17 @@ class PVConv(nn.Module):
         assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2]
         assert coords.shape[1] == 3, f'expect coords: B,3,Npoint, get: {coords.shape}'
         grid, voxel_coords = self.voxelization(features, coords)
-        grid = run_layers(self.voxel_layers, grid)
-        fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
+        layers = list(self.voxel_layers)
+        from .. import train_ops
+        if (self.training and len(layers) >= 2 and isinstance(layers[-1], SE3d) and isinstance(layers[-2], nn.GroupNorm)
+                and layers[-2].affine and train_ops.usable(grid) and layers[-2].num_channels <= 1024
+                and train_ops.adagn_se_devox_usable(grid, layers[-1])):
+            grid = run_layers(layers[:-2], grid)   # GroupNorm -> SE3d -> devoxelize: one op (train_ops._AdaGNSEDevox)
+            fused = train_ops.adagn_se_devox(grid, layers[-2], None, None, layers[-1], voxel_coords, self.resolution)
+            grid = None   # the gated grid does not exist in this form (it only fed the debug payload below)
+        else:
+            grid = run_layers(layers, grid)
+            fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
         if self.add_point_feat:
             fused = fused + self.point_features(features)
         if self.attn is not None:

@@ -475,8 +475,17 @@ class PVConv(nn.Module):
             if self.attn is not None:
                 fused = self.attn(fused)
             return fused, coords_input, time_emb, style
-        grid = run_layers(list(self.voxel_layers), grid, style, conv3d_module)  # convs: fp32-MFMA implicit GEMM (csrc/conv3d.hip)
-        fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
+        layers = list(self.voxel_layers)
+        from .. import train_ops
+        if (self.training and len(layers) >= 2 and isinstance(layers[-1], SE3d) and isinstance(layers[-2], AdaGN)
+                and train_ops.usable(grid) and layers[-2].n_channel <= 1024 and train_ops.adagn_se_devox_usable(grid, layers[-1])):
+            # ... AdaGN -> SE3d -> devoxelize: one op, no gated grid, no dense gradient of the devoxelisation (train_ops._AdaGNSEDevox)
+            grid = run_layers(layers[:-2], grid, style, conv3d_module)
+            factor, bias = layers[-2].affine(style)
+            fused = train_ops.adagn_se_devox(grid, layers[-2].norm, factor, bias, layers[-1], voxel_coords, self.resolution)
+        else:
+            grid = run_layers(layers, grid, style, conv3d_module)  # convs: fp32-MFMA implicit GEMM (csrc/conv3d.hip)
+            fused = F.trilinear_devoxelize(grid, voxel_coords, self.resolution, self.training)
         if self.add_point_feat:
             fused = fused + self.point_features(features, style)
         if self.attn is not None:

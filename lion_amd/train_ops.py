@@ -21,6 +21,7 @@ PWCONV = os.environ.get("LION_TRAIN_PWCONV", "1") != "0"   # 1x1 convolutions of
 # The last number is the global prior's 2048-wide layers on [32, C, 1, 1] activations (32 columns: a weight-streaming skinny
 # GEMM, not what these kernels are tiled for): they stay on the rocBLAS matrix product, everything from 512 columns on is ours.
 PWCONV_MIN_COLS = int(os.environ.get("LION_TRAIN_PWCONV_MIN_COLS", "512"))
+DEVOX_FUSED = os.environ.get("LION_TRAIN_DEVOX_FUSED", "1") != "0"       # AdaGN -> SE3d -> devoxelize as one op (PVConv tail)
 DROPOUT_FUSED = os.environ.get("LION_TRAIN_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind AdaGN + Swish inside the activation pass
 
 
@@ -397,6 +398,109 @@ class _AdaGNSE(torch.autograd.Function):
         dbias = back(dbias, b_shape) if has_b and ctx.needs_input_grad[4] else None
         return (dx, dgw, dgb, dfac, dbias, (dw1 if ctx.needs_input_grad[5] else None), (dw2 if ctx.needs_input_grad[6] else None),
                 None, None)
+
+
+class _AdaGNSEDevox(torch.autograd.Function):
+    """trilinear_devoxelize(SE3d(AdaGN(x)), coords) -- the whole tail of a PVConv's voxel branch behind its second convolution
+    (reference pvcnn2_ada.py:211-233) -- as ONE differentiable op.  All three are linear in x given the [B, C] scalars, and the
+    devoxelisation's weights sum to one per point, so devox(g (A x + Bs)) = (g A) devox(x) + g Bs: the forward devoxelises x itself
+    and never writes a gated grid; the backward gets its two row sums from the POINTS (sum_p gpt ws, sum_p gpt devox(x): no pass over
+    the grid) and writes dx = A' scatter(gpt) + Q + R x inside the scatter's own pass.  Dense passes over [B, C, r^3]: 1 forward
+    (the GroupNorm row sums), 2 backward (read x, write dx); _AdaGNSE followed by the devoxelisation makes 3 and 6."""
+
+    @staticmethod
+    def forward(ctx, x, gw, gb, factor, bias, w1, w2, coords, groups, eps, r):
+        from .functional import backend as _bk
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        Cr = w1.shape[0]
+        L = x[0, 0].numel()
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        stats = torch.empty(B * C, 2, device=dev, dtype=torch.float64)
+        _lib.check(lib.lion_row_stats64(_lib.ptr(x), B * C, L, _lib.ptr(stats), st), "row_stats64")
+        A, Bs, mean, rstd = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(4))
+        gwc, gbc = gw.detach().float().contiguous(), gb.detach().float().contiguous()
+        f, fs = _rowview(factor.detach(), B, C) if factor is not None else (None, 0)
+        bb, bs = _rowview(bias.detach(), B, C) if bias is not None else (None, 0)
+        _lib.check(lib.lion_gn_train_fold64(_lib.ptr(stats), _lib.ptr(gwc), _lib.ptr(gbc), _lib.ptr(f), fs, _lib.ptr(bb), bs,
+                                            B, C, groups, L, eps, _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(mean), _lib.ptr(rstd),
+                                            st), "gn_train_fold64")
+        w1c, w2c = w1.detach().float().contiguous(), w2.detach().float().contiguous()
+        um, g, A2, B2 = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(4))
+        h = torch.empty(B, Cr, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_gn_se_gate_fwd(_lib.ptr(stats), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(w1c), _lib.ptr(w2c), B, C, Cr, L,
+                                           _lib.ptr(um), _lib.ptr(h), _lib.ptr(g), _lib.ptr(A2), _lib.ptr(B2), st), "gn_se_gate_fwd")
+        dv, inds, wgts = _bk._backend.trilinear_devoxelize_forward(int(r), True, coords[:, :3].contiguous(), x.flatten(2))
+        out = torch.addcmul(B2.unsqueeze(-1), dv, A2.unsqueeze(-1))          # [B, C, N]: (g A) devox(x) + g Bs
+        wsum = wgts.sum(1)                                                     # [B, N]: the 8 corner weights of a point
+        ctx.save_for_backward(x, A, Bs, mean, rstd, gwc, gbc, f if f is not None else x.new_empty(0), stats, um, h, g, w1c, w2c,
+                              dv, inds, wgts, wsum)
+        ctx.meta = (groups, factor is not None, bias is not None, fs,
+                    None if factor is None else factor.shape, None if bias is None else bias.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gpt):
+        lib = _lib.load()
+        x, A, Bs, mean, rstd, gwc, gbc, f, stats, um, h, g, w1, w2, dv, inds, wgts, wsum = ctx.saved_tensors
+        groups, has_f, has_b, fs, f_shape, b_shape = ctx.meta
+        gpt = gpt.contiguous()
+        B, C = x.shape[:2]
+        Cr = w1.shape[0]
+        L = x[0, 0].numel()
+        N = gpt.shape[2]
+        st = _lib.stream_ptr(x.device)
+        dev = x.device
+        S = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_rows_dot2(_lib.ptr(gpt), _lib.ptr(dv), _lib.ptr(wsum), B, C, N, _lib.ptr(S), st), "rows_dot2")
+        Sp = torch.empty(B * C, 2, device=dev, dtype=torch.float32)
+        dpre2, Qse, Q, R, Aout = (torch.empty(B, C, device=dev, dtype=torch.float32) for _ in range(5))
+        dpre1 = torch.empty(B, Cr, device=dev, dtype=torch.float32)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        _lib.check(lib.lion_gn_se_gate_bwd(_lib.ptr(S), _lib.ptr(stats), _lib.ptr(A), _lib.ptr(Bs), _lib.ptr(g), _lib.ptr(h),
+                                           _lib.ptr(um), _lib.ptr(w1), _lib.ptr(w2), B, C, Cr, L, _lib.ptr(Sp), _lib.ptr(dpre2),
+                                           _lib.ptr(dpre1), _lib.ptr(Qse), _lib.ptr(dw1), _lib.ptr(dw2), st), "gn_se_gate_bwd")
+        dfac, dbias, dstride = _affine_grad_buffers(B, C, has_f, has_b, dev)
+        pw = torch.empty(B, C, 3, device=dev, dtype=torch.float32)
+        _lib.check(lib.lion_gn_train_bwd_fold(_lib.ptr(Sp), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gwc), _lib.ptr(gbc),
+                                              _lib.ptr(f) if has_f else None, fs, B, C, groups, L, _lib.ptr(Q), _lib.ptr(R),
+                                              _lib.ptr(dfac), _lib.ptr(dbias), dstride, _lib.ptr(pw), _lib.ptr(A), _lib.ptr(stats),
+                                              _lib.ptr(g), _lib.ptr(Qse), _lib.ptr(Aout), st), "gn_train_bwd_fold")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(lib.lion_trilinear_devoxelize_backward_affine(_lib.ptr(gpt), _lib.ptr(inds), _lib.ptr(wgts), _lib.ptr(x),
+                                                                     _lib.ptr(Aout), _lib.ptr(Q), _lib.ptr(R), B, C, N, L,
+                                                                     _lib.ptr(dx), st), "trilinear_devoxelize_backward_affine")
+        dgw, dgb, dxs = _param_grads(pw, ctx.needs_input_grad[1], ctx.needs_input_grad[2], dx is not None and x.dim() == 5)
+        if dxs is not None:
+            tag_channel_sum(dx, dxs)
+
+        def back(g_, shape):
+            shape = tuple(int(d) for d in shape)
+            core = shape
+            while len(core) > 2 and core[-1] == 1:
+                core = core[:-1]
+            return g_.sum_to_size(core if core else (1,)).reshape(shape)
+        dfac = back(dfac, f_shape) if has_f and ctx.needs_input_grad[3] else None
+        dbias = back(dbias, b_shape) if has_b and ctx.needs_input_grad[4] else None
+        return (dx, dgw, dgb, dfac, dbias, (dw1 if ctx.needs_input_grad[5] else None), (dw2 if ctx.needs_input_grad[6] else None),
+                None, None, None, None)
+
+
+def adagn_se_devox_usable(x, se) -> bool:
+    r3 = x[0, 0].numel() if x.dim() == 5 else 0
+    return (DEVOX_FUSED and x.dim() == 5 and se3d_trainable(se, x) and torch.is_grad_enabled() and 0 < r3 * 4 <= 128 * 1024
+            and r3 % 8 == 0)
+
+
+def adagn_se_devox(x, norm, factor, bias, se, coords, r):
+    """trilinear_devoxelize(SE3d(GroupNorm(x) * factor + bias), coords, r) as one op (see _AdaGNSEDevox)"""
+    return _AdaGNSEDevox.apply(x, norm.weight, norm.bias, factor, bias, se.fc[0].weight, se.fc[2].weight, coords.detach(),
+                               int(norm.num_groups), float(norm.eps), int(r))
 
 
 def adagn_se(x, norm, factor, bias, se):

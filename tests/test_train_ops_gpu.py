@@ -647,3 +647,57 @@ def test_training_walks_take_the_adagn_se_op():
     assert fused.call_count == 1 and plain.call_count == 0
     want = layers[1](layers[0](x))
     assert (y - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("B,C,r,N,ada", [(3, 64, 16, 1024, True), (2, 32, 32, 2048, True), (4, 128, 8, 256, False)])
+def test_adagn_se_devox_as_one_op_matches_the_chain(B, C, r, N, ada):
+    """train_ops.adagn_se_devox == trilinear_devoxelize(adagn_se(x)) (the tail of a PVConv's voxel branch, reference
+    pvcnn2_ada.py:211-233): output and all gradients, against the validated two-op chain and its float64 meaning"""
+    from lion_amd import functional as F
+    from lion_amd import train_ops
+    from lion_amd.models.pvcnn2_ada import SE3d
+    torch.manual_seed(B + C + r)
+    norm = torch.nn.GroupNorm(8, C).cuda()
+    se = SE3d(C).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(B, C, r, r, r, device="cuda") * 1.5 + 0.7).requires_grad_(True)
+    factor = (1.0 + 0.3 * torch.randn(B, C, device="cuda")).requires_grad_(True) if ada else None
+    bias = (0.3 * torch.randn(B, C, device="cuda")).requires_grad_(True) if ada else None
+    coords = torch.rand(B, 3, N, device="cuda") * (r - 1)                  # voxel units, some exactly on the border
+    coords[:, :, :4] = torch.tensor([0.0, r - 1.0, 0.5, r - 1.5], device="cuda")
+    gpt = torch.randn(B, C, N, device="cuda")
+    leaves = [x, norm.weight, norm.bias, se.fc[0].weight, se.fc[2].weight] + ([factor, bias] if ada else [])
+    assert train_ops.adagn_se_devox_usable(x, se)
+    y1 = train_ops.adagn_se_devox(x, norm, factor, bias, se, coords, r)
+    g1 = torch.autograd.grad(y1, leaves, gpt)
+    y2 = F.trilinear_devoxelize(train_ops.adagn_se(x, norm, factor, bias, se), coords, r, True)
+    g2 = torch.autograd.grad(y2, leaves, gpt)
+    names = ["dx", "dgw", "dgb", "dw1", "dw2", "dfactor", "dbias"]
+    assert (y1 - y2).abs().max().item() <= 3e-6 * y2.abs().max().item()
+    for n_, a, b_ in zip(names, g1, g2):
+        assert (a - b_).abs().max().item() <= 3e-5 * max(b_.abs().max().item(), 1e-3), n_
+
+
+def test_pvconv_training_takes_the_one_op_tail(monkeypatch):
+    """both PVConv classes hand [.., AdaGN / GroupNorm, SE3d] + devoxelize to ONE op in training; same result as the layer-by-layer walk"""
+    from unittest import mock
+    from lion_amd import train_ops
+    from lion_amd.models import pvcnn2
+    torch.manual_seed(4)
+    pv = pvcnn2.PVConv(32, 32, 3, 16, with_se=True, attention=False, dropout=0.0, verbose=False).cuda().train()
+    feat = torch.randn(2, 32, 512, device="cuda", requires_grad=True)
+    coords = torch.randn(2, 3, 512, device="cuda")
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(train_ops, "DEVOX_FUSED", fused)
+        pv.zero_grad()
+        feat.grad = None
+        with mock.patch.object(train_ops, "adagn_se_devox", wraps=train_ops.adagn_se_devox) as spy:
+            y = pv((feat, coords, None))[0]
+        assert spy.call_count == (1 if fused else 0)
+        y.square().mean().backward()
+        outs.append([y.detach().clone(), feat.grad.clone()] + [p.grad.clone() for p in pv.parameters()])
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 3e-5 * max(b.abs().max().item(), 1e-4)
